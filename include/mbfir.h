@@ -1,0 +1,142 @@
+/*
+ * mbfir.h -- C ABI of the MI355X-native convex FIR / SLR beta-polynomial designer.
+ *
+ * Drop-in boundary for the four convex designers of
+ * shanghong/Multiband-RF-pulse-Design.  Each mbfir_*_solve() replaces the body
+ * of one reference function from "create optimisation arrays" to "return taps"
+ * -- i.e. problem assembly, the external solver call (CVX / linprog / quadprog)
+ * and the tap extraction -- and is what a MEX gateway (matlab/mbfir_mex.c) or a
+ * ctypes binding (the Python host mirror in this repository) binds to:
+ *
+ *   mbfir_ap_solve         <- [h,status] = fir_ap_cvx(n,f,a,d,obj,Peak,dbg)   reference fir_ap_cvx.m:1,44-202
+ *   mbfir_qp_solve         <- [h,status] = fir_qp_cvx(n,f,a,d,k,obj,dbg)      reference fir_qp_cvx.m:1,34-209
+ *   mbfir_linprog_solve    <- [h,status] = fir_linprog(n,f,a,d,h0,dbg)        reference ss/fir_linprog.m:2,46-271
+ *   mbfir_qprog_phs_solve  <- [h,status] = fir_qprog_phs(n,f,ac,dc,x0,dbg)    reference ss/fir_qprog_phs.m:1,49-394
+ *
+ * Conventions (from the reference's MEX precedent rf_tools/mex5/b2a.c:31-68,
+ * abrx.c:35-62: plain double arrays, separate real/imaginary planes):
+ *   - all arrays are caller-owned, contiguous double; complex data is passed as
+ *     separate re/im arrays; `f` has 2*nband entries in [-1,1], `a` 2*nband, `d` nband;
+ *   - taps are written to h_re/h_im (n entries each, caller-allocated);
+ *   - nothing throws across the ABI, nothing calls exit(); the context is
+ *     reusable across calls (bisection wrappers call ~10 times in a row) and is
+ *     not thread-safe (distinct contexts are).
+ *
+ * Return codes of the solve functions:
+ *    0  MBFIR_SOLVED        status 'Solved'   (taps written)
+ *    1  MBFIR_INFEASIBLE    status 'Failed'   (primal/dual infeasibility certificate found)
+ *    2  MBFIR_NUMERICAL     status 'Failed'   (iteration limit / numerical breakdown)
+ *    3  MBFIR_EARLY_FAIL    status 'Failed'   (reference returns Failed before solving,
+ *                                              ss/fir_linprog.m:66-75, ss/fir_qprog_phs.m:193-202)
+ *   <0  usage / HIP error; mbfir_last_error(ctx) holds the message
+ *       -1 MBFIR_E_ARG (the reference's error() cases), -2 MBFIR_E_HIP, -3 MBFIR_E_NODEVICE
+ */
+#ifndef MBFIR_H
+#define MBFIR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBFIR_SOLVED 0
+#define MBFIR_INFEASIBLE 1
+#define MBFIR_NUMERICAL 2
+#define MBFIR_EARLY_FAIL 3
+#define MBFIR_E_ARG (-1)
+#define MBFIR_E_HIP (-2)
+#define MBFIR_E_NODEVICE (-3)
+
+typedef struct mbfir_ctx mbfir_ctx;
+
+/* Solver options.  Zero-initialise (or call mbfir_default_opts) for the defaults. */
+typedef struct mbfir_opts {
+    int grid_m;        /* number of linspace samples of the frequency grid; 0 = the reference's
+                          rule (2*n*15 ap, 10*n qp, 15*n|30*n linprog, 30*n qprog_phs)        */
+    int max_iter;      /* 0 -> 200 */
+    double feastol;    /* 0 -> 1e-8  relative primal/dual residual                              */
+    double abstol;     /* 0 -> 1e-10 absolute gap                                               */
+    double reltol;     /* 0 -> 1e-8  relative gap                                               */
+    int refine;        /* -1 -> 2  iterative-refinement sweeps per KKT solve                    */
+    int verbose;       /* 1: one line per IPM iteration on stderr                               */
+    int shard_rank;    /* frequency-row sharding (multi-GPU): this process's rank ...           */
+    int shard_size;    /* ... out of shard_size (0 or 1 = not sharded)                          */
+} mbfir_opts;
+
+/* Per-solve report. */
+typedef struct mbfir_info {
+    int status;        /* same as the return code */
+    int iters;         /* IPM iterations */
+    int n_unknowns;    /* N  (columns of the conic program) */
+    int n_rows;        /* R  (rows of G) */
+    int n_freq;        /* M_f (distinct frequency rows of the trig matrix) */
+    int n_lp, n_q3, n_big;
+    double pcost, dcost, gap, relgap, pres, dres;
+    double ms_assemble, ms_solve, ms_post, ms_total;   /* host wall-clock */
+    double ms_gram, ms_chol;                           /* device time (HIP events), summed over iterations */
+    double gram_flop;                                  /* algorithmic flop of ONE scaled-Gram launch set */
+} mbfir_info;
+
+/* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to
+ * `count` doubles on the context's stream-ordered memory; op 0 = sum, 1 = max.  The hook must
+ * return after the reduction is complete and visible to the device (0 = ok).  The Python host
+ * wires this to torch.distributed (RCCL over xGMI). */
+typedef int (*mbfir_allreduce_fn)(void* buf, long count, int op, void* user);
+
+mbfir_ctx*  mbfir_create(int device_id);
+void        mbfir_destroy(mbfir_ctx* ctx);
+const char* mbfir_last_error(mbfir_ctx* ctx);
+void        mbfir_default_opts(mbfir_opts* opts);
+void        mbfir_set_allreduce(mbfir_ctx* ctx, mbfir_allreduce_fn fn, void* user);
+const char* mbfir_version(void);
+
+int mbfir_ap_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a,
+                   const double* d, double obj, double peak, const mbfir_opts* opts,
+                   double* h_re, double* h_im, mbfir_info* info);
+
+int mbfir_qp_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a,
+                   const double* d, double kquad, const double* obj, int nobj,
+                   const mbfir_opts* opts, double* h_re, double* h_im, mbfir_info* info);
+
+int mbfir_linprog_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a,
+                        const double* d, const mbfir_opts* opts,
+                        double* h_re, double* h_im, mbfir_info* info);
+
+int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f,
+                          const double* ac_re, const double* ac_im,
+                          const double* dc_re, const double* dc_im, const mbfir_opts* opts,
+                          double* h_re, double* h_im, mbfir_info* info);
+
+/* ---- introspection / test hooks (host only unless stated) --------------------------------
+ * mbfir_assemble(): run the product's problem assembly for designer `which`
+ *   (0 ap, 1 qp, 2 linprog, 3 qprog_phs) WITHOUT touching the GPU and return an opaque
+ *   program; the accessors below expose its structured rows so tests can expand them to the
+ *   dense (c,G,h) and compare with the oracle.  p1..: designer scalars (ap: obj,peak;
+ *   qp: kquad,obj0,obj1,nobj).  For qprog_phs `a`,`d` hold interleaved re,im pairs.      */
+typedef struct mbfir_program mbfir_program;
+int  mbfir_assemble(int which, int n, int nband, const double* f, const double* a, const double* d,
+                    const double* params, int grid_m, mbfir_program** out, char* err, int errlen);
+void mbfir_program_free(mbfir_program* p);
+/* dims[0..9] = Nt, Ne, R, l, nq3, big, Mf, quad(0/1), nnz_id, reserved */
+void mbfir_program_dims(const mbfir_program* p, int* dims);
+/* w[Mf]; col_kind[Nt] (0 cos,1 sin); col_tau[Nt]; col_scale[Nt]; pcol[Nt]; psign[Nt]; c[N]     */
+void mbfir_program_trig(const mbfir_program* p, double* w, int* col_kind, double* col_tau,
+                        double* col_scale, int* pcol, double* psign, double* c);
+/* per row: freq (or -1), col (or -1), alpha, beta, ey[3], h                                     */
+void mbfir_program_rows(const mbfir_program* p, int* freq, int* col, double* alpha, double* beta,
+                        double* ey, double* h);
+
+/* Device kernel test hooks (need a GPU; host arrays in, host arrays out):
+ *  mbfir_test_gram: T = A' diag(dk) A for nw weight vectors; A is m x nt row-major,
+ *     d is nw x m, out is nw x nt x nt (full symmetric).
+ *  mbfir_test_chol: M = inv(chol(H)) for SPD H (n x n); out_l = L, out_m = L^-1 (row-major, lower).
+ *  mbfir_test_specfact: x(2n-1) -> taps (n) through the device fmp2/mag2mp.
+ *  mbfir_test_mfma_peak: measured fp64 MFMA rate, TFLOP/s (bench.py roofline peak).            */
+int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, const double* d, double* out);
+int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m);
+int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im);
+int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tflops_f64_mfma, double* tflops_f64_valu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

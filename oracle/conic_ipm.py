@@ -1,0 +1,398 @@
+"""Oracle solver core (test infrastructure, see oracle/__init__.py).
+
+Dense primal-dual interior-point method for
+
+    minimise c'x   s.t.  G x + s = h,  s in K = R_+^l x Q_3^nq3 x Q_big
+
+written from the published mathematics, not from any file of the reference
+(the reference delegates this step to CVX/SDPT3, linprog and quadprog, which
+are not vendored -- fir_ap_cvx.m:160-169, fir_qp_cvx.m:145-191,
+ss/fir_linprog.m:245-251, ss/fir_qprog_phs.m:339-342):
+
+  * homogeneous self-dual embedding (tau, kappa) so that infeasible
+    instances end with a Farkas certificate instead of diverging
+    (L. Vandenberghe, "The CVXOPT linear and quadratic cone program solvers",
+    2010, section 6-7; A. Domahidi et al., "ECOS", ECC 2013);
+  * Nesterov-Todd scaling for the second-order cones;
+  * Mehrotra predictor-corrector, step fraction 0.99, sigma=(1-alpha_aff)^3;
+  * KKT systems reduced to the normal equations  (G' W^-2 G) dx = rhs  and
+    solved by dense Cholesky, with one or two steps of iterative refinement
+    on the un-regularised reduced system.
+
+The product's HIP solver implements the same iteration (same initial point,
+same step rule, same stopping rule), so the two agree to rounding and the
+parity tests can compare taps at 1e-6 relative l-inf.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+STEP = 0.99
+STATUS_OPTIMAL = 0
+STATUS_PRIMAL_INFEASIBLE = 1
+STATUS_DUAL_INFEASIBLE = 2
+STATUS_MAXIT = 3
+STATUS_NUMERICAL = 4
+
+
+class _Cone:
+    """K = R_+^l x Q_3^nq3 x Q_big acting on flat vectors of length R."""
+
+    def __init__(self, l, nq3, big):
+        self.l, self.nq3, self.big = l, nq3, big
+        self.o3 = l
+        self.ob = l + 3 * nq3
+        self.R = self.ob + big
+        self.degree = l + nq3 + (1 if big else 0)
+
+    def split(self, v):
+        return (v[: self.l], v[self.o3:self.ob].reshape(self.nq3, 3), v[self.ob:])
+
+    def e(self):
+        v = np.zeros(self.R)
+        v[: self.l] = 1.0
+        v[self.o3:self.ob:3] = 1.0
+        if self.big:
+            v[self.ob] = 1.0
+        return v
+
+    def min_residual(self, v):
+        """max over cones of -(distance inside): <0 means strictly interior."""
+        vl, vq, vb = self.split(v)
+        t = -np.inf
+        if self.l:
+            t = max(t, -vl.min())
+        if self.nq3:
+            t = max(t, (np.hypot(vq[:, 1], vq[:, 2]) - vq[:, 0]).max())
+        if self.big:
+            t = max(t, np.linalg.norm(vb[1:]) - vb[0])
+        return t
+
+
+def _jres(v0, nrm1):
+    # v0^2 - ||v1||^2 without the cancellation of the naive form
+    return (v0 - nrm1) * (v0 + nrm1)
+
+
+class _Scaling:
+    """Nesterov-Todd scaling W (symmetric) for the current (s, z)."""
+
+    def __init__(self, cone, s, z):
+        self.cone = cone
+        sl, sq, sb = cone.split(s)
+        zl, zq, zb = cone.split(z)
+        self.wl = np.sqrt(sl / zl)                 # W = diag(wl) on the LP rows
+        self.dl = zl / sl                          # W^-2
+        if cone.nq3:
+            self.eta3, self.wb3 = self._soc(sq, zq)
+        if cone.big:
+            eb, wb = self._soc(sb[None, :], zb[None, :])
+            self.etab, self.wbb = eb[0], wb[0]
+
+    @staticmethod
+    def _soc(s, z):
+        ns = np.sqrt(np.sum(s[:, 1:] ** 2, axis=1))
+        nz = np.sqrt(np.sum(z[:, 1:] ** 2, axis=1))
+        a = np.sqrt(_jres(s[:, 0], ns))
+        b = np.sqrt(_jres(z[:, 0], nz))
+        sb = s / a[:, None]
+        zb = z / b[:, None]
+        gamma = np.sqrt((1.0 + np.sum(sb * zb, axis=1)) / 2.0)
+        wbar = np.empty_like(s)
+        wbar[:, 0] = (sb[:, 0] + zb[:, 0]) / (2 * gamma)
+        wbar[:, 1:] = (sb[:, 1:] - zb[:, 1:]) / (2 * gamma[:, None])
+        eta = np.sqrt(a / b)
+        return eta, wbar
+
+    @staticmethod
+    def _soc_apply(eta, wbar, u, inverse):
+        w0 = wbar[:, 0]
+        w1 = wbar[:, 1:]
+        u0 = u[:, 0]
+        u1 = u[:, 1:]
+        dot = np.sum(w1 * u1, axis=1)
+        out = np.empty_like(u)
+        if inverse:
+            out[:, 0] = (w0 * u0 - dot) / eta
+            out[:, 1:] = (u1 + ((-u0 + dot / (1 + w0)))[:, None] * w1) / eta[:, None]
+        else:
+            out[:, 0] = (w0 * u0 + dot) * eta
+            out[:, 1:] = (u1 + ((u0 + dot / (1 + w0)))[:, None] * w1) * eta[:, None]
+        return out
+
+    def apply(self, v, inverse=False):
+        c = self.cone
+        out = np.empty_like(v)
+        vl, vq, vb = c.split(v)
+        out[: c.l] = vl / self.wl if inverse else vl * self.wl
+        if c.nq3:
+            out[c.o3:c.ob] = self._soc_apply(self.eta3, self.wb3, vq, inverse).ravel()
+        if c.big:
+            out[c.ob:] = self._soc_apply(np.array([self.etab]), self.wbb[None, :],
+                                         vb[None, :], inverse)[0]
+        return out
+
+    def inv2(self, V):
+        """W^-2 V for a vector (R,) or a matrix (R, k)."""
+        c = self.cone
+        vec = V.ndim == 1
+        if vec:
+            V = V[:, None]
+        out = np.empty_like(V)
+        out[: c.l] = self.dl[:, None] * V[: c.l]
+        if c.nq3:
+            Vq = V[c.o3:c.ob].reshape(c.nq3, 3, -1)
+            u = self.wb3 * np.array([1.0, -1.0, -1.0])        # J wbar
+            uv = np.einsum("ka,kan->kn", u, Vq)
+            o = 2 * u[:, :, None] * uv[:, None, :]
+            o[:, 0, :] -= Vq[:, 0, :]
+            o[:, 1:, :] += Vq[:, 1:, :]
+            out[c.o3:c.ob] = (o / (self.eta3 ** 2)[:, None, None]).reshape(3 * c.nq3, -1)
+        if c.big:
+            Vb = V[c.ob:]
+            u = self.wbb.copy()
+            u[1:] = -u[1:]
+            o = 2 * np.outer(u, u @ Vb)
+            o[0] -= Vb[0]
+            o[1:] += Vb[1:]
+            out[c.ob:] = o / self.etab ** 2
+        return out[:, 0] if vec else out
+
+
+def _soc_prod(u, v):
+    out = np.empty_like(u)
+    out[:, 0] = np.sum(u * v, axis=1)
+    out[:, 1:] = u[:, :1] * v[:, 1:] + v[:, :1] * u[:, 1:]
+    return out
+
+
+def _soc_div(lam, d):
+    """x with lam o x = d."""
+    l0 = lam[:, 0]
+    l1 = lam[:, 1:]
+    a = _jres(l0, np.sqrt(np.sum(l1 ** 2, axis=1)))
+    ld = np.sum(l1 * d[:, 1:], axis=1)
+    out = np.empty_like(d)
+    out[:, 0] = (l0 * d[:, 0] - ld) / a
+    out[:, 1:] = (d[:, 1:] - out[:, :1] * l1) / l0[:, None]
+    return out
+
+
+def _cone_prod(c, u, v):
+    out = np.empty_like(u)
+    ul, uq, ub = c.split(u)
+    vl, vq, vb = c.split(v)
+    out[: c.l] = ul * vl
+    if c.nq3:
+        out[c.o3:c.ob] = _soc_prod(uq, vq).ravel()
+    if c.big:
+        out[c.ob:] = _soc_prod(ub[None, :], vb[None, :])[0]
+    return out
+
+
+def _cone_div(c, lam, d):
+    out = np.empty_like(d)
+    ll, lq, lb = c.split(lam)
+    dl, dq, db = c.split(d)
+    out[: c.l] = dl / ll
+    if c.nq3:
+        out[c.o3:c.ob] = _soc_div(lq, dq).ravel()
+    if c.big:
+        out[c.ob:] = _soc_div(lb[None, :], db[None, :])[0]
+    return out
+
+
+def _soc_step(lam, d):
+    """max over cones of (||rho_1|| - rho_0), rho = T(lam) d, T lam = e."""
+    l0 = lam[:, 0]
+    l1 = lam[:, 1:]
+    a = np.sqrt(_jres(l0, np.sqrt(np.sum(l1 ** 2, axis=1))))
+    lb0 = l0 / a
+    lb1 = l1 / a[:, None]
+    dot = np.sum(lb1 * d[:, 1:], axis=1)
+    rho0 = (lb0 * d[:, 0] - dot) / a
+    rho1 = (d[:, 1:] + ((-d[:, 0] + dot / (1 + lb0)))[:, None] * lb1) / a[:, None]
+    return (np.sqrt(np.sum(rho1 ** 2, axis=1)) - rho0).max()
+
+
+def _max_step(c, lam, d):
+    """t such that lam + alpha d in K  <=>  alpha <= 1/t (t<=0: unbounded)."""
+    ll, lq, lb = c.split(lam)
+    dl, dq, db = c.split(d)
+    t = -np.inf
+    if c.l:
+        t = max(t, (-dl / ll).max())
+    if c.nq3:
+        t = max(t, _soc_step(lq, dq))
+    if c.big:
+        t = max(t, _soc_step(lb[None, :], db[None, :]))
+    return t
+
+
+def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
+          reltol=1e-9, static_reg=0.0, refine=1, verbose=False, history=None):
+    """Returns dict(status, x, s, z, iters, pcost, dcost, gap, pres, dres).
+
+    Stopping rule (all quantities of the de-homogenised point x/tau ...):
+      pres = ||Gx+s-h||/max(1,||h||), dres = ||G'z+c||/max(1,||c||),
+      gap  = s'z, relgap = gap/max(|pcost|,|dcost|)  -> optimal when
+      pres,dres <= feastol and (gap <= abstol or relgap <= reltol).
+    Certificates: primal infeasible when h'z<0 and ||G'z||/(-h'z) <= feastol;
+    dual infeasible when c'x<0 and ||Gx+s||/(-c'x) <= feastol.
+    """
+    c = np.asarray(c, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64)
+    G = np.asarray(G, dtype=np.float64)
+    cone = _Cone(l, nq3, big)
+    R, N = G.shape
+    assert R == cone.R
+    nrm_h = max(1.0, np.linalg.norm(h))
+    nrm_c = max(1.0, np.linalg.norm(c))
+    e = cone.e()
+
+    def factor(Wm):
+        H = G.T @ (Wm.inv2(G) if Wm is not None else G)
+        H = 0.5 * (H + H.T)
+        reg = static_reg * np.max(np.diag(H)) if static_reg else 0.0
+        bump = 0.0
+        for _ in range(20):
+            try:
+                Hr = H + (reg + bump) * np.eye(N) if (reg + bump) else H
+                cf = sla.cho_factor(Hr, lower=True, check_finite=True)
+                return H, cf
+            except (sla.LinAlgError, ValueError):
+                bump = max(1e-14 * np.max(np.diag(H)), 10 * bump)
+        raise FloatingPointError("Cholesky failed")
+
+    def kkt_solve(Wm, H, cf, bx, bz):
+        """[0 G'; G -W^2][dx; dz] = [bx; bz].
+
+        dz is kept as an explicit vector and corrected incrementally, so the
+        dual equation G'dz = bx is driven to rounding level even when
+        ||H|| eps is large (the residual of an increment scales with the
+        increment, not with dx)."""
+        wbz = Wm.inv2(bz) if Wm is not None else bz
+        rhs = bx + G.T @ wbz
+        dx = sla.cho_solve(cf, rhs)
+        Gdx = G @ dx
+        dz = (Wm.inv2(Gdx) if Wm is not None else Gdx) - wbz
+        nb = max(np.linalg.norm(bx), 1e-300)
+        for _ in range(refine):
+            r = bx - G.T @ dz
+            if np.linalg.norm(r) <= 1e-14 * nb:
+                break
+            ddx = sla.cho_solve(cf, r)
+            dx = dx + ddx
+            Gd = G @ ddx
+            dz = dz + (Wm.inv2(Gd) if Wm is not None else Gd)
+        return dx, dz
+
+    # ---- initial point (W = I) ------------------------------------------
+    H, cf = factor(None)
+    x, r_ = kkt_solve(None, H, cf, np.zeros(N), h)          # min ||Gx-h||
+    s = -r_                                                 # h - Gx
+    ts = cone.min_residual(s)
+    if ts >= -1e-8 * max(1.0, np.linalg.norm(s)):
+        s = s + (1.0 + ts) * e
+    _, z = kkt_solve(None, H, cf, -c, np.zeros(R))          # G'z=-c, least norm
+    tz = cone.min_residual(z)
+    if tz >= -1e-8 * max(1.0, np.linalg.norm(z)):
+        z = z + (1.0 + tz) * e
+    tau, kappa = 1.0, 1.0
+    status = STATUS_MAXIT
+    it = 0
+    info = {}
+    for it in range(max_iter + 1):
+        rx = G.T @ z + c * tau
+        rz = G @ x + s - h * tau
+        cx, hz = c @ x, h @ z
+        rt = kappa + cx + hz
+        sz = s @ z
+        mu = (sz + kappa * tau) / (cone.degree + 1)
+        pcost, dcost = cx / tau, -hz / tau
+        gap = sz / tau ** 2
+        pres = np.linalg.norm(rz) / tau / nrm_h
+        dres = np.linalg.norm(rx) / tau / nrm_c
+        den = max(abs(pcost), abs(dcost))
+        relgap = gap / den if den > 0 else np.inf
+        hresx = np.linalg.norm(rx - c * tau)                # ||G'z||
+        hresz = np.linalg.norm(rz + h * tau)                # ||Gx+s||
+        pinfres = hresx / (-hz) if hz < 0 else np.inf
+        dinfres = hresz / (-cx) if cx < 0 else np.inf
+        info = dict(iters=it, pcost=pcost, dcost=dcost, gap=gap, relgap=relgap,
+                    pres=pres, dres=dres, tau=tau, kappa=kappa, mu=mu,
+                    pinfres=pinfres, dinfres=dinfres)
+        if history is not None:
+            history.append(dict(info))
+        if verbose:
+            print("%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e"
+                  % (it, pcost, dcost, gap, pres, dres, kappa / tau, mu))
+        if pres <= feastol and dres <= feastol and (gap <= abstol or relgap <= reltol):
+            status = STATUS_OPTIMAL
+            break
+        if pinfres <= feastol:
+            status = STATUS_PRIMAL_INFEASIBLE
+            break
+        if dinfres <= feastol:
+            status = STATUS_DUAL_INFEASIBLE
+            break
+        if it == max_iter:
+            break
+        try:
+            Wm = _Scaling(cone, s, z)
+            lam = Wm.apply(z)
+            H, cf = factor(Wm)
+            x1, z1 = kkt_solve(Wm, H, cf, -c, h)
+        except FloatingPointError:
+            status = STATUS_NUMERICAL
+            break
+        if not (np.all(np.isfinite(x1)) and np.all(np.isfinite(z1))):
+            status = STATUS_NUMERICAL
+            break
+        wz1 = Wm.apply(z1)
+        den_t = kappa / tau + wz1 @ wz1
+
+        def direction(sigma, ds_c, dk_c):
+            # ds_c, dk_c: right-hand sides of the (scaled) complementarity rows
+            lds = _cone_div(cone, lam, ds_c)
+            bx = -(1 - sigma) * rx
+            bz = -(1 - sigma) * rz - Wm.apply(lds)
+            x2, z2 = kkt_solve(Wm, H, cf, bx, bz)
+            bt = -(1 - sigma) * rt
+            dtau = (dk_c / tau - bt + c @ x2 + h @ z2) / den_t
+            dx = x2 + dtau * x1
+            dz = z2 + dtau * z1
+            wdz = Wm.apply(dz)
+            dss = lds - wdz                                   # W^-1 ds
+            ds = Wm.apply(dss)
+            dkap = (dk_c - kappa * dtau) / tau
+            return dx, ds, dz, dtau, dkap, dss, wdz
+
+        def step_of(dss, wdz, dtau, dkap, frac):
+            t = max(0.0, _max_step(cone, lam, dss), _max_step(cone, lam, wdz),
+                    -dtau / tau, -dkap / kappa)
+            return 1.0 if t == 0.0 else min(1.0, frac / t)
+
+        ll = _cone_prod(cone, lam, lam)
+        dxa, dsa, dza, dta, dka, dssa, wdza = direction(0.0, -ll, -kappa * tau)
+        alpha_a = step_of(dssa, wdza, dta, dka, 1.0)
+        sigma = (1.0 - alpha_a) ** 3
+        ds_c = sigma * mu * e - ll - _cone_prod(cone, dssa, wdza)
+        dk_c = sigma * mu - kappa * tau - dka * dta
+        dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, ds_c, dk_c)
+        alpha = step_of(dss, wdz, dtau, dkap, STEP)
+        if history is not None:
+            sl_, zl_ = s[:cone.l], z[:cone.l]
+            history[-1].update(alpha=alpha, alpha_a=alpha_a, sigma=sigma,
+                               cmin=(sl_ * zl_).min() / mu if cone.l else 1.0,
+                               cmax=(sl_ * zl_).max() / mu if cone.l else 1.0)
+        x = x + alpha * dx
+        s = s + alpha * ds
+        z = z + alpha * dz
+        tau = tau + alpha * dtau
+        kappa = kappa + alpha * dkap
+        if not (np.isfinite(tau) and tau > 0 and np.all(np.isfinite(x))):
+            status = STATUS_NUMERICAL
+            break
+    out = dict(status=status, x=x / tau, s=s / tau, z=z / tau)
+    out.update(info)
+    return out
