@@ -1,0 +1,352 @@
+"""mbfir -- MI355X-native convex FIR / SLR beta-polynomial designer (host side).
+
+Python mirror of the four convex designers of shanghong/Multiband-RF-pulse-Design
+(same names, argument order, defaults, return convention and error behaviour as the
+MATLAB functions they replace):
+
+    h, status = fir_ap_cvx(n, f, a, d, obj, Peak, dbg)      # reference fir_ap_cvx.m:1
+    h, status = fir_qp_cvx(n, f, a, d, k, obj, dbg)         # reference fir_qp_cvx.m:1
+    h, status = fir_linprog(n, f, a, d, h0, dbg)            # reference ss/fir_linprog.m:2
+    h, status = fir_qprog_phs(n, f, ac, dc, x0, dbg)        # reference ss/fir_qprog_phs.m:1
+
+Everything is computed by the hand-written HIP solver behind the C ABI of
+include/mbfir.h (libmbfir.so, built in-tree by __graft_entry__.build()); this module is
+a ctypes binding plus argument checking.  There is NO CPU fallback: if the library is
+missing or no GPU is present the calls raise.
+
+The directory name contains '-', so import the package through the repo-root shim:
+    import mbfir
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmbfir.so")
+
+SOLVED, INFEASIBLE, NUMERICAL, EARLY_FAIL = 0, 1, 2, 3
+E_ARG, E_HIP, E_NODEVICE = -1, -2, -3
+
+
+class MbfirError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    """struct mbfir_opts (include/mbfir.h)."""
+    _fields_ = [("grid_m", C.c_int), ("max_iter", C.c_int), ("feastol", C.c_double),
+                ("abstol", C.c_double), ("reltol", C.c_double), ("refine", C.c_int),
+                ("verbose", C.c_int), ("shard_rank", C.c_int), ("shard_size", C.c_int)]
+
+
+class Info(C.Structure):
+    """struct mbfir_info (include/mbfir.h)."""
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("n_unknowns", C.c_int), ("n_rows", C.c_int),
+                ("n_freq", C.c_int), ("n_lp", C.c_int), ("n_q3", C.c_int), ("n_big", C.c_int),
+                ("pcost", C.c_double), ("dcost", C.c_double), ("gap", C.c_double), ("relgap", C.c_double),
+                ("pres", C.c_double), ("dres", C.c_double),
+                ("ms_assemble", C.c_double), ("ms_solve", C.c_double), ("ms_post", C.c_double),
+                ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
+                ("gram_flop", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lib = None
+
+# every symbol include/mbfir.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mbfir_create": (C.c_void_p, [C.c_int]),
+    "mbfir_destroy": (None, [C.c_void_p]),
+    "mbfir_last_error": (C.c_char_p, [C.c_void_p]),
+    "mbfir_default_opts": (None, [C.POINTER(Opts)]),
+    "mbfir_set_allreduce": (None, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "mbfir_version": (C.c_char_p, []),
+    "mbfir_ap_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double,
+                                 C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
+    "mbfir_qp_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int,
+                                 C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
+    "mbfir_linprog_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp,
+                                      C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
+    "mbfir_qprog_phs_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp,
+                                        C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
+    "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
+                                 C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
+    "mbfir_program_free": (None, [C.c_void_p]),
+    "mbfir_program_dims": (None, [C.c_void_p, _ip]),
+    "mbfir_program_trig": (None, [C.c_void_p, _dp, _ip, _dp, _dp, _ip, _dp, _dp]),
+    "mbfir_program_rows": (None, [C.c_void_p, _ip, _ip, _dp, _dp, _dp, _dp]),
+    "mbfir_test_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_specfact": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_mfma_peak": (C.c_int, [C.c_void_p, _dp, _dp]),
+}
+
+
+def load_library():
+    """dlopen libmbfir.so and bind every symbol of include/mbfir.h.  Raises when the
+    library has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MbfirError("libmbfir.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                         % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _vec(x, dtype=np.float64):
+    return np.ascontiguousarray(np.asarray(x, dtype=dtype).ravel())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Context:
+    """Owns the device memory, stream and (optionally) the all-reduce hook of one GPU.
+    Reusable across calls; not thread-safe (mirrors mbfir_ctx)."""
+
+    def __init__(self, device=None):
+        lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        self._h = lib.mbfir_create(device)
+        if not self._h:
+            raise MbfirError("mbfir_create(%d) failed: %s" % (device, lib.mbfir_last_error(None).decode()))
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().mbfir_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return load_library().mbfir_last_error(self._h).decode()
+
+    def set_allreduce(self, fn):
+        """fn(ptr:int, count:int, op:int) -> int ; op 0 = sum, 1 = max (device pointer)."""
+        self._cb = ALLREDUCE_FN(lambda buf, count, op, user: int(fn(buf, count, op)))
+        load_library().mbfir_set_allreduce(self._h, self._cb, None)
+
+
+_default_ctx = {}
+
+
+def get_context(device=None):
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def make_opts(**kw):
+    o = Opts()
+    load_library().mbfir_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+def _finish(ctx, rc, hre, him, info, want_info):
+    if rc < 0:
+        msg = ctx.last_error()
+        if rc == E_ARG:
+            raise ValueError(msg)            # the reference's error() calls
+        raise MbfirError("mbfir solve failed (%d): %s" % (rc, msg))
+    if rc == SOLVED:
+        h, status = hre + 1j * him, "Solved"
+    else:
+        h, status = np.zeros(0, dtype=np.complex128), "Failed"      # h = [] on failure
+    if want_info:
+        d = info.as_dict()
+        d["rc"] = rc
+        return h, status, d
+    return h, status
+
+
+def fir_ap_cvx(n, f, a, d, obj=0.0, Peak=1e-3, dbg=0, *, opts=None, ctx=None, info=False):
+    """Arbitrary-phase multiband magnitude design (reference fir_ap_cvx.m).
+    Returns (h, status): h complex ndarray of n taps (the reference's 1 x n row),
+    status 'Solved' or 'Failed' (h empty).  obj < 0 raises ValueError('invalid input of obj')."""
+    if n is None or f is None or a is None or d is None:
+        raise ValueError("not enough input")                       # fir_ap_cvx.m:32
+    ctx = ctx or get_context()
+    f, a, d = _vec(f), _vec(a), _vec(d)
+    _check_spec(f, a, d)
+    hre, him, inf = np.zeros(n), np.zeros(n), Info()
+    o = opts if opts is not None else make_opts(verbose=1 if dbg else 0)
+    rc = load_library().mbfir_ap_solve(ctx._h, int(n), len(d), _ptr(f), _ptr(a), _ptr(d), float(obj),
+                                       float(Peak), C.byref(o), _ptr(hre), _ptr(him), C.byref(inf))
+    return _finish(ctx, rc, hre, him, inf, info)
+
+
+def fir_qp_cvx(n, f, a, d, k=100.0, obj=0.0, dbg=0, *, opts=None, ctx=None, info=False):
+    """Quadratic-phase design (reference fir_qp_cvx.m).  obj scalar -> E_total + obj*Peak,
+    two entries -> delta + obj(1)*E_total + obj(2)*Peak.  Returns (h, status), h n x 1."""
+    if n is None or f is None or a is None or d is None:
+        raise ValueError("not enough input")                       # fir_qp_cvx.m:28
+    ctx = ctx or get_context()
+    f, a, d = _vec(f), _vec(a), _vec(d)
+    _check_spec(f, a, d)
+    objv = _vec(obj)
+    if len(objv) not in (1, 2):
+        raise ValueError("invalid input of obj")                   # fir_qp_cvx.m:194-196
+    hre, him, inf = np.zeros(n), np.zeros(n), Info()
+    o = opts if opts is not None else make_opts(verbose=1 if dbg else 0)
+    rc = load_library().mbfir_qp_solve(ctx._h, int(n), len(d), _ptr(f), _ptr(a), _ptr(d), float(k),
+                                       _ptr(objv), len(objv), C.byref(o), _ptr(hre), _ptr(him), C.byref(inf))
+    return _finish(ctx, rc, hre, him, inf, info)
+
+
+def fir_linprog(n, f, a, d, h0=None, dbg=0, *, opts=None, ctx=None, info=False):
+    """Linear-phase (Hermitian-symmetric) multiband LP (reference ss/fir_linprog.m).
+    h0 is the reference's warm start for its active-set linprog; an interior-point
+    method has no use for it and it is ignored.  Returns (h, status), h n x 1."""
+    ctx = ctx or get_context()
+    f, a, d = _vec(f), _vec(a), _vec(d)
+    _check_spec(f, a, d)
+    hre, him, inf = np.zeros(n), np.zeros(n), Info()
+    o = opts if opts is not None else make_opts(verbose=1 if dbg else 0)
+    rc = load_library().mbfir_linprog_solve(ctx._h, int(n), len(d), _ptr(f), _ptr(a), _ptr(d), C.byref(o),
+                                            _ptr(hre), _ptr(him), C.byref(inf))
+    return _finish(ctx, rc, hre, him, inf, info)
+
+
+def fir_qprog_phs(n, f, ac, dc, x0=None, dbg=0, *, opts=None, ctx=None, info=False):
+    """Minimum-energy design with per-band magnitude and phase bounds (reference
+    ss/fir_qprog_phs.m).  ac (2 per band) and dc (1 per band) are complex.  x0 is
+    overwritten by [] in the reference (:338) and ignored here.  Returns (h, status)."""
+    ctx = ctx or get_context()
+    f = _vec(f)
+    ac = np.ascontiguousarray(np.asarray(ac, dtype=np.complex128).ravel())
+    dc = np.ascontiguousarray(np.asarray(dc, dtype=np.complex128).ravel())
+    if len(f) % 2 or len(ac) != len(f) or len(dc) != len(f) // 2:
+        raise ValueError("f, ac, dc have inconsistent lengths")
+    are, aim = _vec(ac.real), _vec(ac.imag)
+    dre, dim = _vec(dc.real), _vec(dc.imag)
+    hre, him, inf = np.zeros(n), np.zeros(n), Info()
+    o = opts if opts is not None else make_opts(verbose=1 if dbg else 0)
+    rc = load_library().mbfir_qprog_phs_solve(ctx._h, int(n), len(dc), _ptr(f), _ptr(are), _ptr(aim), _ptr(dre),
+                                              _ptr(dim), C.byref(o), _ptr(hre), _ptr(him), C.byref(inf))
+    return _finish(ctx, rc, hre, him, inf, info)
+
+
+def _check_spec(f, a, d):
+    if len(f) % 2 or len(a) != len(f) or len(d) != len(f) // 2:
+        raise ValueError("f, a, d have inconsistent lengths")
+
+
+# ---- host-only introspection (no GPU): structured program -> dense (c, G, h) -------------------
+def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0):
+    """Run the product's C++ problem assembly for designer `which` (0 ap, 1 qp, 2 linprog,
+    3 qprog_phs; for 3 pass complex a, d) and expand the structured rows to dense arrays.
+    Returns (rc, dict) -- used by the CPU tests to compare against the oracle."""
+    lib = load_library()
+    f = _vec(f)
+    if which == 3:
+        ac = np.asarray(a, dtype=np.complex128).ravel()
+        dc = np.asarray(d, dtype=np.complex128).ravel()
+        a = _vec(np.stack([ac.real, ac.imag], 1))
+        d = _vec(np.stack([dc.real, dc.imag], 1))
+    else:
+        a, d = _vec(a), _vec(d)
+    params = _vec(list(params) + [0.0] * 4)
+    out = C.c_void_p()
+    err = C.create_string_buffer(256)
+    rc = lib.mbfir_assemble(which, int(n), len(f) // 2, _ptr(f), _ptr(a), _ptr(d), _ptr(params), int(grid_m),
+                            C.byref(out), err, 256)
+    if rc != 0:
+        return rc, err.value.decode()
+    try:
+        dims = np.zeros(10, dtype=np.int32)
+        lib.mbfir_program_dims(out, dims.ctypes.data_as(_ip))
+        Nt, Ne, R, l, nq3, big, Mf, quad = [int(v) for v in dims[:8]]
+        w = np.zeros(Mf)
+        kind = np.zeros(Nt, dtype=np.int32)
+        tau, scale, psign = np.zeros(Nt), np.zeros(Nt), np.zeros(Nt)
+        pcol = np.zeros(Nt, dtype=np.int32)
+        c = np.zeros(Nt + Ne)
+        lib.mbfir_program_trig(out, _ptr(w), kind.ctypes.data_as(_ip), _ptr(tau), _ptr(scale),
+                               pcol.ctypes.data_as(_ip), _ptr(psign), _ptr(c))
+        freq = np.zeros(R, dtype=np.int32)
+        col = np.zeros(R, dtype=np.int32)
+        al, be, ey, h = np.zeros(R), np.zeros(R), np.zeros((R, 3)), np.zeros(R)
+        lib.mbfir_program_rows(out, freq.ctypes.data_as(_ip), col.ctypes.data_as(_ip), _ptr(al), _ptr(be),
+                               _ptr(ey), _ptr(h))
+    finally:
+        lib.mbfir_program_free(out)
+    arg = np.outer(w, tau)
+    A1 = scale * np.where(kind == 0, np.cos(arg), np.sin(arg))
+    A2 = psign * A1[:, pcol] if quad else np.zeros_like(A1)
+    G = np.zeros((R, Nt + Ne))
+    tr = freq >= 0
+    G[tr, :Nt] = al[tr, None] * A1[freq[tr]] + be[tr, None] * A2[freq[tr]]
+    idr = np.nonzero(col >= 0)[0]
+    G[idr, col[idr]] += al[idr]
+    G[:, Nt:] = ey[:, :Ne]
+    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad)
+
+
+# ---- device kernel test hooks --------------------------------------------------------------------
+def _check(ctx, rc):
+    if rc != 0:
+        raise MbfirError("mbfir test hook failed (%d): %s" % (rc, ctx.last_error()))
+
+
+def test_gram(A, d, ctx=None):
+    ctx = ctx or get_context()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    d = np.ascontiguousarray(np.atleast_2d(d), dtype=np.float64)
+    m, nt = A.shape
+    nw = d.shape[0]
+    out = np.zeros((nw, nt, nt))
+    _check(ctx, load_library().mbfir_test_gram(ctx._h, m, nt, nw, _ptr(A), _ptr(d), _ptr(out)))
+    return out
+
+
+def test_chol(H, ctx=None):
+    ctx = ctx or get_context()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    n = H.shape[0]
+    L, M = np.zeros((n, n)), np.zeros((n, n))
+    _check(ctx, load_library().mbfir_test_chol(ctx._h, n, _ptr(H), _ptr(L), _ptr(M)))
+    return L, M
+
+
+def test_specfact(x, n, ctx=None):
+    ctx = ctx or get_context()
+    x = _vec(x)
+    hre, him = np.zeros(n), np.zeros(n)
+    _check(ctx, load_library().mbfir_test_specfact(ctx._h, int(n), _ptr(x), _ptr(hre), _ptr(him)))
+    return hre + 1j * him
+
+
+def mfma_peak(ctx=None):
+    """Measured fp64 MFMA and VALU rates in TFLOP/s (roofline denominators)."""
+    ctx = ctx or get_context()
+    a, b = C.c_double(), C.c_double()
+    _check(ctx, load_library().mbfir_test_mfma_peak(ctx._h, C.byref(a), C.byref(b)))
+    return a.value, b.value

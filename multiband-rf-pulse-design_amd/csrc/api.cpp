@@ -1,0 +1,212 @@
+// C ABI of include/mbfir.h: context management and the four designer entry points.
+// Each entry point = host assembly (assemble.cpp) -> device IPM (solver.hip) -> tap extraction.
+#include "../../include/mbfir.h"
+#include "program.h"
+#include "solver.h"
+#include <chrono>
+#include <cstring>
+#include <memory>
+
+using namespace mbfir;
+
+struct mbfir_ctx {
+    std::unique_ptr<Solver> solver;
+    std::string err;
+    mbfir_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+SolveOpts to_opts(const mbfir_opts* o) {
+    SolveOpts s;
+    if (!o) return s;
+    if (o->max_iter > 0) s.max_iter = o->max_iter;
+    if (o->feastol > 0) s.feastol = o->feastol;
+    if (o->abstol > 0) s.abstol = o->abstol;
+    if (o->reltol > 0) s.reltol = o->reltol;
+    if (o->refine >= 0) s.refine = o->refine;
+    s.verbose = o->verbose;
+    return s;
+}
+
+int status_to_rc(int st) {
+    switch (st) {
+        case ST_OPTIMAL: return MBFIR_SOLVED;
+        case ST_PRIMAL_INFEASIBLE:
+        case ST_DUAL_INFEASIBLE: return MBFIR_INFEASIBLE;
+        default: return MBFIR_NUMERICAL;
+    }
+}
+
+void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int rc, double t0, double t_asm,
+               double t_solved, double t_end) {
+    if (!info) return;
+    std::memset(info, 0, sizeof(*info));
+    info->status = rc; info->iters = si.iters; info->n_unknowns = P.N(); info->n_rows = P.R; info->n_freq = P.Mf;
+    info->n_lp = P.l; info->n_q3 = P.nq3; info->n_big = P.big;
+    info->pcost = si.pcost; info->dcost = si.dcost; info->gap = si.gap; info->relgap = si.relgap;
+    info->pres = si.pres; info->dres = si.dres;
+    info->ms_assemble = (t_asm - t0) + si.ms_assemble; info->ms_solve = si.ms_solve;
+    info->ms_post = t_end - t_solved; info->ms_total = t_end - t0;
+    info->ms_gram = si.ms_gram; info->ms_chol = si.ms_chol; info->gram_flop = si.gram_flop;
+}
+
+// Common driver: `asm_rc` is the assembly result, `post` maps the solution vector to taps.
+template <class Post>
+int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, const mbfir_opts* opts,
+        mbfir_info* info, double t0, Post post) {
+    if (!ctx) return MBFIR_E_ARG;
+    if (info) std::memset(info, 0, sizeof(*info));
+    if (asm_rc != 0) {
+        ctx->err = asm_err;
+        if (info) info->status = asm_rc;
+        return asm_rc;
+    }
+    if (opts && opts->shard_size > 1 && !ctx->allreduce) {
+        ctx->err = "row-sharded solve requested without an all-reduce hook";
+        return MBFIR_E_ARG;
+    }
+    try {
+        double t_asm = now_ms();
+        SolveInfo si;
+        std::vector<double> x;
+        SolveOpts so = to_opts(opts);
+        int st = ctx->solver->solve(P, so, x, si);
+        double t_solved = now_ms();
+        int rc = status_to_rc(st);
+        if (rc == MBFIR_SOLVED) post(x);
+        fill_info(info, P, si, rc, t0, t_asm, t_solved, now_ms());
+        return rc;
+    } catch (const std::exception& e) {
+        ctx->err = e.what();
+        if (info) info->status = MBFIR_E_HIP;
+        return MBFIR_E_HIP;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mbfir_version(void) { return "mbfir 0.1 (gfx950)"; }
+
+void mbfir_default_opts(mbfir_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->refine = -1;
+}
+
+mbfir_ctx* mbfir_create(int device_id) {
+    try {
+        mbfir_ctx* c = new mbfir_ctx();
+        c->solver.reset(new Solver(device_id));
+        return c;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return nullptr;
+    }
+}
+
+void mbfir_destroy(mbfir_ctx* ctx) { delete ctx; }
+
+const char* mbfir_last_error(mbfir_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void mbfir_set_allreduce(mbfir_ctx* ctx, mbfir_allreduce_fn fn, void* user) {
+    if (!ctx) return;
+    ctx->allreduce = fn;
+    ctx->allreduce_user = user;
+}
+
+int mbfir_ap_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,
+                   double obj, double peak, const mbfir_opts* opts, double* h_re, double* h_im,
+                   mbfir_info* info) {
+    double t0 = now_ms();
+    TrigProgram P;
+    std::string e;
+    int rc = assemble_ap(n, nband, f, a, d, obj, peak, opts ? opts->grid_m : 0, P, e);
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>&) {
+        ctx->solver->specfact_last(n, h_re, h_im);           // fir_ap_cvx.m:185-186,202
+    });
+}
+
+int mbfir_qp_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,
+                   double kquad, const double* obj, int nobj, const mbfir_opts* opts, double* h_re,
+                   double* h_im, mbfir_info* info) {
+    double t0 = now_ms();
+    TrigProgram P;
+    std::string e;
+    int rc = assemble_qp(n, nband, f, a, d, kquad, obj, nobj, opts ? opts->grid_m : 0, P, e);
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
+        for (int i = 0; i < n; ++i) { h_re[i] = x[i]; h_im[i] = x[n + i]; }     // fir_qp_cvx.m:209
+    });
+}
+
+int mbfir_linprog_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,
+                        const mbfir_opts* opts, double* h_re, double* h_im, mbfir_info* info) {
+    double t0 = now_ms();
+    TrigProgram P;
+    std::string e;
+    int rc = assemble_linprog(n, nband, f, a, d, opts ? opts->grid_m : 0, P, e);
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
+        // fill_h, ss/fir_linprog.m:274-296: Hermitian extension of the half filter
+        const int nh = P.nhalf;
+        for (int i = 0; i < n; ++i) { h_re[i] = 0; h_im[i] = 0; }
+        if (P.real_filter) {
+            if (P.odd_filter) for (int k = 0; k < nh; ++k) { h_re[nh - 1 + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
+            else for (int k = 0; k < nh; ++k) { h_re[nh + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
+        } else if (P.odd_filter) {
+            for (int k = 0; k < nh; ++k) {
+                double re = x[k], im = k == 0 ? 0.0 : x[nh + k - 1];
+                h_re[nh - 1 + k] = re; h_im[nh - 1 + k] = im;
+                h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
+            }
+        } else {
+            for (int k = 0; k < nh; ++k) {
+                double re = x[k], im = x[nh + k];
+                h_re[nh + k] = re; h_im[nh + k] = im;
+                h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
+            }
+        }
+    });
+}
+
+int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* ac_re,
+                          const double* ac_im, const double* dc_re, const double* dc_im,
+                          const mbfir_opts* opts, double* h_re, double* h_im, mbfir_info* info) {
+    double t0 = now_ms();
+    TrigProgram P;
+    std::string e;
+    int rc = assemble_qprog_phs(n, nband, f, ac_re, ac_im, dc_re, dc_im, opts ? opts->grid_m : 0, P, e);
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
+        for (int i = 0; i < n; ++i) { h_re[i] = x[i]; h_im[i] = x[n + i]; }     // ss/fir_qprog_phs.m:389
+    });
+}
+
+// ---- device kernel test hooks ------------------------------------------------------------------
+#define MBFIR_TRY(ctx, stmt)                   \
+    if (!ctx) return MBFIR_E_ARG;              \
+    try { stmt; return 0; }                    \
+    catch (const std::exception& e) { ctx->err = e.what(); return MBFIR_E_HIP; }
+
+int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, const double* d, double* out) {
+    MBFIR_TRY(ctx, ctx->solver->test_gram(m, nt, nw, A, d, out));
+}
+int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m) {
+    MBFIR_TRY(ctx, ctx->solver->test_chol(n, H, out_l, out_m));
+}
+int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im) {
+    MBFIR_TRY(ctx, ctx->solver->test_specfact(n, x, h_re, h_im));
+}
+int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tf_mfma, double* tf_valu) {
+    MBFIR_TRY(ctx, ctx->solver->test_mfma_peak(tf_mfma, tf_valu));
+}
+
+}  // extern "C"

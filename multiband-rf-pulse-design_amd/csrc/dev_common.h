@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, fp64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace mbfir {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+
+#define MBFIR_HIP(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            throw mbfir::HipError(std::string(#expr) + ": " + hipGetErrorString(e__) + " at " + \
+                                  __FILE__ + ":" + std::to_string(__LINE__));                  \
+    } while (0)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// Block-wide sum; result valid in every thread.  sh must hold >= 17 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < nw; ++i) t += sh[i];
+        sh[16] = t;
+    }
+    __syncthreads();
+    return sh[16];
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int i = 1; i < nw; ++i) t = fmax(t, sh[i]);
+        sh[16] = t;
+    }
+    __syncthreads();
+    return sh[16];
+}
+
+inline int cdiv(long a, long b) { return int((a + b - 1) / b); }
+inline long round_up(long a, long b) { return ((a + b - 1) / b) * b; }
+
+// ---- kernels implemented in gram.hip / chol.hip / specfact.hip --------------------------------
+struct GramPlan {
+    int ld = 0;        // padded column count of A1 (multiple of 128)
+    int ntile = 0;     // ld / 128
+    int ntiles = 0;    // lower-triangular tile count
+    int nsplit = 0;    // split-K factor
+    int chunks = 0;    // K chunks (16 rows each) per split
+    int Mpad = 0;      // padded row count (multiple of 16*nsplit)
+    int nw = 1;        // number of weight vectors
+    size_t slab_doubles = 0;
+};
+GramPlan gram_plan(int Mf, int Nt, int nw);
+// T[w] (ld x ld, full symmetric) = A' diag(d[w]) A ; A is Mpad x ld row-major, d is nw x Mpad.
+void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
+                 const int* tile_ij, hipStream_t st);
+void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
+
+// Cholesky + inverse of the Cholesky factor.  H is np x np row-major (np multiple of 64), lower
+// triangle referenced; on exit H holds L (upper zeroed), M = L^-1 (lower), Mt = M'.
+// W1, W2 are np x np workspaces.  flag[0] != 0 on a non-positive pivot.
+void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st);
+
+// y[v] = Lo * b[v] for a row-major lower (upper=0) or upper (upper=1) triangular np x np matrix.
+void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
+                    hipStream_t st);
+
+// Spectral factorisation (fir_ap_cvx.m:185-186,264-304): x (2n-1) -> n taps (re, im interleaved
+// in hout[2n]).  work must hold 6*lp doubles, lp = 8*2^ceil(log2(2n-1)).
+int specfact_lp(int n);
+void specfact_launch(const double* x, int n, double* work, double* hout, hipStream_t st);
+
+}  // namespace mbfir

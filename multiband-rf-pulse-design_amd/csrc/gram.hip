@@ -1,0 +1,174 @@
+// K2: scaled Gram  T_w = A' diag(d_w) A  on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// A is the materialised frequency matrix (Mpad x ld, row-major: one row per frequency, so the
+// reduction index -- the frequency -- is the slow index and both MFMA operands are read as
+// 128-byte contiguous segments).  Work decomposition:
+//   * output tiles of 128 x 128, lower triangle only (T is symmetric);
+//   * split-K over the frequency axis (blockIdx.y) so that a (2n-1)^2 output still fills 256 CUs;
+//     partial tiles go to a slab and a second kernel adds them in a fixed order (deterministic);
+//   * per workgroup: 4 waves in a 2 x 2 arrangement, each owning a 64 x 64 sub-tile = 4 x 4 MFMA
+//     blocks (128 accumulator VGPRs per weight vector);
+//   * 16-row K chunks staged through LDS (register double-buffered, one barrier per chunk);
+//     LDS rows padded to 144 doubles so the 4 k-slices of one ds_read_b64 hit disjoint banks.
+// Algorithmic work: Mf * Nt * (Nt + 1) flop per weight vector (lower triangle).
+#include "dev_common.h"
+
+namespace mbfir {
+
+constexpr int GT = 128;
+constexpr int GKB = 16;
+constexpr int GLDP = 144;
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int ld,
+                                              const double* __restrict__ d, int Mpad, int chunks,
+                                              const int* __restrict__ tile_ij, int ntiles,
+                                              double* __restrict__ slab) {
+    __shared__ double As[2][GKB][GLDP];
+    __shared__ double Bs[2][GKB][GLDP];
+    __shared__ double Ds[2][NW][GKB];
+    const int t = blockIdx.x, split = blockIdx.y;
+    const int ti = tile_ij[2 * t], tj = tile_ij[2 * t + 1];
+    const bool diag = ti == tj;
+    const int I0 = ti * GT, J0 = tj * GT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wi = wv >> 1, wj = wv & 1;
+    const long k0 = (long)split * chunks * GKB;
+
+    v4d acc[NW][4][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[w][a][b] = (v4d){0, 0, 0, 0};
+
+    double2 ra[4], rb[4];
+    double rd = 0;
+    auto gload = [&](int c) {
+        const long kb = k0 + (long)c * GKB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = tid + 256 * q;
+            int row = idx >> 6, c2 = idx & 63;
+            const double* p = A + (kb + row) * ld;
+            ra[q] = *reinterpret_cast<const double2*>(p + I0 + 2 * c2);
+            if (!diag) rb[q] = *reinterpret_cast<const double2*>(p + J0 + 2 * c2);
+        }
+        if (tid < NW * GKB) rd = d[(long)(tid / GKB) * Mpad + kb + (tid % GKB)];
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = tid + 256 * q;
+            int row = idx >> 6, c2 = idx & 63;
+            *reinterpret_cast<double2*>(&As[buf][row][2 * c2]) = ra[q];
+            if (!diag) *reinterpret_cast<double2*>(&Bs[buf][row][2 * c2]) = rb[q];
+        }
+        if (tid < NW * GKB) Ds[buf][tid / GKB][tid % GKB] = rd;
+    };
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < chunks) gload(c + 1);
+        const double(*Bsrc)[GLDP] = diag ? As[buf] : Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < GKB / 4; ++kk) {
+            const int krow = kk * 4 + (lane >> 4);
+            double af[4], bf[4], dv[NW];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = As[buf][krow][wi * 64 + a * 16 + (lane & 15)];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = Bsrc[krow][wj * 64 + b * 16 + (lane & 15)];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dv[w] = Ds[buf][w][krow];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double bw = bf[b] * dv[w];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[w][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bw, acc[w][a][b], 0, 0, 0);
+                }
+        }
+        if (c + 1 < chunks) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double* out = slab + (((long)split * ntiles + t) * NW + w) * (GT * GT);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int i = wi * 64 + a * 16 + (lane >> 4) + 4 * r;
+                    int j = wj * 64 + b * 16 + (lane & 15);
+                    out[i * GT + j] = acc[w][a][b][r];
+                }
+    }
+}
+
+// Sum the split-K partial tiles in a fixed order and write the full symmetric T.
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ slab, int nsplit,
+                                                     int ntiles, int nw,
+                                                     const int* __restrict__ tile_ij, int ld,
+                                                     double* __restrict__ T) {
+    const int t = blockIdx.x, w = blockIdx.y;
+    const int ti = tile_ij[2 * t], tj = tile_ij[2 * t + 1];
+    const bool diag = ti == tj;
+    double* Tw = T + (long)w * ld * ld;
+    for (int e = threadIdx.x; e < GT * GT; e += 256) {
+        int i = e >> 7, j = e & 127;
+        if (diag && j > i) continue;
+        double v = 0;
+        for (int s = 0; s < nsplit; ++s) v += slab[(((long)s * ntiles + t) * nw + w) * (GT * GT) + e];
+        long gi = (long)ti * GT + i, gj = (long)tj * GT + j;
+        Tw[gi * ld + gj] = v;
+        Tw[gj * ld + gi] = v;
+    }
+}
+
+GramPlan gram_plan(int Mf, int Nt, int nw) {
+    GramPlan gp;
+    gp.nw = nw;
+    gp.ld = int(round_up(Nt, GT));
+    gp.ntile = gp.ld / GT;
+    gp.ntiles = gp.ntile * (gp.ntile + 1) / 2;
+    int total_chunks = cdiv(Mf, GKB);
+    int want = cdiv(512, gp.ntiles);
+    gp.nsplit = std::max(1, std::min(want, total_chunks));
+    gp.chunks = cdiv(total_chunks, gp.nsplit);
+    gp.nsplit = cdiv(total_chunks, gp.chunks);
+    gp.Mpad = gp.nsplit * gp.chunks * GKB;
+    gp.slab_doubles = (size_t)gp.nsplit * gp.ntiles * nw * GT * GT;
+    return gp;
+}
+
+void gram_tiles_host(const GramPlan& gp, int* tile_ij) {
+    int t = 0;
+    for (int i = 0; i < gp.ntile; ++i)
+        for (int j = 0; j <= i; ++j) { tile_ij[2 * t] = i; tile_ij[2 * t + 1] = j; ++t; }
+}
+
+void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
+                 const int* tile_ij, hipStream_t st) {
+    // One launch per weight vector: three accumulator sets (384 VGPRs) would spill, and the
+    // kernel is MFMA-bound, so re-reading A from L2/MALL costs nothing measurable.
+    dim3 grid(gp.ntiles, gp.nsplit);
+    const size_t per_w = (size_t)gp.nsplit * gp.ntiles * GT * GT;
+    for (int w = 0; w < gp.nw; ++w) {
+        hipLaunchKernelGGL(k_gram<1>, grid, dim3(256), 0, st, A, gp.ld, d + (size_t)w * gp.Mpad, gp.Mpad,
+                           gp.chunks, tile_ij, gp.ntiles, slab + w * per_w);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(gp.ntiles, 1), dim3(256), 0, st, slab + w * per_w, gp.nsplit,
+                           gp.ntiles, 1, tile_ij, gp.ld, T + (size_t)w * gp.ld * gp.ld);
+    }
+}
+
+}  // namespace mbfir

@@ -1,0 +1,46 @@
+// Host-visible interface of the device IPM (solver.hip).
+#pragma once
+#include "program.h"
+#include <vector>
+
+namespace mbfir {
+
+enum { ST_OPTIMAL = 0, ST_PRIMAL_INFEASIBLE = 1, ST_DUAL_INFEASIBLE = 2, ST_MAXIT = 3, ST_NUMERICAL = 4 };
+
+struct SolveOpts {
+    int max_iter = 200;
+    double feastol = 1e-8, abstol = 1e-10, reltol = 1e-8;
+    int refine = 2;
+    int verbose = 0;
+    bool timing = true;     // HIP-event timing of the Gram / Cholesky phases (adds two event syncs per iteration)
+};
+
+struct SolveInfo {
+    int status = 0, iters = 0, n_unknowns = 0, n_rows = 0, n_freq = 0;
+    double pcost = 0, dcost = 0, gap = 0, relgap = 0, pres = 0, dres = 0;
+    double ms_assemble = 0, ms_solve = 0, ms_gram = 0, ms_chol = 0, gram_flop = 0;
+};
+
+class Solver {
+public:
+    explicit Solver(int device);
+    ~Solver();
+    Solver(const Solver&) = delete;
+    Solver& operator=(const Solver&) = delete;
+    // Solve the conic program; xout = x / tau (N entries).  Returns ST_*; throws HipError.
+    int solve(const TrigProgram& P, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info);
+    // fir_ap_cvx tap extraction on the device from the solution left by the last solve().
+    void specfact_last(int n, double* h_re, double* h_im);
+    // kernel test hooks
+    void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
+    void test_chol(int n, const double* H, double* out_l, double* out_m);
+    void test_specfact(int n, const double* x, double* h_re, double* h_im);
+    void test_mfma_peak(double* tf_mfma, double* tf_valu);
+    void* stream() const;
+
+private:
+    struct Impl;
+    Impl* impl;
+};
+
+}  // namespace mbfir

@@ -1,0 +1,1490 @@
+// Device-resident primal-dual interior-point solver for the structured conic program of
+// program.h:   min c'z  s.t.  G z + s = h,  s in R_+^l x Q_3^nq3 x Q_big.
+//
+// Algorithm (identical, step for step, to the test oracle oracle/conic_ipm.py so the two agree to
+// rounding): homogeneous self-dual embedding, Nesterov-Todd scaling, Mehrotra predictor-corrector
+// (step fraction 0.99, sigma = (1-alpha_aff)^3), KKT systems reduced to the normal equations
+//   (G' W^-2 G) dx = bx + G' W^-2 bz ,  dz = W^-2 (G dx - bz)
+// with dz kept explicit and corrected incrementally (`refine` sweeps) so the dual equation
+// G'dz = bx holds to rounding.
+//
+// Per iteration on the GPU:
+//   K1  G v   : A1 * [v, P'v]  (k_amulti, HBM-bound, one wave per frequency row) + row gather
+//   K3  G' v  : per-frequency aggregation (CSR) + A1' * [p1, p2] (k_atmulti, HBM-bound)
+//   K6  NT scaling, per-frequency 2x2 weight blocks (k_freq_blocks)
+//   K2  T_k = A1' D_k A1 on the fp64 matrix cores (gram.hip), H assembled from T11,T12,T22 through
+//       the quadrature permutation P plus the sparse identity-row / border / big-cone terms
+//   K4  Cholesky + triangular inverse (chol.hip); every solve = two triangular GEMVs
+//   K5  step length: closed form per cone, block max-reductions, scalars stay on the device
+// One host synchronisation per iteration (termination test on 24 doubles).
+#include "dev_common.h"
+#include "cone_dev.h"
+#include "program.h"
+#include "solver.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace mbfir {
+
+enum {
+    S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
+    S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
+    S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD, S_COUNT = 64
+};
+constexpr double STEP = 0.99;
+constexpr int NPART = 1024;   // max blocks contributing to a reduction
+
+// ------------------------------------------------------------------------------------------------
+// device-side problem description
+struct DProg {
+    int Nt, Ne, N, Mf, R, l, nq3, big, quad;
+    int ld, Mpad, LDV, Rp, np;
+    const double *w, *col_tau, *col_scale, *psign, *c;
+    const int *col_kind, *pcol;
+    const int *freq, *col;
+    const double *alpha, *beta, *ey, *h;
+    const int *f_ptr, *f_rows;        // frequency -> rows
+    const int *c_ptr, *c_rows;        // column   -> identity rows
+    const int *yrows; int nyrows;     // rows with a non-zero ey
+};
+
+// ------------------------------------------------------------------------------------------------
+// trig matrix
+__global__ void k_build_A1(DProg P, double* __restrict__ A1) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= P.Nt || i >= P.Mf) return;
+    double sn, cs;
+    sincos(P.w[i] * P.col_tau[j], &sn, &cs);
+    A1[(long)i * P.ld + j] = P.col_scale[j] * (P.col_kind[j] ? sn : cs);
+}
+
+// XX = [v ; P'v]  (second half only when quad)
+template <int NV>
+__global__ void k_make_xx(DProg P, const double* __restrict__ v, double* __restrict__ XX) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.Nt) return;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double val = v[(long)q * P.LDV + j];
+        XX[(long)q * P.LDV + j] = val;
+        if (P.quad) XX[(long)(NV + q) * P.LDV + P.pcol[j]] = P.psign[j] * val;
+    }
+}
+
+// K1: U[v][i] = sum_j A1[i][j] XX[v][j]; one wave per frequency row, 16-byte loads.
+template <int NVV>
+__global__ __launch_bounds__(256) void k_amulti(const double* __restrict__ A1, int ld, int Mf,
+                                                const double* __restrict__ XX, int ldv,
+                                                double* __restrict__ UU, int Mpad) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= Mf) return;
+    const double* a = A1 + (long)row * ld;
+    double acc[NVV];
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) acc[v] = 0;
+    for (int j = 2 * lane; j < ld; j += 128) {
+        double2 t = *reinterpret_cast<const double2*>(a + j);
+#pragma unroll
+        for (int v = 0; v < NVV; ++v) {
+            double2 xv = *reinterpret_cast<const double2*>(XX + (long)v * ldv + j);
+            acc[v] += t.x * xv.x + t.y * xv.y;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) {
+        double s = wave_sum(acc[v]);
+        if (lane == 0) UU[(long)v * Mpad + row] = s;
+    }
+}
+
+// rows of G v from the per-frequency products
+template <int NV>
+__global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* __restrict__ X,
+                         double* __restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+    const int f = P.freq[r], cl = P.col[r];
+    const double al = P.alpha[r], be = P.beta[r];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double val = 0;
+        if (f >= 0) {
+            val = al * UU[(long)v * P.Mpad + f];
+            if (P.quad) val += be * UU[(long)(NV + v) * P.Mpad + f];
+        } else if (cl >= 0) {
+            val = al * X[(long)v * P.LDV + cl];
+        }
+        for (int e = 0; e < P.Ne; ++e) val += P.ey[3 * r + e] * X[(long)v * P.LDV + P.Nt + e];
+        out[(long)v * P.Rp + r] = val;
+    }
+}
+
+// K3 step 1: p1[i] = sum_{rows at i} alpha_r val_r, p2 likewise with beta
+template <int NV>
+__global__ void k_freq_agg(DProg P, const double* __restrict__ val, double* __restrict__ PP) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.Mf) return;
+    double p1[NV], p2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
+    for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
+        int r = P.f_rows[q];
+        double al = P.alpha[r], be = P.beta[r];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double x = val[(long)v * P.Rp + r];
+            p1[v] += al * x;
+            p2[v] += be * x;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        PP[(long)v * P.Mpad + i] = p1[v];
+        if (P.quad) PP[(long)(NV + v) * P.Mpad + i] = p2[v];
+    }
+}
+
+// K3 step 2: partial[split][v][j] = sum_{i in split} A1[i][j] PP[v][i].  Block = 64 x 4 threads:
+// 4 waves share 128 columns and interleave rows; partial sums are combined through LDS.
+constexpr int AT_ROWS = 256;
+template <int NVV>
+__global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, int ld, int Mpad,
+                                                 const double* __restrict__ PP, double* __restrict__ partial) {
+    __shared__ double sh[4][NVV][128];
+    const int lane = threadIdx.x, wq = threadIdx.y;
+    const int col0 = blockIdx.x * 128 + 2 * lane, split = blockIdx.y;
+    const int r0 = split * AT_ROWS, r1 = min(r0 + AT_ROWS, Mpad);
+    double2 acc[NVV];
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) acc[v] = make_double2(0, 0);
+#pragma unroll 4
+    for (int i = r0 + wq; i < r1; i += 4) {
+        double2 t = *reinterpret_cast<const double2*>(A1 + (long)i * ld + col0);
+#pragma unroll
+        for (int v = 0; v < NVV; ++v) {
+            double p = PP[(long)v * Mpad + i];
+            acc[v].x += t.x * p;
+            acc[v].y += t.y * p;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) {
+        sh[wq][v][2 * lane] = acc[v].x;
+        sh[wq][v][2 * lane + 1] = acc[v].y;
+    }
+    __syncthreads();
+    const int tid = wq * 64 + lane;
+    for (int e = tid; e < NVV * 128; e += 256) {
+        int v = e >> 7, cc = e & 127;
+        double s = sh[0][v][cc] + sh[1][v][cc] + sh[2][v][cc] + sh[3][v][cc];
+        partial[((long)split * NVV + v) * ld + blockIdx.x * 128 + cc] = s;
+    }
+}
+
+// K3 step 3: fold the split partials, apply the quadrature permutation, add identity rows.
+template <int NV>
+__global__ void k_gt_combine(DProg P, const double* __restrict__ partial, int nsplit,
+                             const double* __restrict__ val, double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.Nt) return;
+    const int NVV = P.quad ? 2 * NV : NV;
+    const int pj = P.quad ? P.pcol[j] : 0;
+    const double sj = P.quad ? P.psign[j] : 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double t1 = 0, t2 = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            t1 += partial[((long)s * NVV + v) * P.ld + j];
+            if (P.quad) t2 += partial[((long)s * NVV + NV + v) * P.ld + pj];
+        }
+        double g = t1 + sj * t2;
+        for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
+            int r = P.c_rows[q];
+            g += P.alpha[r] * val[(long)v * P.Rp + r];
+        }
+        out[(long)v * P.LDV + j] = g;
+    }
+}
+// y block of G'v:  out[v][Nt+e] = sum_r ey[r][e] val[v][r]   (one block)
+template <int NV>
+__global__ __launch_bounds__(256) void k_gt_y(DProg P, const double* __restrict__ val, double* __restrict__ out) {
+    __shared__ double sh[17];
+    for (int v = 0; v < NV; ++v)
+        for (int e = 0; e < P.Ne; ++e) {
+            double a = 0;
+            for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
+                int r = P.yrows[q];
+                a += P.ey[3 * r + e] * val[(long)v * P.Rp + r];
+            }
+            a = block_sum(a, sh);
+            if (threadIdx.x == 0) out[(long)v * P.LDV + P.Nt + e] = a;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions: every block writes NC partial values; scalar kernels fold them in a fixed order
+template <int NC>
+__device__ __forceinline__ void block_partials(double vals[NC], double* __restrict__ part, bool is_max) {
+    __shared__ double sh[17];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double s = is_max ? block_max(vals[c], sh) : block_sum(vals[c], sh);
+        if (threadIdx.x == 0) part[(long)blockIdx.x * NC + c] = s;
+    }
+}
+__device__ __forceinline__ double fold_partials(const double* part, int nb, int nc, int c, bool is_max, double* sh) {
+    double a = is_max ? -1e300 : 0.0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        double v = part[(long)b * nc + c];
+        a = is_max ? fmax(a, v) : a + v;
+    }
+    return is_max ? block_max(a, sh) : block_sum(a, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// big cone (one workgroup).  Vectors are slices at offset ob of the R-space vectors.
+struct BigW {
+    double eta, w0;
+};
+__device__ __forceinline__ double big_dot(const double* a, const double* b, int n, double* sh) {
+    double t = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t += a[i] * b[i];
+    return block_sum(t, sh);
+}
+
+// scaling of the big cone: wbb (w0 in [0], w1 in [1..]), eta -> Sc[S_ETAB]; lam = W z
+__global__ __launch_bounds__(1024) void k_big_scaling(int big, const double* __restrict__ s,
+                                                      const double* __restrict__ z, double* __restrict__ wbb,
+                                                      double* __restrict__ lam, double* __restrict__ Sc) {
+    __shared__ double sh[17];
+    const int n1 = big - 1;
+    double ns = sqrt(big_dot(s + 1, s + 1, n1, sh)), nz = sqrt(big_dot(z + 1, z + 1, n1, sh));
+    double a = sqrt(jres(s[0], ns)), b = sqrt(jres(z[0], nz));
+    double sz1 = big_dot(s + 1, z + 1, n1, sh);
+    double gamma = sqrt((1.0 + (s[0] * z[0] + sz1) / (a * b)) / 2.0);
+    double w0 = (s[0] / a + z[0] / b) / (2 * gamma);
+    double eta = sqrt(a / b);
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) wbb[1 + i] = (s[1 + i] / a - z[1 + i] / b) / (2 * gamma);
+    if (threadIdx.x == 0) { wbb[0] = w0; Sc[S_ETAB] = eta; Sc[S_WB0] = w0; }
+    __syncthreads();
+    // lam = W z
+    double dot = big_dot(wbb + 1, z + 1, n1, sh);
+    double f = z[0] + dot / (1 + w0);
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) lam[1 + i] = (z[1 + i] + f * wbb[1 + i]) * eta;
+    if (threadIdx.x == 0) lam[0] = (w0 * z[0] + dot) * eta;
+}
+
+// out = W u / W^-1 u for the big cone (device function; all threads of the block participate)
+__device__ __forceinline__ void big_apply(int big, const double* wbb, double eta, const double* u, double* out,
+                                          bool inverse, double* sh) {
+    const int n1 = big - 1;
+    const double w0 = wbb[0], u0 = u[0];
+    double dot = big_dot(wbb + 1, u + 1, n1, sh);
+    if (inverse) {
+        double f = -u0 + dot / (1 + w0);
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) out[1 + i] = (u[1 + i] + f * wbb[1 + i]) / eta;
+        __syncthreads();
+        if (threadIdx.x == 0) out[0] = (w0 * u0 - dot) / eta;
+    } else {
+        double f = u0 + dot / (1 + w0);
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) out[1 + i] = (u[1 + i] + f * wbb[1 + i]) * eta;
+        __syncthreads();
+        if (threadIdx.x == 0) out[0] = (w0 * u0 + dot) * eta;
+    }
+    __syncthreads();
+}
+// out (op)= W^-2 v : mode 0: out = W^-2 v - sub (sub may be null) ; mode 1: out += W^-2 v
+__device__ __forceinline__ void big_inv2(int big, const double* wbb, double eta, const double* v, const double* sub,
+                                         double* out, int mode, double* sh) {
+    const int n1 = big - 1;
+    const double u0 = wbb[0], e2 = 1.0 / (eta * eta), v0 = v[0];
+    double uv = u0 * v0 - big_dot(wbb + 1, v + 1, n1, sh);          // (Jw)'v
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+        double t = (2 * (-wbb[1 + i]) * uv + v[1 + i]) * e2;
+        if (mode == 0) out[1 + i] = t - (sub ? sub[1 + i] : 0.0);
+        else out[1 + i] += t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = (2 * u0 * uv - v0) * e2;
+        if (mode == 0) out[0] = t - (sub ? sub[0] : 0.0);
+        else out[0] += t;
+    }
+    __syncthreads();
+}
+// max-step term ||rho1|| - rho0 for direction d relative to lam
+__device__ __forceinline__ double big_step(int big, const double* lam, const double* d, double* sh) {
+    const int n1 = big - 1;
+    double nl = sqrt(big_dot(lam + 1, lam + 1, n1, sh));
+    double a = sqrt(jres(lam[0], nl));
+    double lb0 = lam[0] / a;
+    double dot = big_dot(lam + 1, d + 1, n1, sh) / a;                 // lbar1'd1
+    double rho0 = (lb0 * d[0] - dot) / a;
+    double f = -d[0] + dot / (1 + lb0);
+    double t = 0;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+        double r = (d[1 + i] + f * lam[1 + i] / a) / a;
+        t += r * r;
+    }
+    t = block_sum(t, sh);
+    return sqrt(t) - rho0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 scaling for LP rows and Q3 cones (thread per cone); lam = W z
+__global__ void k_scaling(DProg P, const double* __restrict__ s, const double* __restrict__ z,
+                          double* __restrict__ dl, double* __restrict__ wl, double* __restrict__ w3,
+                          double* __restrict__ lam) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.l) {
+        double sv = s[t], zv = z[t];
+        dl[t] = zv / sv;
+        wl[t] = sqrt(sv / zv);
+        lam[t] = sqrt(sv * zv);
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l, r = P.l + 3 * c;
+        double ss[3] = {s[r], s[r + 1], s[r + 2]}, zz[3] = {z[r], z[r + 1], z[r + 2]}, ll[3];
+        Soc3 W = soc3_scaling(ss, zz);
+        soc3_apply(W, zz, ll, false);
+        w3[4 * c] = W.eta; w3[4 * c + 1] = W.w0; w3[4 * c + 2] = W.w1; w3[4 * c + 3] = W.w2;
+        lam[r] = ll[0]; lam[r + 1] = ll[1]; lam[r + 2] = ll[2];
+    }
+}
+__device__ __forceinline__ Soc3 load_w3(const double* w3, int c) {
+    Soc3 W;
+    W.eta = w3[4 * c]; W.w0 = w3[4 * c + 1]; W.w1 = w3[4 * c + 2]; W.w2 = w3[4 * c + 3];
+    return W;
+}
+
+// out = W^-2 in - sub  (mode 0)   or   out += W^-2 in  (mode 1), LP rows + Q3 cones
+template <int NV>
+__global__ void k_winv2(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                        const double* __restrict__ in, const double* __restrict__ sub, double* __restrict__ out,
+                        int mode) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.l) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            long o = (long)v * P.Rp + t;
+            double val = dl[t] * in[o];
+            if (mode == 0) out[o] = val - (sub ? sub[o] : 0.0);
+            else out[o] += val;
+        }
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l;
+        Soc3 W = load_w3(w3, c);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            long o = (long)v * P.Rp + P.l + 3 * c;
+            double vv[3] = {in[o], in[o + 1], in[o + 2]}, rr[3];
+            soc3_inv2_apply(W, vv, rr);
+            for (int a = 0; a < 3; ++a) {
+                if (mode == 0) out[o + a] = rr[a] - (sub ? sub[o + a] : 0.0);
+                else out[o + a] += rr[a];
+            }
+        }
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(1024) void k_big_winv2(DProg P, const double* __restrict__ wbb,
+                                                    const double* __restrict__ Sc, const double* __restrict__ in,
+                                                    const double* __restrict__ sub, double* __restrict__ out, int mode) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    for (int v = 0; v < NV; ++v) {
+        long o = (long)v * P.Rp + ob;
+        big_inv2(P.big, wbb, Sc[S_ETAB], in + o, sub ? sub + o : nullptr, out + o, mode, sh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residuals
+// rows: rz = Gx + s - h tau ; bz batch: [0] = h (constant system), [1] = s - rz (affine)
+__global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __restrict__ Gx, const double* __restrict__ s,
+                                                    const double* __restrict__ z, const double* __restrict__ Sc,
+                                                    double* __restrict__ rz, double* __restrict__ bz2,
+                                                    double* __restrict__ part) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[4] = {0, 0, 0, 0};
+    if (r < P.R) {
+        double tau = Sc[S_TAU], gx = Gx[r], sv = s[r], zv = z[r], hv = P.h[r];
+        double res = gx + sv - hv * tau;
+        rz[r] = res;
+        bz2[r] = hv;
+        bz2[P.Rp + r] = sv - res;
+        v[0] = res * res; v[1] = sv * zv; v[2] = hv * zv; v[3] = (gx + sv) * (gx + sv);
+    }
+    block_partials<4>(v, part, false);
+}
+// columns: rx = G'z + c tau ; bx batch: [0] = -c, [1] = -rx
+__global__ __launch_bounds__(256) void k_resid_cols(DProg P, const double* __restrict__ GTz, const double* __restrict__ x,
+                                                    const double* __restrict__ Sc, double* __restrict__ rx,
+                                                    double* __restrict__ bx2, double* __restrict__ part) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[3] = {0, 0, 0};
+    if (j < P.N) {
+        double tau = Sc[S_TAU], g = GTz[j], cv = P.c[j];
+        double res = g + cv * tau;
+        rx[j] = res;
+        bx2[j] = -cv;
+        bx2[P.LDV + j] = -res;
+        v[0] = res * res; v[1] = cv * x[j]; v[2] = g * g;
+    }
+    block_partials<3>(v, part, false);
+}
+__global__ __launch_bounds__(256) void k_scal_resid(double* __restrict__ Sc, const double* __restrict__ partR, int nbR,
+                                                    const double* __restrict__ partN, int nbN) {
+    __shared__ double sh[17];
+    double rz2 = fold_partials(partR, nbR, 4, 0, false, sh);
+    double sz = fold_partials(partR, nbR, 4, 1, false, sh);
+    double hz = fold_partials(partR, nbR, 4, 2, false, sh);
+    double gxs2 = fold_partials(partR, nbR, 4, 3, false, sh);
+    double rx2 = fold_partials(partN, nbN, 3, 0, false, sh);
+    double cx = fold_partials(partN, nbN, 3, 1, false, sh);
+    double gtz2 = fold_partials(partN, nbN, 3, 2, false, sh);
+    if (threadIdx.x == 0) {
+        double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
+        Sc[S_RT] = kap + cx + hz;
+        Sc[S_MU] = (sz + kap * tau) / (Sc[S_DEG] + 1.0);
+        Sc[S_CX] = cx; Sc[S_HZ] = hz; Sc[S_SZ] = sz;
+        double pcost = cx / tau, dcost = -hz / tau, gap = sz / (tau * tau);
+        Sc[S_PCOST] = pcost; Sc[S_DCOST] = dcost; Sc[S_GAP] = gap;
+        Sc[S_PRES] = sqrt(rz2) / tau / Sc[S_NRMH];
+        Sc[S_DRES] = sqrt(rx2) / tau / Sc[S_NRMC];
+        double den = fmax(fabs(pcost), fabs(dcost));
+        Sc[S_RELGAP] = den > 0 ? gap / den : 1e300;
+        Sc[S_PINF] = hz < 0 ? sqrt(gtz2) / (-hz) : 1e300;
+        Sc[S_DINF] = cx < 0 ? sqrt(gxs2) / (-cx) : 1e300;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// N-space helpers
+// rhs[v][j] = bx[v][j] + t[v][j]
+template <int NV>
+__global__ void k_add_n(DProg P, const double* __restrict__ a, const double* __restrict__ b, double sb,
+                        double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.N) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        long o = (long)v * P.LDV + j;
+        out[o] = a[o] + sb * b[o];
+    }
+}
+template <int NV>
+__global__ void k_axpy_n(DProg P, const double* __restrict__ a, double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.N) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[(long)v * P.LDV + j] += a[(long)v * P.LDV + j];
+}
+
+// dots needed for dtau: c'x1, c'x2 (N space) ; h'z1, h'z2, ||W z1||^2 (R space)
+__global__ __launch_bounds__(256) void k_dots_n(DProg P, const double* __restrict__ x1, const double* __restrict__ x2,
+                                                double* __restrict__ part) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[2] = {0, 0};
+    if (j < P.N) { v[0] = P.c[j] * x1[j]; v[1] = P.c[j] * x2[j]; }
+    block_partials<2>(v, part, false);
+}
+__global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+                                                const double* __restrict__ z1, const double* __restrict__ z2,
+                                                double* __restrict__ part) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[3] = {0, 0, 0};
+    if (t < P.l) {
+        v[0] = P.h[t] * z1[t]; v[1] = P.h[t] * z2[t];
+        double wz = wl[t] * z1[t];
+        v[2] = wz * wz;
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l, r = P.l + 3 * c;
+        Soc3 W = load_w3(w3, c);
+        double zz[3] = {z1[r], z1[r + 1], z1[r + 2]}, wz[3];
+        soc3_apply(W, zz, wz, false);
+        for (int a = 0; a < 3; ++a) { v[0] += P.h[r + a] * z1[r + a]; v[1] += P.h[r + a] * z2[r + a]; v[2] += wz[a] * wz[a]; }
+    }
+    block_partials<3>(v, part, false);
+}
+// big-cone contribution to the same three sums (written as one extra partial row)
+__global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __restrict__ wbb, const double* __restrict__ Sc,
+                                                   const double* __restrict__ z1, const double* __restrict__ z2,
+                                                   double* __restrict__ scratch, double* __restrict__ part_row) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    double a = big_dot(P.h + ob, z1 + ob, P.big, sh);
+    double b = big_dot(P.h + ob, z2 + ob, P.big, sh);
+    big_apply(P.big, wbb, Sc[S_ETAB], z1 + ob, scratch, false, sh);
+    double c = big_dot(scratch, scratch, P.big, sh);
+    if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; part_row[2] = c; }
+}
+
+// dtau for the affine (mode 0) or the combined (mode 1) direction
+__global__ __launch_bounds__(256) void k_scal_dtau(double* __restrict__ Sc, const double* __restrict__ partN, int nbN,
+                                                   const double* __restrict__ partR, int nbR, int mode) {
+    __shared__ double sh[17];
+    double cx1 = fold_partials(partN, nbN, 2, 0, false, sh);
+    double cx2 = fold_partials(partN, nbN, 2, 1, false, sh);
+    double hz1 = fold_partials(partR, nbR, 3, 0, false, sh);
+    double hz2 = fold_partials(partR, nbR, 3, 1, false, sh);
+    double wz1 = fold_partials(partR, nbR, 3, 2, false, sh);
+    if (threadIdx.x == 0) {
+        double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
+        double den = kap / tau + wz1;
+        (void)cx1; (void)hz1;
+        if (mode == 0) {
+            double dkc = -kap * tau, bt = -Sc[S_RT];
+            Sc[S_DTAU_A] = (dkc / tau - bt + cx2 + hz2) / den;
+            Sc[S_DKAP_A] = (dkc - kap * Sc[S_DTAU_A]) / tau;
+        } else {
+            double sigma = Sc[S_SIGMA];
+            double dkc = sigma * Sc[S_MU] - kap * tau - Sc[S_DKAP_A] * Sc[S_DTAU_A];
+            double bt = -(1 - sigma) * Sc[S_RT];
+            Sc[S_DTAU] = (dkc / tau - bt + cx2 + hz2) / den;
+            Sc[S_DKAP] = (dkc - kap * Sc[S_DTAU]) / tau;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// affine direction in the scaled space:  dz = z2 + dtau z1 ; wdz = W dz ; dss = -lam - wdz
+// (lam \ (-lam o lam) = -lam).  Stores dssa, wdza; emits the two step-length maxima.
+__global__ __launch_bounds__(256) void k_aff_post(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+                                                  const double* __restrict__ lam, const double* __restrict__ z1,
+                                                  const double* __restrict__ z2, const double* __restrict__ Sc,
+                                                  double* __restrict__ dssa, double* __restrict__ wdza,
+                                                  double* __restrict__ part) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double dtau = Sc[S_DTAU_A];
+    double v[2] = {-1e300, -1e300};
+    if (t < P.l) {
+        double dz = z2[t] + dtau * z1[t], wdz = wl[t] * dz, l = lam[t];
+        double dss = -l - wdz;
+        dssa[t] = dss; wdza[t] = wdz;
+        v[0] = -dss / l; v[1] = -wdz / l;
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l, r = P.l + 3 * c;
+        Soc3 W = load_w3(w3, c);
+        double dz[3], wdz[3], dss[3], ll[3];
+        for (int a = 0; a < 3; ++a) { dz[a] = z2[r + a] + dtau * z1[r + a]; ll[a] = lam[r + a]; }
+        soc3_apply(W, dz, wdz, false);
+        for (int a = 0; a < 3; ++a) { dss[a] = -ll[a] - wdz[a]; dssa[r + a] = dss[a]; wdza[r + a] = wdz[a]; }
+        v[0] = soc3_step(ll, dss); v[1] = soc3_step(ll, wdz);
+    }
+    block_partials<2>(v, part, true);
+}
+__global__ __launch_bounds__(1024) void k_big_aff_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
+                                                       const double* __restrict__ z1, const double* __restrict__ z2,
+                                                       const double* __restrict__ Sc, double* __restrict__ dssa,
+                                                       double* __restrict__ wdza, double* __restrict__ scratch,
+                                                       double* __restrict__ part_row) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    const double dtau = Sc[S_DTAU_A];
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) scratch[i] = z2[ob + i] + dtau * z1[ob + i];
+    __syncthreads();
+    big_apply(P.big, wbb, Sc[S_ETAB], scratch, wdza + ob, false, sh);
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dssa[ob + i] = -lam[ob + i] - wdza[ob + i];
+    __syncthreads();
+    double a = big_step(P.big, lam + ob, dssa + ob, sh);
+    double b = big_step(P.big, lam + ob, wdza + ob, sh);
+    if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; }
+}
+// step length + sigma (mode 0, affine) or final alpha and tau/kappa update (mode 1)
+__global__ __launch_bounds__(256) void k_scal_step(double* __restrict__ Sc, const double* __restrict__ part, int nb, int mode) {
+    __shared__ double sh[17];
+    double ts = fold_partials(part, nb, 2, 0, true, sh);
+    double tz = fold_partials(part, nb, 2, 1, true, sh);
+    if (threadIdx.x == 0) {
+        double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
+        double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+        double dkap = mode == 0 ? Sc[S_DKAP_A] : Sc[S_DKAP];
+        double t = fmax(0.0, fmax(fmax(ts, tz), fmax(-dtau / tau, -dkap / kap)));
+        Sc[S_TMAX] = t;
+        if (mode == 0) {
+            double a = t == 0.0 ? 1.0 : fmin(1.0, 1.0 / t);
+            Sc[S_ALPHA_A] = a;
+            Sc[S_SIGMA] = (1 - a) * (1 - a) * (1 - a);
+        } else {
+            double a = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
+            Sc[S_ALPHA] = a;
+            Sc[S_TAU] = tau + a * dtau;
+            Sc[S_KAPPA] = kap + a * dkap;
+        }
+    }
+}
+
+// combined right-hand side: ds_c = sigma mu e - lam o lam - dssa o wdza ; lds = lam \ ds_c ;
+// bz = -(1-sigma) rz - W lds ;  (bx = -(1-sigma) rx is formed by k_comb_bx)
+__global__ void k_comb_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+                           const double* __restrict__ lam, const double* __restrict__ dssa,
+                           const double* __restrict__ wdza, const double* __restrict__ rz,
+                           const double* __restrict__ Sc, double* __restrict__ lds, double* __restrict__ bz) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double sigma = Sc[S_SIGMA], smu = sigma * Sc[S_MU];
+    if (t < P.l) {
+        double l = lam[t];
+        double dsc = smu - l * l - dssa[t] * wdza[t];
+        double q = dsc / l;
+        lds[t] = q;
+        bz[t] = -(1 - sigma) * rz[t] - wl[t] * q;
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l, r = P.l + 3 * c;
+        Soc3 W = load_w3(w3, c);
+        double ll[3] = {lam[r], lam[r + 1], lam[r + 2]}, a3[3] = {dssa[r], dssa[r + 1], dssa[r + 2]},
+               b3[3] = {wdza[r], wdza[r + 1], wdza[r + 2]}, p1[3], p2[3], dsc[3], q[3], wq[3];
+        soc3_prod(ll, ll, p1);
+        soc3_prod(a3, b3, p2);
+        dsc[0] = smu - p1[0] - p2[0]; dsc[1] = -p1[1] - p2[1]; dsc[2] = -p1[2] - p2[2];
+        soc3_div(ll, dsc, q);
+        soc3_apply(W, q, wq, false);
+        for (int a = 0; a < 3; ++a) { lds[r + a] = q[a]; bz[r + a] = -(1 - sigma) * rz[r + a] - wq[a]; }
+    }
+}
+__global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
+                                                       const double* __restrict__ dssa, const double* __restrict__ wdza,
+                                                       const double* __restrict__ rz, const double* __restrict__ Sc,
+                                                       double* __restrict__ lds, double* __restrict__ bz,
+                                                       double* __restrict__ scratch) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    const int n1 = P.big - 1;
+    const double sigma = Sc[S_SIGMA], smu = sigma * Sc[S_MU];
+    const double* L = lam + ob;
+    const double* A = dssa + ob;
+    const double* B = wdza + ob;
+    double ll = big_dot(L, L, P.big, sh), ab = big_dot(A, B, P.big, sh);
+    double l0 = L[0], a0 = A[0], b0 = B[0];
+    // dsc = sigma mu e - lam o lam - dssa o wdza  -> scratch
+    for (int i = threadIdx.x; i < n1; i += blockDim.x)
+        scratch[1 + i] = -(2 * l0 * L[1 + i]) - (a0 * B[1 + i] + b0 * A[1 + i]);
+    if (threadIdx.x == 0) scratch[0] = smu - ll - ab;
+    __syncthreads();
+    // q = lam \ dsc  -> lds
+    double nl = sqrt(big_dot(L + 1, L + 1, n1, sh));
+    double a = jres(l0, nl);
+    double ld = big_dot(L + 1, scratch + 1, n1, sh);
+    double q0 = (l0 * scratch[0] - ld) / a;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) lds[ob + 1 + i] = (scratch[1 + i] - q0 * L[1 + i]) / l0;
+    if (threadIdx.x == 0) lds[ob] = q0;
+    __syncthreads();
+    // bz = -(1-sigma) rz - W q
+    big_apply(P.big, wbb, Sc[S_ETAB], lds + ob, scratch, false, sh);
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) bz[ob + i] = -(1 - sigma) * rz[ob + i] - scratch[i];
+}
+__global__ void k_comb_bx(DProg P, const double* __restrict__ rx, const double* __restrict__ Sc, double* __restrict__ bx) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P.N) bx[j] = -(1 - Sc[S_SIGMA]) * rx[j];
+}
+
+// combined direction: dz = z2 + dtau z1 ; wdz = W dz ; dss = lds - wdz ; ds = W dss
+__global__ __launch_bounds__(256) void k_comb_post(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+                                                   const double* __restrict__ lam, const double* __restrict__ lds,
+                                                   const double* __restrict__ z1, const double* __restrict__ z2,
+                                                   const double* __restrict__ Sc, double* __restrict__ ds,
+                                                   double* __restrict__ dz, double* __restrict__ part) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double dtau = Sc[S_DTAU];
+    double v[2] = {-1e300, -1e300};
+    if (t < P.l) {
+        double d = z2[t] + dtau * z1[t], wdz = wl[t] * d, l = lam[t];
+        double dss = lds[t] - wdz;
+        dz[t] = d; ds[t] = wl[t] * dss;
+        v[0] = -dss / l; v[1] = -wdz / l;
+    } else if (t < P.l + P.nq3) {
+        int c = t - P.l, r = P.l + 3 * c;
+        Soc3 W = load_w3(w3, c);
+        double d3[3], wdz[3], dss[3], ll[3], dsv[3];
+        for (int a = 0; a < 3; ++a) { d3[a] = z2[r + a] + dtau * z1[r + a]; ll[a] = lam[r + a]; }
+        soc3_apply(W, d3, wdz, false);
+        for (int a = 0; a < 3; ++a) dss[a] = lds[r + a] - wdz[a];
+        soc3_apply(W, dss, dsv, false);
+        for (int a = 0; a < 3; ++a) { dz[r + a] = d3[a]; ds[r + a] = dsv[a]; }
+        v[0] = soc3_step(ll, dss); v[1] = soc3_step(ll, wdz);
+    }
+    block_partials<2>(v, part, true);
+}
+__global__ __launch_bounds__(1024) void k_big_comb_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
+                                                        const double* __restrict__ lds, const double* __restrict__ z1,
+                                                        const double* __restrict__ z2, const double* __restrict__ Sc,
+                                                        double* __restrict__ ds, double* __restrict__ dz,
+                                                        double* __restrict__ scratch, double* __restrict__ part_row) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    const double dtau = Sc[S_DTAU];
+    double* wdz = scratch;
+    double* dss = scratch + P.big;
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dz[ob + i] = z2[ob + i] + dtau * z1[ob + i];
+    __syncthreads();
+    big_apply(P.big, wbb, Sc[S_ETAB], dz + ob, wdz, false, sh);
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dss[i] = lds[ob + i] - wdz[i];
+    __syncthreads();
+    big_apply(P.big, wbb, Sc[S_ETAB], dss, ds + ob, false, sh);
+    double a = big_step(P.big, lam + ob, dss, sh);
+    double b = big_step(P.big, lam + ob, wdz, sh);
+    if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; }
+}
+
+// x += alpha (x2 + dtau x1) ; s += alpha ds ; z += alpha dz
+__global__ void k_update(DProg P, const double* __restrict__ Sc, const double* __restrict__ x1,
+                         const double* __restrict__ x2, double* __restrict__ x, const double* __restrict__ ds,
+                         const double* __restrict__ dz, double* __restrict__ s, double* __restrict__ z) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a = Sc[S_ALPHA], dtau = Sc[S_DTAU];
+    if (t < P.N) x[t] += a * (x2[t] + dtau * x1[t]);
+    if (t < P.R) { s[t] += a * ds[t]; z[t] += a * dz[t]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// H assembly
+// per-frequency 2x2 weight block [D11 D12; D12 D22] and border vectors B1[e], B2[e]
+__global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                              double* __restrict__ Dw, double* __restrict__ BB) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.Mf) return;
+    double d11 = 0, d12 = 0, d22 = 0, b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0};
+    for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
+        int r = P.f_rows[q];
+        if (r < P.l) {
+            double d = dl[r], al = P.alpha[r], be = P.beta[r];
+            d11 += d * al * al; d12 += d * al * be; d22 += d * be * be;
+            for (int e = 0; e < P.Ne; ++e) { b1[e] += d * al * P.ey[3 * r + e]; b2[e] += d * be * P.ey[3 * r + e]; }
+        } else {
+            int c = (r - P.l) / 3, a = (r - P.l) - 3 * c;
+            if (a != 1) continue;                       // a cone is handled once, at its first trig row
+            int r0 = P.l + 3 * c;
+            double m[6];
+            soc3_inv2(load_w3(w3, c), m);
+            double al[3] = {0, P.alpha[r0 + 1], P.alpha[r0 + 2]}, be[3] = {0, P.beta[r0 + 1], P.beta[r0 + 2]};
+            for (int p = 1; p < 3; ++p)
+                for (int s = 1; s < 3; ++s) {
+                    double mm = sym3(m, p, s);
+                    d11 += mm * al[p] * al[s]; d12 += mm * al[p] * be[s]; d22 += mm * be[p] * be[s];
+                }
+            for (int e = 0; e < P.Ne; ++e) {
+                for (int p = 1; p < 3; ++p) {
+                    double t = 0;
+                    for (int s = 0; s < 3; ++s) t += sym3(m, p, s) * P.ey[3 * (r0 + s) + e];
+                    b1[e] += al[p] * t; b2[e] += be[p] * t;
+                }
+            }
+        }
+    }
+    Dw[i] = d11;
+    if (P.quad) { Dw[P.Mpad + i] = d12; Dw[2L * P.Mpad + i] = d22; }
+    for (int e = 0; e < P.Ne; ++e) {
+        BB[(long)e * P.Mpad + i] = b1[e];
+        if (P.quad) BB[(long)(P.Ne + e) * P.Mpad + i] = b2[e];
+    }
+}
+
+// H (np x np) from the Gram matrices and the border products.  TT[v][j] = (A1' BB[v])[j].
+__global__ void k_assemble_H(DProg P, const double* __restrict__ T, const double* __restrict__ TT,
+                             double* __restrict__ H) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (k >= P.np || j >= P.np) return;
+    double v = 0;
+    const long ld = P.ld, ld2 = ld * ld;
+    if (j < P.Nt && k < P.Nt) {
+        v = T[j * ld + k];
+        if (P.quad) {
+            int pj = P.pcol[j], pk = P.pcol[k];
+            double sj = P.psign[j], sk = P.psign[k];
+            v += sj * sk * T[2 * ld2 + pj * ld + pk] + sk * T[ld2 + j * ld + pk] + sj * T[ld2 + pj * ld + k];
+        }
+    } else if (j < P.N && k < P.N) {
+        int jj = j < k ? j : k, kk = j < k ? k : j;       // jj < Nt <= kk  or both >= Nt
+        if (jj < P.Nt) {
+            int e = kk - P.Nt;
+            v = TT[(long)e * P.LDV + jj];
+            if (P.quad) v += P.psign[jj] * TT[(long)(P.Ne + e) * P.LDV + P.pcol[jj]];
+        }
+    } else if (j == k) {
+        v = 1.0;                                          // padding
+    }
+    H[(long)j * P.np + k] = v;
+}
+// fold the atmulti partials of the border products: TT[v][j] = sum_s partial[s][v][j]
+__global__ void k_fold_tt(DProg P, const double* __restrict__ partial, int nsplit, int nvv, double* __restrict__ TT) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (j >= P.ld) return;
+    double t = 0;
+    for (int s = 0; s < nsplit; ++s) t += partial[((long)s * nvv + v) * P.ld + j];
+    TT[(long)v * P.LDV + j] = t;
+}
+// identity rows: thread j owns row j of H (and the mirrored border entries)
+__global__ void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                             double* __restrict__ H) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.Nt) return;
+    const long np = P.np;
+    for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
+        int r = P.c_rows[q];
+        double al = P.alpha[r];
+        if (r < P.l) {
+            double d = dl[r];
+            H[j * np + j] += d * al * al;
+            for (int e = 0; e < P.Ne; ++e) {
+                double t = d * al * P.ey[3 * r + e];
+                H[j * np + P.Nt + e] += t;
+                H[(P.Nt + e) * np + j] += t;
+            }
+        } else if (r < P.l + 3 * P.nq3) {
+            int c = (r - P.l) / 3, a = (r - P.l) - 3 * c, r0 = P.l + 3 * c;
+            double m[6];
+            soc3_inv2(load_w3(w3, c), m);
+            for (int b = 0; b < 3; ++b) {
+                double mm = sym3(m, a, b);
+                int cb = P.col[r0 + b];
+                if (cb >= 0) H[j * np + cb] += al * P.alpha[r0 + b] * mm;
+                for (int e = 0; e < P.Ne; ++e) {
+                    double t = al * mm * P.ey[3 * (r0 + b) + e];
+                    H[j * np + P.Nt + e] += t;
+                    H[(P.Nt + e) * np + j] += t;
+                }
+            }
+        }
+    }
+}
+// y-y block: sum over rows with a non-zero ey (LP rows and Q3 cones); one block
+__global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                              double* __restrict__ H) {
+    __shared__ double sh[17];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
+        int r = P.yrows[q];
+        if (r < P.l) {
+            double d = dl[r];
+            for (int e = 0; e < P.Ne; ++e)
+                for (int f = 0; f < P.Ne; ++f) acc[3 * e + f] += d * P.ey[3 * r + e] * P.ey[3 * r + f];
+        } else if (r < P.l + 3 * P.nq3) {
+            int c = (r - P.l) / 3, a = (r - P.l) - 3 * c, r0 = P.l + 3 * c;
+            double m[6];
+            soc3_inv2(load_w3(w3, c), m);
+            for (int b = 0; b < 3; ++b)
+                for (int e = 0; e < P.Ne; ++e)
+                    for (int f = 0; f < P.Ne; ++f)
+                        acc[3 * e + f] += P.ey[3 * r + e] * sym3(m, a, b) * P.ey[3 * (r0 + b) + f];
+        }
+    }
+    for (int e = 0; e < P.Ne; ++e)
+        for (int f = 0; f < P.Ne; ++f) {
+            double t = block_sum(acc[3 * e + f], sh);
+            if (threadIdx.x == 0) H[(long)(P.Nt + e) * P.np + P.Nt + f] += t;
+        }
+}
+// big cone: q = G_b'(J wbar)  then  H += eta^-2 (2 q q' - G_b' J G_b)
+__global__ void k_big_q(DProg P, const double* __restrict__ wbb, double* __restrict__ qv, double* __restrict__ qd) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const long ob = P.l + 3L * P.nq3;
+    if (t >= P.big) return;
+    int r = int(ob) + t;
+    double u = t == 0 ? wbb[0] : -wbb[t];
+    if (P.col[r] >= 0) {                                    // one identity row per column in the big cone
+        qv[P.col[r]] = P.alpha[r] * u;
+        if (t > 0) qd[P.col[r]] = P.alpha[r] * P.alpha[r];
+    }
+    if (t == 0)
+        for (int e = 0; e < P.Ne; ++e) qv[P.Nt + e] = P.ey[3 * r + e] * u;
+}
+__global__ void k_H_big(DProg P, const double* __restrict__ qv, const double* __restrict__ qd,
+                        const double* __restrict__ Sc, double* __restrict__ H) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (k >= P.N || j >= P.N) return;
+    const double e2 = 1.0 / (Sc[S_ETAB] * Sc[S_ETAB]);
+    const long ob = P.l + 3L * P.nq3;
+    double v = 2 * qv[j] * qv[k];
+    if (j == k && j < P.Nt) v += qd[j];                      // - G_b' J G_b on the x block: + alpha_k^2 e e'
+    if (j >= P.Nt && k >= P.Nt) v -= P.ey[3 * ob + (j - P.Nt)] * P.ey[3 * ob + (k - P.Nt)];
+    H[(long)j * P.np + k] += e2 * v;
+}
+
+// initial point helpers -----------------------------------------------------------------------
+// cone "distance outside" (max over cones of -(interior distance)) and ||v||^2
+__global__ __launch_bounds__(256) void k_cone_resid(DProg P, const double* __restrict__ v, double* __restrict__ part) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double a[2] = {-1e300, 0};
+    if (t < P.l) { a[0] = -v[t]; a[1] = v[t] * v[t]; }
+    else if (t < P.l + P.nq3) {
+        int r = P.l + 3 * (t - P.l);
+        a[0] = sqrt(v[r + 1] * v[r + 1] + v[r + 2] * v[r + 2]) - v[r];
+        a[1] = v[r] * v[r] + v[r + 1] * v[r + 1] + v[r + 2] * v[r + 2];
+    }
+    __shared__ double sh[17];
+    double m = block_max(a[0], sh), s = block_sum(a[1], sh);
+    if (threadIdx.x == 0) { part[2L * blockIdx.x] = m; part[2L * blockIdx.x + 1] = s; }
+}
+__global__ __launch_bounds__(1024) void k_big_cone_resid(DProg P, const double* __restrict__ v, double* __restrict__ part_row) {
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    double n1 = big_dot(v + ob + 1, v + ob + 1, P.big - 1, sh);
+    if (threadIdx.x == 0) { part_row[0] = sqrt(n1) - v[ob]; part_row[1] = n1 + v[ob] * v[ob]; }
+}
+// v += (1 + t) e  when  t >= -1e-8 max(1, ||v||)
+__global__ __launch_bounds__(256) void k_cone_shift(DProg P, double* __restrict__ v, const double* __restrict__ part, int nb) {
+    __shared__ double sh[17];
+    double tmax = fold_partials(part, nb, 2, 0, true, sh);
+    double nrm = sqrt(fold_partials(part, nb, 2, 1, false, sh));
+    if (!(tmax >= -1e-8 * fmax(1.0, nrm))) return;
+    const double add = 1.0 + tmax;
+    const long ncones = (long)P.l + P.nq3 + (P.big ? 1 : 0);
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < ncones; t += (long)gridDim.x * blockDim.x) {
+        long r = t < P.l ? t : (t < P.l + P.nq3 ? P.l + 3 * (t - P.l) : P.l + 3L * P.nq3);
+        v[r] += add;
+    }
+}
+__global__ void k_neg_copy_r(DProg P, const double* __restrict__ a, double* __restrict__ out, double sgn) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < P.R) out[r] = sgn * a[r];
+}
+__global__ void k_init_rhs(DProg P, double* __restrict__ bx2, double* __restrict__ bz2) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.N) { bx2[t] = 0.0; bx2[P.LDV + t] = -P.c[t]; }
+    if (t < P.R) { bz2[t] = P.h[t]; bz2[P.Rp + t] = 0.0; }
+}
+// H for the initial point (W = I): weights d=1 for LP rows, M = I for cones
+__global__ void k_unit_scaling(DProg P, double* __restrict__ dl, double* __restrict__ wl, double* __restrict__ w3,
+                               double* __restrict__ wbb, double* __restrict__ Sc) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.l) { dl[t] = 1.0; wl[t] = 1.0; }
+    if (t < P.nq3) { w3[4 * t] = 1.0; w3[4 * t + 1] = 1.0; w3[4 * t + 2] = 0.0; w3[4 * t + 3] = 0.0; }
+    if (t < P.big) wbb[t] = t == 0 ? 1.0 : 0.0;
+    if (t == 0) { Sc[S_ETAB] = 1.0; Sc[S_WB0] = 1.0; }
+}
+__global__ void k_finish_x(DProg P, const double* __restrict__ x, const double* __restrict__ Sc, double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P.N) out[j] = x[j] / Sc[S_TAU];
+}
+__global__ void k_norms_hc(DProg P, double* __restrict__ Sc) {
+    __shared__ double sh[17];
+    double a = 0, b = 0;
+    for (int r = threadIdx.x; r < P.R; r += blockDim.x) a += P.h[r] * P.h[r];
+    for (int j = threadIdx.x; j < P.N; j += blockDim.x) b += P.c[j] * P.c[j];
+    a = block_sum(a, sh); b = block_sum(b, sh);
+    if (threadIdx.x == 0) {
+        Sc[S_NRMH] = fmax(1.0, sqrt(a));
+        Sc[S_NRMC] = fmax(1.0, sqrt(b));
+        Sc[S_DEG] = double(P.l + P.nq3 + (P.big ? 1 : 0));
+        Sc[S_TAU] = 1.0; Sc[S_KAPPA] = 1.0;
+    }
+}
+
+// ================================================================================================
+// host driver
+// ================================================================================================
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool measuring = false;      // first pass: only add up the sizes
+    void reset() { off = 0; }
+    template <class T>
+    T* get(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (!measuring && off + bytes > cap) throw HipError("device arena exhausted");
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+struct Solver::Impl {
+    int device = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Arena ar;
+    double* hostSc = nullptr;    // pinned
+    int* hostFlag = nullptr;     // pinned
+    std::string err;
+
+    // per-solve device pointers
+    DProg P{};
+    GramPlan gp;
+    int nsplit_at = 0;
+    double *A1, *T, *slab, *H, *M, *Mt, *W1, *Sc;
+    int *tile_ij, *flag;
+    double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
+    double *XX, *UU, *PP, *partial, *TT, *Dw, *BB, *qv;
+    double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz;
+    double *bx2, *bz2, *dx2, *dz2, *rx, *rz, *GTz, *Gx;
+    double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
+    double *partR, *partN, *xout, *hout, *sfwork;
+    int nbR = 0, nbN = 0, nbC = 0;
+
+    void ensure_arena(size_t bytes) {
+        if (bytes <= ar.cap) { ar.reset(); return; }
+        if (ar.base) MBFIR_HIP(hipFree(ar.base));
+        ar.base = nullptr; ar.cap = 0;
+        MBFIR_HIP(hipMalloc(&ar.base, bytes));
+        ar.cap = bytes;
+        ar.reset();
+    }
+    template <class T>
+    T* upload(const std::vector<T>& v) {
+        T* p = ar.get<T>(std::max<size_t>(v.size(), 1));
+        if (!v.empty() && !ar.measuring) MBFIR_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        return p;
+    }
+
+    // ---- operators ----
+    template <int NV>
+    void apply_G(const double* v, double* out) {
+        const int NVV = P.quad ? 2 * NV : NV;
+        const double* xx = v;
+        if (P.quad) {
+            hipLaunchKernelGGL(k_make_xx<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, v, XX);
+            xx = XX;
+        }
+        dim3 g(cdiv(P.Mf, 4));
+        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        else hipLaunchKernelGGL(k_amulti<4>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
+    }
+    void atmulti(int nvv, const double* pp) {
+        dim3 g(P.ld / 128, nsplit_at), b(64, 4);
+        switch (nvv) {
+            case 1: hipLaunchKernelGGL(k_atmulti<1>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            case 2: hipLaunchKernelGGL(k_atmulti<2>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            case 3: hipLaunchKernelGGL(k_atmulti<3>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            case 4: hipLaunchKernelGGL(k_atmulti<4>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            case 6: hipLaunchKernelGGL(k_atmulti<6>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            default: throw HipError("atmulti: unsupported vector count");
+        }
+    }
+    template <int NV>
+    void apply_GT(const double* val, double* out) {
+        const int NVV = P.quad ? 2 * NV : NV;
+        hipLaunchKernelGGL(k_freq_agg<NV>, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, val, PP);
+        atmulti(NVV, PP);
+        hipLaunchKernelGGL(k_gt_combine<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, partial, nsplit_at, val, out);
+        if (P.Ne > 0) hipLaunchKernelGGL(k_gt_y<NV>, dim3(1), dim3(256), 0, st, P, val, out);
+    }
+    template <int NV>
+    void winv2(const double* in, const double* sub, double* out, int mode) {
+        hipLaunchKernelGGL(k_winv2<NV>, dim3(cdiv(P.l + P.nq3, 256)), dim3(256), 0, st, P, dl, w3, in, sub, out, mode);
+        if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, in, sub, out, mode);
+    }
+    template <int NV>
+    void hsolve(const double* rhs, double* out) {
+        trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st);
+        trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
+    }
+    // [0 G'; G -W^2][dx; dz] = [bx; bz]
+    template <int NV>
+    void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, int refine) {
+        winv2<NV>(bz, nullptr, wbz, 0);
+        apply_GT<NV>(wbz, tmpN);
+        hipLaunchKernelGGL(k_add_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, bx, tmpN, 1.0, rhsN);
+        hsolve<NV>(rhsN, dx);
+        apply_G<NV>(dx, tmpR);
+        winv2<NV>(tmpR, wbz, dz, 0);
+        for (int it = 0; it < refine; ++it) {
+            apply_GT<NV>(dz, tmpN);
+            hipLaunchKernelGGL(k_add_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, bx, tmpN, -1.0, rhsN);
+            hsolve<NV>(rhsN, tmpN2);
+            hipLaunchKernelGGL(k_axpy_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, tmpN2, dx);
+            apply_G<NV>(tmpN2, tmpR);
+            winv2<NV>(tmpR, nullptr, dz, 1);
+        }
+    }
+    // H = G' W^-2 G from the current scaling, then Cholesky + inverse
+    float gram_ms = 0, chol_ms = 0;
+    bool timing = true;
+    void build_H() {
+        hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dl, w3, Dw, BB);
+        if (timing) hipEventRecord(ev0, st);
+        gram_launch(gp, A1, Dw, slab, T, tile_ij, st);
+        if (timing) { hipEventRecord(ev1, st); }
+        if (P.Ne > 0) {
+            int nvv = P.quad ? 2 * P.Ne : P.Ne;
+            atmulti(nvv, BB);
+            hipLaunchKernelGGL(k_fold_tt, dim3(cdiv(P.ld, 256), nvv), dim3(256), 0, st, P, partial, nsplit_at, nvv, TT);
+        }
+        hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H);
+        hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
+        if (P.Ne > 0 && P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H);
+        if (P.big) {
+            hipMemsetAsync(qv, 0, sizeof(double) * 2 * P.LDV, st);
+            hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
+            hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+        }
+        float g = 0;
+        if (timing) { hipEventSynchronize(ev1); hipEventElapsedTime(&g, ev0, ev1); gram_ms += g; hipEventRecord(ev0, st); }
+        chol_inv_launch(H, M, Mt, W1, P.np, flag, st);
+        if (timing) { hipEventRecord(ev1, st); hipEventSynchronize(ev1); hipEventElapsedTime(&g, ev0, ev1); chol_ms += g; }
+    }
+};
+
+Solver::Solver(int device) : impl(new Impl()) {
+    impl->device = device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw HipError("no HIP device available");
+    MBFIR_HIP(hipSetDevice(device));
+    MBFIR_HIP(hipStreamCreate(&impl->st));
+    MBFIR_HIP(hipEventCreate(&impl->ev0));
+    MBFIR_HIP(hipEventCreate(&impl->ev1));
+    MBFIR_HIP(hipHostMalloc(&impl->hostSc, sizeof(double) * S_COUNT));
+    MBFIR_HIP(hipHostMalloc(&impl->hostFlag, sizeof(int) * 4));
+}
+Solver::~Solver() {
+    if (!impl) return;
+    hipSetDevice(impl->device);
+    if (impl->ar.base) hipFree(impl->ar.base);
+    if (impl->hostSc) hipHostFree(impl->hostSc);
+    if (impl->hostFlag) hipHostFree(impl->hostFlag);
+    if (impl->ev0) hipEventDestroy(impl->ev0);
+    if (impl->ev1) hipEventDestroy(impl->ev1);
+    if (impl->st) hipStreamDestroy(impl->st);
+    delete impl;
+}
+void* Solver::stream() const { return impl->st; }
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    hipStream_t st = S.st;
+    const double t_begin = now_ms();
+    // ---- host-side index structures --------------------------------------------------------
+    const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;
+    std::vector<int> f_ptr(Mf + 1, 0), f_rows, c_ptr(Nt + 1, 0), c_rows, yrows;
+    for (int r = 0; r < R; ++r) {
+        if (Q.freq[r] >= 0) f_ptr[Q.freq[r] + 1]++;
+        if (Q.col[r] >= 0) c_ptr[Q.col[r] + 1]++;
+        if (Q.ey[3 * r] != 0 || Q.ey[3 * r + 1] != 0 || Q.ey[3 * r + 2] != 0) yrows.push_back(r);
+        if (Q.freq[r] >= 0 && r >= Q.l) {
+            int a = (r - Q.l) % 3;
+            if (r >= Q.l + 3 * Q.nq3 || a == 0) throw HipError("unsupported cone layout (trig row at cone position 0 / in big cone)");
+        }
+    }
+    for (int i = 0; i < Mf; ++i) f_ptr[i + 1] += f_ptr[i];
+    for (int j = 0; j < Nt; ++j) c_ptr[j + 1] += c_ptr[j];
+    f_rows.resize(f_ptr[Mf]); c_rows.resize(c_ptr[Nt]);
+    {
+        std::vector<int> fp(f_ptr.begin(), f_ptr.end() - 1), cp(c_ptr.begin(), c_ptr.end() - 1);
+        for (int r = 0; r < R; ++r) {
+            if (Q.freq[r] >= 0) f_rows[fp[Q.freq[r]]++] = r;
+            if (Q.col[r] >= 0) c_rows[cp[Q.col[r]]++] = r;
+        }
+    }
+    // ---- sizes -----------------------------------------------------------------------------
+    const int nw = Q.quad ? 3 : 1;
+    S.gp = gram_plan(Mf, Nt, nw);
+    DProg& P = S.P;
+    P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
+    P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
+    P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
+    P.nyrows = int(yrows.size());
+    S.nsplit_at = cdiv(P.Mpad, AT_ROWS);
+    const int ncone = P.l + P.nq3;
+    S.nbR = cdiv(R, 256); S.nbN = cdiv(N, 256); S.nbC = cdiv(ncone, 256);
+    if (S.nbR + 1 > NPART * 64) throw HipError("problem too large for the reduction buffers");
+    const size_t ld = P.ld, np = P.np, LDV = P.LDV, Rp = P.Rp, Mpad = P.Mpad;
+    const int lp = Q.which == DES_AP ? specfact_lp(Q.n) : 0;
+    std::vector<int> tiles(2 * S.gp.ntiles);
+    gram_tiles_host(S.gp, tiles.data());
+    Arena& ar = S.ar;
+    char* zero_from = nullptr;
+    size_t zero_bytes = 0;
+    auto layout = [&]() {
+    // ---- upload the program ----------------------------------------------------------------
+    P.w = S.upload(Q.w); P.col_kind = S.upload(Q.col_kind); P.col_tau = S.upload(Q.col_tau);
+    P.col_scale = S.upload(Q.col_scale); P.pcol = S.upload(Q.pcol); P.psign = S.upload(Q.psign);
+    P.c = S.upload(Q.c); P.freq = S.upload(Q.freq); P.col = S.upload(Q.col); P.alpha = S.upload(Q.alpha);
+    P.beta = S.upload(Q.beta); P.ey = S.upload(Q.ey); P.h = S.upload(Q.h);
+    P.f_ptr = S.upload(f_ptr); P.f_rows = S.upload(f_rows); P.c_ptr = S.upload(c_ptr); P.c_rows = S.upload(c_rows);
+    P.yrows = S.upload(yrows);
+    S.tile_ij = S.upload(tiles);
+    // ---- work buffers ----------------------------------------------------------------------
+    zero_from = ar.base + ar.off;
+    S.A1 = ar.get<double>(Mpad * ld);
+    S.T = ar.get<double>(nw * ld * ld);
+    S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np);
+    S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4);
+    S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
+    S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
+    S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV);
+    S.bxc = ar.get<double>(LDV); S.dxc = ar.get<double>(LDV); S.qv = ar.get<double>(2 * LDV);
+    S.XX = ar.get<double>(4 * LDV); S.TT = ar.get<double>(6 * LDV); S.xout = ar.get<double>(LDV);
+    S.s = ar.get<double>(Rp); S.z = ar.get<double>(Rp); S.lam = ar.get<double>(Rp); S.dl = ar.get<double>(Rp);
+    S.wl = ar.get<double>(Rp); S.w3 = ar.get<double>(4 * (size_t)std::max(P.nq3, 1)); S.wbb = ar.get<double>(std::max(P.big, 1));
+    S.tmpR = ar.get<double>(2 * Rp); S.wbz = ar.get<double>(2 * Rp); S.bz2 = ar.get<double>(2 * Rp); S.dz2 = ar.get<double>(2 * Rp);
+    S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
+    S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
+    S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(2 * (size_t)std::max(P.big, 1) + 8);
+    S.UU = ar.get<double>(4 * Mpad); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(3 * Mpad); S.BB = ar.get<double>(6 * Mpad);
+    S.partial = ar.get<double>((size_t)S.nsplit_at * 6 * ld);
+    S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
+    S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
+    S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
+    zero_bytes = size_t(ar.base + ar.off - zero_from);
+    S.slab = ar.get<double>(S.gp.slab_doubles);
+    };
+    ar.measuring = true; ar.reset();
+    { char* keep = ar.base; ar.base = nullptr; layout(); ar.base = keep; }
+    const size_t need = ar.off + 4096;
+    ar.measuring = false;
+    S.ensure_arena(need);
+    layout();
+    MBFIR_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
+    // ---- build A1, norms -------------------------------------------------------------------
+    hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
+    hipLaunchKernelGGL(k_norms_hc, dim3(1), dim3(256), 0, st, P, S.Sc);
+    MBFIR_HIP(hipStreamSynchronize(st));
+    const double t_assembled = now_ms();
+    S.gram_ms = S.chol_ms = 0;
+    S.timing = o.timing;
+
+    const int nbRc = S.nbC + (P.big ? 1 : 0);      // cone-indexed reductions (+1 row for the big cone)
+    auto cone_shift = [&](double* v) {
+        hipLaunchKernelGGL(k_cone_resid, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, v, S.partR);
+        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, dim3(1), dim3(1024), 0, st, P, v, S.partR + 2L * std::max(S.nbC, 1));
+        hipLaunchKernelGGL(k_cone_shift, dim3(64), dim3(256), 0, st, P, v, S.partR, std::max(S.nbC, 1) + (P.big ? 1 : 0));
+    };
+    // ---- initial point (W = I) -------------------------------------------------------------
+    hipLaunchKernelGGL(k_unit_scaling, dim3(cdiv(std::max(std::max(P.l, P.nq3), std::max(P.big, 1)), 256)), dim3(256), 0, st,
+                       P, S.dl, S.wl, S.w3, S.wbb, S.Sc);
+    S.build_H();
+    hipLaunchKernelGGL(k_init_rhs, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.bx2, S.bz2);
+    S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, o.refine);
+    MBFIR_HIP(hipMemcpyAsync(S.x, S.dx2, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2, S.s, -1.0);
+    cone_shift(S.s);
+    hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2 + Rp, S.z, 1.0);
+    cone_shift(S.z);
+    (void)nbRc;
+
+    int status = ST_MAXIT, it = 0;
+    double* hs = S.hostSc;
+    for (it = 0; it <= o.max_iter; ++it) {
+        // residuals
+        S.apply_G<1>(S.x, S.Gx);
+        S.apply_GT<1>(S.z, S.GTz);
+        hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR);
+        hipLaunchKernelGGL(k_resid_cols, dim3(S.nbN), dim3(256), 0, st, P, S.GTz, S.x, S.Sc, S.rx, S.bx2, S.partN);
+        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(256), 0, st, S.Sc, S.partR, S.nbR, S.partN, S.nbN);
+        MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
+        MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        MBFIR_HIP(hipStreamSynchronize(st));
+        info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
+        info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
+        if (o.verbose)
+            fprintf(stderr, "%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e cholflag %d\n",
+                    it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES], hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU],
+                    hs[S_ALPHA], hs[S_SIGMA], S.hostFlag[0]);
+        if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) {
+            status = ST_NUMERICAL; break;
+        }
+        if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) {
+            status = ST_OPTIMAL; break;
+        }
+        if (hs[S_PINF] <= o.feastol) { status = ST_PRIMAL_INFEASIBLE; break; }
+        if (hs[S_DINF] <= o.feastol) { status = ST_DUAL_INFEASIBLE; break; }
+        if (it == o.max_iter) break;
+        // scaling + H
+        hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam);
+        if (P.big) {
+            const long ob = P.l + 3L * P.nq3;
+            hipLaunchKernelGGL(k_big_scaling, dim3(1), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc);
+        }
+        S.build_H();
+        // constant + affine systems in one batch: [x1 z1], [x2 z2]
+        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, o.refine);
+        double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp;
+        auto dots = [&](const double* xx2, const double* zz2, int mode) {
+            hipLaunchKernelGGL(k_dots_n, dim3(S.nbN), dim3(256), 0, st, P, x1, xx2, S.partN);
+            hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
+            int nb = std::max(S.nbC, 1);
+            if (P.big) {
+                hipLaunchKernelGGL(k_big_dots, dim3(1), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
+                nb += 1;
+            }
+            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(256), 0, st, S.Sc, S.partN, S.nbN, S.partR, nb, mode);
+        };
+        dots(x2a, z2a, 0);
+        {
+            int nb = std::max(S.nbC, 1);
+            hipLaunchKernelGGL(k_aff_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, z2a, S.Sc, S.dssa, S.wdza, S.partR);
+            if (P.big) {
+                hipLaunchKernelGGL(k_big_aff_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, z1, z2a, S.Sc, S.dssa, S.wdza,
+                                   S.scratch, S.partR + 2L * nb);
+                nb += 1;
+            }
+            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, 0);
+        }
+        // combined direction
+        hipLaunchKernelGGL(k_comb_rhs, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.dssa, S.wdza, S.rz, S.Sc,
+                           S.lds, S.bzc);
+        if (P.big)
+            hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
+                               S.scratch);
+        hipLaunchKernelGGL(k_comb_bx, dim3(S.nbN), dim3(256), 0, st, P, S.rx, S.Sc, S.bxc);
+        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, o.refine);
+        dots(S.dxc, S.dzc, 1);
+        {
+            int nb = std::max(S.nbC, 1);
+            hipLaunchKernelGGL(k_comb_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.lds, z1, S.dzc, S.Sc, S.ds, S.dz, S.partR);
+            if (P.big) {
+                hipLaunchKernelGGL(k_big_comb_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.lds, z1, S.dzc, S.Sc, S.ds, S.dz,
+                                   S.scratch, S.partR + 2L * nb);
+                nb += 1;
+            }
+            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, 1);
+            hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
+        }
+    }
+    (void)t_begin;
+    info.status = status;
+    info.ms_assemble = t_assembled - t_begin;
+    info.ms_gram = S.gram_ms; info.ms_chol = S.chol_ms;
+    hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xout);
+    xout.assign(N, 0.0);
+    MBFIR_HIP(hipMemcpyAsync(xout.data(), S.xout, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    MBFIR_HIP(hipStreamSynchronize(st));
+    info.ms_solve = now_ms() - t_assembled;
+    info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
+    info.gram_flop = double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
+    return status;
+}
+
+}  // namespace mbfir
+
+// ================================================================================================
+// post-processing and test hooks
+// ================================================================================================
+namespace mbfir {
+
+void Solver::specfact_last(int n, double* h_re, double* h_im) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    specfact_launch(S.xout, n, S.sfwork, S.hout, S.st);
+    std::vector<double> h(2 * (size_t)n);
+    MBFIR_HIP(hipMemcpyAsync(h.data(), S.hout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    for (int i = 0; i < n; ++i) { h_re[i] = h[2 * i]; h_im[i] = h[2 * i + 1]; }
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { MBFIR_HIP(hipMalloc(&p, std::max<size_t>(bytes, 256))); }
+    ~DevBuf() { if (p) hipFree(p); }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+
+void Solver::test_gram(int m, int nt, int nw, const double* A, const double* d, double* out) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    GramPlan gp = gram_plan(m, nt, nw);
+    const size_t ld = gp.ld, Mpad = gp.Mpad;
+    DevBuf dA(Mpad * ld * 8), dd(nw * Mpad * 8), dslab(gp.slab_doubles * 8), dT(nw * ld * ld * 8), dt(2 * gp.ntiles * 4);
+    MBFIR_HIP(hipMemsetAsync(dA.p, 0, Mpad * ld * 8, S.st));
+    MBFIR_HIP(hipMemsetAsync(dd.p, 0, nw * Mpad * 8, S.st));
+    MBFIR_HIP(hipMemcpy2DAsync(dA.p, ld * 8, A, (size_t)nt * 8, (size_t)nt * 8, m, hipMemcpyHostToDevice, S.st));
+    for (int w = 0; w < nw; ++w)
+        MBFIR_HIP(hipMemcpyAsync(dd.as<double>() + w * Mpad, d + (size_t)w * m, (size_t)m * 8, hipMemcpyHostToDevice, S.st));
+    std::vector<int> tiles(2 * gp.ntiles);
+    gram_tiles_host(gp, tiles.data());
+    MBFIR_HIP(hipMemcpyAsync(dt.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, S.st));
+    gram_launch(gp, dA.as<double>(), dd.as<double>(), dslab.as<double>(), dT.as<double>(), dt.as<int>(), S.st);
+    for (int w = 0; w < nw; ++w)
+        MBFIR_HIP(hipMemcpy2DAsync(out + (size_t)w * nt * nt, (size_t)nt * 8, dT.as<double>() + w * ld * ld, ld * 8,
+                                   (size_t)nt * 8, nt, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+}
+
+void Solver::test_chol(int n, const double* Hh, double* out_l, double* out_m) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const size_t np = round_up(n, 64);
+    std::vector<double> Hp(np * np, 0.0);
+    for (size_t i = 0; i < np; ++i) Hp[i * np + i] = 1.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Hp[i * np + j] = Hh[(size_t)i * n + j];
+    DevBuf dH(np * np * 8), dM(np * np * 8), dMt(np * np * 8), dW(np * np * 8), df(16);
+    MBFIR_HIP(hipMemcpyAsync(dH.p, Hp.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
+    chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st);
+    MBFIR_HIP(hipMemcpy2DAsync(out_l, (size_t)n * 8, dH.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpy2DAsync(out_m, (size_t)n * 8, dM.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+}
+
+void Solver::test_specfact(int n, const double* x, double* h_re, double* h_im) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const int lp = specfact_lp(n);
+    DevBuf dx((2 * (size_t)n) * 8), dw(6 * (size_t)lp * 8), dh(2 * (size_t)n * 8);
+    MBFIR_HIP(hipMemcpyAsync(dx.p, x, (2 * (size_t)n - 1) * 8, hipMemcpyHostToDevice, S.st));
+    specfact_launch(dx.as<double>(), n, dw.as<double>(), dh.as<double>(), S.st);
+    std::vector<double> h(2 * (size_t)n);
+    MBFIR_HIP(hipMemcpyAsync(h.data(), dh.p, 2 * (size_t)n * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+    for (int i = 0; i < n; ++i) { h_re[i] = h[2 * i]; h_im[i] = h[2 * i + 1]; }
+}
+
+// fp64 peak microbenchmarks (roofline denominators; the local hardware guide lists no fp64
+// matrix peak).  One wave per SIMD, 8 independent accumulators, operands in registers.
+__global__ __launch_bounds__(256) void k_peak_mfma(double* out, int iters) {
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    v4d c[8];
+    for (int i = 0; i < 8; ++i) c[i] = (v4d){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_peak_valu(double* out, int iters) {
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+    double c[16];
+    for (int i = 0; i < 16; ++i) c[i] = i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = fma(c[i], a, b);
+    }
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += c[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+void Solver::test_mfma_peak(double* tf_mfma, double* tf_valu) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    hipDeviceProp_t prop;
+    MBFIR_HIP(hipGetDeviceProperties(&prop, S.device));
+    const int blocks = prop.multiProcessorCount * 2, iters = 20000;
+    DevBuf dout((size_t)blocks * 256 * 8);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(S.ev0, S.st);
+        hipLaunchKernelGGL(k_peak_mfma, dim3(blocks), dim3(256), 0, S.st, dout.as<double>(), iters);
+        hipEventRecord(S.ev1, S.st);
+        MBFIR_HIP(hipEventSynchronize(S.ev1));
+        hipEventElapsedTime(&ms, S.ev0, S.ev1);
+    }
+    *tf_mfma = double(blocks) * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(S.ev0, S.st);
+        hipLaunchKernelGGL(k_peak_valu, dim3(blocks), dim3(256), 0, S.st, dout.as<double>(), iters);
+        hipEventRecord(S.ev1, S.st);
+        MBFIR_HIP(hipEventSynchronize(S.ev1));
+        hipEventElapsedTime(&ms, S.ev0, S.ev1);
+    }
+    *tf_valu = double(blocks) * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
+    MBFIR_HIP(hipGetLastError());
+}
+
+}  // namespace mbfir
