@@ -39,7 +39,8 @@ SolveOpts to_opts(const mbfir_opts* o) {
 
 int status_to_rc(int st) {
     switch (st) {
-        case ST_OPTIMAL: return MBFIR_SOLVED;
+        case ST_OPTIMAL:
+        case ST_OPTIMAL_INACCURATE: return MBFIR_SOLVED;      // reference accepts 'Inaccurate/Solved' (fir_ap_cvx.m:176)
         case ST_PRIMAL_INFEASIBLE:
         case ST_DUAL_INFEASIBLE: return MBFIR_INFEASIBLE;
         default: return MBFIR_NUMERICAL;

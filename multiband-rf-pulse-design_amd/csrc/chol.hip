@@ -54,27 +54,30 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) S[e >> 6][e & 63] = src[(long)(e >> 6) * ld + (e & 63)];
 }
 
-// Panel step k: every block factorises the 64x64 diagonal block in LDS (redundantly -- 87 kflop)
-// and inverts it; block 0 publishes L_kk and inv(L_kk); block b>0 forms L_ik = A_ik inv(L_kk)'.
+// Panel step k: every block factorises the 64x64 diagonal block in LDS (redundantly -- 87 kflop);
+// block 0 publishes L_kk and its inverse (a diagonal block of M); block b>0 forms
+// L_ik = A_ik L_kk^-T by forward substitution (multiplying by the explicit inverse is not
+// backward stable and breaks the factorisation on the near-singular late IPM iterates).
+// Pivot rule: a pivot that is not above pivtol * H_jj is rounding noise; it is replaced by 1e128,
+// which removes that column from the factorisation (flag counts the replacements).
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ H, double* __restrict__ M, int np,
-                                                    int k, int* __restrict__ flag) {
+                                                    int k, const double* __restrict__ d0, double pivtol,
+                                                    int* __restrict__ flag) {
     __shared__ double S[CB][CLD];
     __shared__ double X[CB][CLD];
-    __shared__ double Bt[CB][CLD];
     const int tid = threadIdx.x;
     const long kk = (long)k * CB;
     for (int e = tid; e < CB * CB; e += 256) {
         int i = e >> 6, j = e & 63;
         S[i][j] = j <= i ? H[(kk + i) * np + kk + j] : 0.0;
-        X[i][j] = 0.0;
     }
     // unblocked right-looking Cholesky of S
     for (int j = 0; j < CB; ++j) {
         __syncthreads();
         double p = S[j][j];
-        if (!(p > 0.0)) {
-            if (tid == 0 && blockIdx.x == 0) atomicExch(flag, k * CB + j + 1);
-            p = fabs(p) + 1e-300;
+        if (!(p > pivtol * d0[kk + j])) {
+            if (tid == 0 && blockIdx.x == 0) atomicAdd(flag, 1);
+            p = 1e128;
         }
         const double r = sqrt(p), rinv = 1.0 / r;
         __syncthreads();
@@ -88,17 +91,19 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ H, doub
         }
     }
     __syncthreads();
-    // X = S^-1 (lower): thread c solves S x = e_c by forward substitution
-    if (tid < CB) {
-        const int c = tid;
-        for (int i = c; i < CB; ++i) {
-            double sum = (i == c) ? 1.0 : 0.0;
-            for (int j = c; j < i; ++j) sum -= S[i][j] * X[j][c];
-            X[i][c] = sum / S[i][i];
-        }
-    }
-    __syncthreads();
     if (blockIdx.x == 0) {
+        // X = S^-1 (lower): thread c solves S x = e_c by forward substitution
+        for (int e = tid; e < CB * CB; e += 256) X[e >> 6][e & 63] = 0.0;
+        __syncthreads();
+        if (tid < CB) {
+            const int c = tid;
+            for (int i = c; i < CB; ++i) {
+                double sum = (i == c) ? 1.0 : 0.0;
+                for (int j = c; j < i; ++j) sum -= S[i][j] * X[j][c];
+                X[i][c] = sum / S[i][i];
+            }
+        }
+        __syncthreads();
         for (int e = tid; e < CB * CB; e += 256) {
             int i = e >> 6, j = e & 63;
             H[(kk + i) * np + kk + j] = S[i][j];
@@ -106,13 +111,21 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ H, doub
         }
         return;
     }
+    // rows of A_ik: 4 threads per row (same wave), x_j = (a_j - sum_{t<j} x_t S[j][t]) / S[j][j]
     const long ii = (long)(k + blockIdx.x) * CB;
-    load_block(Bt, H + ii * np + kk, np);
+    load_block(X, H + ii * np + kk, np);
     __syncthreads();
-    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    mma64<true>(Bt, X, 0, CB, acc);            // L_ik[r][c] = sum_j A_ik[r][j] * X[c][j]
+    const int r = tid >> 2, q = tid & 3;
+    for (int j = 0; j < CB; ++j) {
+        double part = 0;
+        for (int t = q; t < j; t += 4) part += X[r][t] * S[j][t];
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (q == 0) X[r][j] = (X[r][j] - part) / S[j][j];
+        __syncthreads();                      // the row's 4 lanes (and the compiler) see the new x_j
+    }
     double* dst = H + ii * np + kk;
-    acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = v; });
+    for (int e = tid; e < CB * CB; e += 256) dst[(long)(e >> 6) * np + (e & 63)] = X[e >> 6][e & 63];
 }
 
 // Trailing update after panel k:  A_ij -= L_ik L_jk'   for k < j <= i.
@@ -192,12 +205,20 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
     for (int r = threadIdx.y; r < 32; r += blockDim.y) Mt[(long)(bx + r) * np + by + threadIdx.x] = tile[threadIdx.x][r];
 }
 
+__global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < np) d0[j] = H[(long)j * np + j];
+}
+
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st) {
     const int nblk = np / CB;
+    const double pivtol = 1e-13;                 // oracle/conic_ipm.py PIVTOL
+    double* d0 = W1;                             // W1 is first used after the factorisation
     hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
     hipMemsetAsync(flag, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, d0);
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, st, H, M, np, k, flag);
+        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, st, H, M, np, k, d0, pivtol, flag);
         int nrem = nblk - k - 1;
         if (nrem > 0)
             hipLaunchKernelGGL(k_chol_trail, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, st, H, np, k);

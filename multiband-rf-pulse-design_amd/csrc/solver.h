@@ -5,7 +5,8 @@
 
 namespace mbfir {
 
-enum { ST_OPTIMAL = 0, ST_PRIMAL_INFEASIBLE = 1, ST_DUAL_INFEASIBLE = 2, ST_MAXIT = 3, ST_NUMERICAL = 4 };
+enum { ST_OPTIMAL = 0, ST_PRIMAL_INFEASIBLE = 1, ST_DUAL_INFEASIBLE = 2, ST_MAXIT = 3, ST_NUMERICAL = 4,
+       ST_OPTIMAL_INACCURATE = 5 };
 
 struct SolveOpts {
     int max_iter = 200;

@@ -32,10 +32,13 @@ namespace mbfir {
 enum {
     S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
     S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
-    S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD, S_COUNT = 64
+    S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
+    S_RNA = 40 /* 8 sweep norms, batch solve */, S_RNB = 48 /* 8 sweep norms, combined solve */, S_COUNT = 64
 };
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
+constexpr int MAX_SWEEPS = 8;
+constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1e-5;
 
 // ------------------------------------------------------------------------------------------------
 // device-side problem description
@@ -476,6 +479,38 @@ __global__ void k_add_n(DProg P, const double* __restrict__ a, const double* __r
         out[o] = a[o] + sb * b[o];
     }
 }
+// r[v] = bx[v] - t[v] with per-vector sum of squares (refinement residual)
+template <int NV>
+__global__ __launch_bounds__(256) void k_resid_n(DProg P, const double* __restrict__ bx, const double* __restrict__ t,
+                                                 double* __restrict__ out, double* __restrict__ part) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = 0;
+    if (j < P.N) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            long o = (long)q * P.LDV + j;
+            double r = bx[o] - t[o];
+            out[o] = r;
+            v[q] = r * r;
+        }
+    }
+    block_partials<NV>(v, part, false);
+}
+__global__ __launch_bounds__(256) void k_scal_rnorm(double* __restrict__ Sc, const double* __restrict__ part, int nb, int nv, int slot) {
+    __shared__ double sh[17];
+    double m = 0;
+    for (int v = 0; v < nv; ++v) m = fmax(m, sqrt(fold_partials(part, nb, nv, v, false, sh)));
+    if (threadIdx.x == 0) Sc[slot] = m;
+}
+template <int NV>
+__global__ void k_axpy_r(DProg P, const double* __restrict__ a, double* __restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.R) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[(long)v * P.Rp + r] += a[(long)v * P.Rp + r];
+}
 template <int NV>
 __global__ void k_axpy_n(DProg P, const double* __restrict__ a, double* __restrict__ out) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,47 +586,73 @@ __global__ __launch_bounds__(256) void k_scal_dtau(double* __restrict__ Sc, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// affine direction in the scaled space:  dz = z2 + dtau z1 ; wdz = W dz ; dss = -lam - wdz
-// (lam \ (-lam o lam) = -lam).  Stores dssa, wdza; emits the two step-length maxima.
-__global__ __launch_bounds__(256) void k_aff_post(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+// Direction in the scaled space (affine: mode 0, combined: mode 1).
+//   dz = z2 + dtau z1
+//   ds = -(1-sigma) rz - G x2 - dtau (G x1 - h)      (primal equation, so the primal residual
+//                                                      contracts by exactly 1 - alpha (1-sigma))
+//   wdz = W dz ; dss = W^-1 ds
+// mode 0 stores dssa, wdza (Mehrotra corrector); mode 1 stores ds, dz.  Emits the step maxima.
+__global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                                                   const double* __restrict__ lam, const double* __restrict__ z1,
-                                                  const double* __restrict__ z2, const double* __restrict__ Sc,
-                                                  double* __restrict__ dssa, double* __restrict__ wdza,
-                                                  double* __restrict__ part) {
+                                                  const double* __restrict__ z2, const double* __restrict__ g1,
+                                                  const double* __restrict__ g2, const double* __restrict__ rz,
+                                                  const double* __restrict__ Sc, double* __restrict__ outA,
+                                                  double* __restrict__ outB, double* __restrict__ part, int mode) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double dtau = Sc[S_DTAU_A];
+    const double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+    const double oms = mode == 0 ? 1.0 : 1.0 - Sc[S_SIGMA];
     double v[2] = {-1e300, -1e300};
     if (t < P.l) {
-        double dz = z2[t] + dtau * z1[t], wdz = wl[t] * dz, l = lam[t];
-        double dss = -l - wdz;
-        dssa[t] = dss; wdza[t] = wdz;
+        double dz = z2[t] + dtau * z1[t], l = lam[t];
+        double ds = -oms * rz[t] - g2[t] - dtau * (g1[t] - P.h[t]);
+        double wdz = wl[t] * dz, dss = ds / wl[t];
+        if (mode == 0) { outA[t] = dss; outB[t] = wdz; } else { outA[t] = ds; outB[t] = dz; }
         v[0] = -dss / l; v[1] = -wdz / l;
     } else if (t < P.l + P.nq3) {
         int c = t - P.l, r = P.l + 3 * c;
         Soc3 W = load_w3(w3, c);
-        double dz[3], wdz[3], dss[3], ll[3];
-        for (int a = 0; a < 3; ++a) { dz[a] = z2[r + a] + dtau * z1[r + a]; ll[a] = lam[r + a]; }
+        double dz[3], ds[3], wdz[3], dss[3], ll[3];
+        for (int a = 0; a < 3; ++a) {
+            dz[a] = z2[r + a] + dtau * z1[r + a];
+            ds[a] = -oms * rz[r + a] - g2[r + a] - dtau * (g1[r + a] - P.h[r + a]);
+            ll[a] = lam[r + a];
+        }
         soc3_apply(W, dz, wdz, false);
-        for (int a = 0; a < 3; ++a) { dss[a] = -ll[a] - wdz[a]; dssa[r + a] = dss[a]; wdza[r + a] = wdz[a]; }
+        soc3_apply(W, ds, dss, true);
+        for (int a = 0; a < 3; ++a) {
+            if (mode == 0) { outA[r + a] = dss[a]; outB[r + a] = wdz[a]; } else { outA[r + a] = ds[a]; outB[r + a] = dz[a]; }
+        }
         v[0] = soc3_step(ll, dss); v[1] = soc3_step(ll, wdz);
     }
     block_partials<2>(v, part, true);
 }
-__global__ __launch_bounds__(1024) void k_big_aff_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
+__global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
                                                        const double* __restrict__ z1, const double* __restrict__ z2,
-                                                       const double* __restrict__ Sc, double* __restrict__ dssa,
-                                                       double* __restrict__ wdza, double* __restrict__ scratch,
-                                                       double* __restrict__ part_row) {
+                                                       const double* __restrict__ g1, const double* __restrict__ g2,
+                                                       const double* __restrict__ rz, const double* __restrict__ Sc,
+                                                       double* __restrict__ outA, double* __restrict__ outB,
+                                                       double* __restrict__ scratch, double* __restrict__ part_row, int mode) {
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
-    const double dtau = Sc[S_DTAU_A];
-    for (int i = threadIdx.x; i < P.big; i += blockDim.x) scratch[i] = z2[ob + i] + dtau * z1[ob + i];
+    const double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+    const double oms = mode == 0 ? 1.0 : 1.0 - Sc[S_SIGMA];
+    double* dzv = scratch;                 // big
+    double* dsv = scratch + P.big;         // big
+    double* wdz = scratch + 2 * P.big;     // big
+    double* dss = scratch + 3 * P.big;     // big
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) {
+        dzv[i] = z2[ob + i] + dtau * z1[ob + i];
+        dsv[i] = -oms * rz[ob + i] - g2[ob + i] - dtau * (g1[ob + i] - P.h[ob + i]);
+    }
     __syncthreads();
-    big_apply(P.big, wbb, Sc[S_ETAB], scratch, wdza + ob, false, sh);
-    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dssa[ob + i] = -lam[ob + i] - wdza[ob + i];
+    big_apply(P.big, wbb, Sc[S_ETAB], dzv, wdz, false, sh);
+    big_apply(P.big, wbb, Sc[S_ETAB], dsv, dss, true, sh);
+    for (int i = threadIdx.x; i < P.big; i += blockDim.x) {
+        if (mode == 0) { outA[ob + i] = dss[i]; outB[ob + i] = wdz[i]; } else { outA[ob + i] = dsv[i]; outB[ob + i] = dzv[i]; }
+    }
     __syncthreads();
-    double a = big_step(P.big, lam + ob, dssa + ob, sh);
-    double b = big_step(P.big, lam + ob, wdza + ob, sh);
+    double a = big_step(P.big, lam + ob, dss, sh);
+    double b = big_step(P.big, lam + ob, wdz, sh);
     if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; }
 }
 // step length + sigma (mode 0, affine) or final alpha and tau/kappa update (mode 1)
@@ -679,54 +740,6 @@ __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __
 __global__ void k_comb_bx(DProg P, const double* __restrict__ rx, const double* __restrict__ Sc, double* __restrict__ bx) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < P.N) bx[j] = -(1 - Sc[S_SIGMA]) * rx[j];
-}
-
-// combined direction: dz = z2 + dtau z1 ; wdz = W dz ; dss = lds - wdz ; ds = W dss
-__global__ __launch_bounds__(256) void k_comb_post(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
-                                                   const double* __restrict__ lam, const double* __restrict__ lds,
-                                                   const double* __restrict__ z1, const double* __restrict__ z2,
-                                                   const double* __restrict__ Sc, double* __restrict__ ds,
-                                                   double* __restrict__ dz, double* __restrict__ part) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double dtau = Sc[S_DTAU];
-    double v[2] = {-1e300, -1e300};
-    if (t < P.l) {
-        double d = z2[t] + dtau * z1[t], wdz = wl[t] * d, l = lam[t];
-        double dss = lds[t] - wdz;
-        dz[t] = d; ds[t] = wl[t] * dss;
-        v[0] = -dss / l; v[1] = -wdz / l;
-    } else if (t < P.l + P.nq3) {
-        int c = t - P.l, r = P.l + 3 * c;
-        Soc3 W = load_w3(w3, c);
-        double d3[3], wdz[3], dss[3], ll[3], dsv[3];
-        for (int a = 0; a < 3; ++a) { d3[a] = z2[r + a] + dtau * z1[r + a]; ll[a] = lam[r + a]; }
-        soc3_apply(W, d3, wdz, false);
-        for (int a = 0; a < 3; ++a) dss[a] = lds[r + a] - wdz[a];
-        soc3_apply(W, dss, dsv, false);
-        for (int a = 0; a < 3; ++a) { dz[r + a] = d3[a]; ds[r + a] = dsv[a]; }
-        v[0] = soc3_step(ll, dss); v[1] = soc3_step(ll, wdz);
-    }
-    block_partials<2>(v, part, true);
-}
-__global__ __launch_bounds__(1024) void k_big_comb_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
-                                                        const double* __restrict__ lds, const double* __restrict__ z1,
-                                                        const double* __restrict__ z2, const double* __restrict__ Sc,
-                                                        double* __restrict__ ds, double* __restrict__ dz,
-                                                        double* __restrict__ scratch, double* __restrict__ part_row) {
-    __shared__ double sh[17];
-    const long ob = P.l + 3L * P.nq3;
-    const double dtau = Sc[S_DTAU];
-    double* wdz = scratch;
-    double* dss = scratch + P.big;
-    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dz[ob + i] = z2[ob + i] + dtau * z1[ob + i];
-    __syncthreads();
-    big_apply(P.big, wbb, Sc[S_ETAB], dz + ob, wdz, false, sh);
-    for (int i = threadIdx.x; i < P.big; i += blockDim.x) dss[i] = lds[ob + i] - wdz[i];
-    __syncthreads();
-    big_apply(P.big, wbb, Sc[S_ETAB], dss, ds + ob, false, sh);
-    double a = big_step(P.big, lam + ob, dss, sh);
-    double b = big_step(P.big, lam + ob, wdz, sh);
-    if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; }
 }
 
 // x += alpha (x2 + dtau x1) ; s += alpha ds ; z += alpha dz
@@ -1009,7 +1022,7 @@ struct Solver::Impl {
     double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
     double *XX, *UU, *PP, *partial, *TT, *Dw, *BB, *qv;
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz;
-    double *bx2, *bz2, *dx2, *dz2, *rx, *rz, *GTz, *Gx;
+    double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
     double *partR, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
@@ -1073,21 +1086,24 @@ struct Solver::Impl {
         trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st);
         trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
     }
-    // [0 G'; G -W^2][dx; dz] = [bx; bz]
+    // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  `nsweep` refinement sweeps on the dual
+    // equation; the residual norm measured before sweep k goes to Sc[slot + k].
     template <int NV>
-    void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, int refine) {
+    void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot) {
         winv2<NV>(bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
         hipLaunchKernelGGL(k_add_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, bx, tmpN, 1.0, rhsN);
         hsolve<NV>(rhsN, dx);
-        apply_G<NV>(dx, tmpR);
-        winv2<NV>(tmpR, wbz, dz, 0);
-        for (int it = 0; it < refine; ++it) {
+        apply_G<NV>(dx, gdx);
+        winv2<NV>(gdx, wbz, dz, 0);
+        for (int it = 0; it < nsweep; ++it) {
             apply_GT<NV>(dz, tmpN);
-            hipLaunchKernelGGL(k_add_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, bx, tmpN, -1.0, rhsN);
+            hipLaunchKernelGGL(k_resid_n<NV>, dim3(nbN), dim3(256), 0, st, P, bx, tmpN, rhsN, partN);
+            if (it < MAX_SWEEPS) hipLaunchKernelGGL(k_scal_rnorm, dim3(1), dim3(256), 0, st, Sc, partN, nbN, NV, slot + it);
             hsolve<NV>(rhsN, tmpN2);
             hipLaunchKernelGGL(k_axpy_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, tmpN2, dx);
             apply_G<NV>(tmpN2, tmpR);
+            hipLaunchKernelGGL(k_axpy_r<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, tmpR, gdx);
             winv2<NV>(tmpR, nullptr, dz, 1);
         }
     }
@@ -1217,9 +1233,10 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     S.s = ar.get<double>(Rp); S.z = ar.get<double>(Rp); S.lam = ar.get<double>(Rp); S.dl = ar.get<double>(Rp);
     S.wl = ar.get<double>(Rp); S.w3 = ar.get<double>(4 * (size_t)std::max(P.nq3, 1)); S.wbb = ar.get<double>(std::max(P.big, 1));
     S.tmpR = ar.get<double>(2 * Rp); S.wbz = ar.get<double>(2 * Rp); S.bz2 = ar.get<double>(2 * Rp); S.dz2 = ar.get<double>(2 * Rp);
+    S.gdx2 = ar.get<double>(2 * Rp); S.gdxc = ar.get<double>(Rp); S.xbest = ar.get<double>(LDV);
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
-    S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(2 * (size_t)std::max(P.big, 1) + 8);
+    S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
     S.UU = ar.get<double>(4 * Mpad); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(3 * Mpad); S.BB = ar.get<double>(6 * Mpad);
     S.partial = ar.get<double>((size_t)S.nsplit_at * 6 * ld);
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
@@ -1254,16 +1271,19 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
                        P, S.dl, S.wl, S.w3, S.wbb, S.Sc);
     S.build_H();
     hipLaunchKernelGGL(k_init_rhs, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.bx2, S.bz2);
-    S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, o.refine);
+    int nsweep = o.refine;
+    S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA);
     MBFIR_HIP(hipMemcpyAsync(S.x, S.dx2, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2, S.s, -1.0);
     cone_shift(S.s);
     hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2 + Rp, S.z, 1.0);
     cone_shift(S.z);
-    (void)nbRc;
 
     int status = ST_MAXIT, it = 0;
     double* hs = S.hostSc;
+    double best_merit = 1e300;
+    SolveInfo best_info;
+    bool have_best = false;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         S.apply_G<1>(S.x, S.Gx);
@@ -1274,20 +1294,44 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
+        if (it > 0) {
+            // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
+            // measured before each sweep of the two KKT solves of the previous iteration
+            const double tol = REFTOL * hs[S_NRMC];
+            int need = 0;
+            bool unconverged = false;
+            for (int slot : {int(S_RNA), int(S_RNB)}) {
+                int k = -1;
+                for (int q = 0; q < std::min(nsweep, MAX_SWEEPS); ++q)
+                    if (hs[slot + q] <= tol) { k = q; break; }
+                if (k < 0) unconverged = true;
+                else need = std::max(need, k);
+            }
+            nsweep = unconverged ? std::min(MAX_SWEEPS, nsweep + 1) : std::max(1, need);
+        }
         info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
         info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
         if (o.verbose)
-            fprintf(stderr, "%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e cholflag %d\n",
+            fprintf(stderr, "%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d\n",
                     it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES], hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU],
-                    hs[S_ALPHA], hs[S_SIGMA], S.hostFlag[0]);
+                    hs[S_ALPHA], hs[S_SIGMA], nsweep, S.hostFlag[0]);
         if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) {
             status = ST_NUMERICAL; break;
         }
         if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) {
             status = ST_OPTIMAL; break;
         }
-        if (hs[S_PINF] <= o.feastol) { status = ST_PRIMAL_INFEASIBLE; break; }
-        if (hs[S_DINF] <= o.feastol) { status = ST_DUAL_INFEASIBLE; break; }
+        const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
+        if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { status = ST_PRIMAL_INFEASIBLE; break; }
+        if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { status = ST_DUAL_INFEASIBLE; break; }
+        {
+            double merit = std::max(std::max(hs[S_PRES], hs[S_DRES]),
+                                    std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol));
+            if (merit < best_merit) {
+                best_merit = merit; best_info = info; have_best = true;
+                hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
+            }
+        }
         if (it == o.max_iter) break;
         // scaling + H
         hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam);
@@ -1297,8 +1341,8 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         }
         S.build_H();
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
-        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, o.refine);
-        double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp;
+        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA);
+        double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
         auto dots = [&](const double* xx2, const double* zz2, int mode) {
             hipLaunchKernelGGL(k_dots_n, dim3(S.nbN), dim3(256), 0, st, P, x1, xx2, S.partN);
             hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
@@ -1309,17 +1353,19 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
             }
             hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(256), 0, st, S.Sc, S.partN, S.nbN, S.partR, nb, mode);
         };
-        dots(x2a, z2a, 0);
-        {
+        auto dir_post = [&](const double* zz2, const double* gg2, double* outA, double* outB, int mode) {
             int nb = std::max(S.nbC, 1);
-            hipLaunchKernelGGL(k_aff_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, z2a, S.Sc, S.dssa, S.wdza, S.partR);
+            hipLaunchKernelGGL(k_dir_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+                               S.partR, mode);
             if (P.big) {
-                hipLaunchKernelGGL(k_big_aff_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, z1, z2a, S.Sc, S.dssa, S.wdza,
-                                   S.scratch, S.partR + 2L * nb);
+                hipLaunchKernelGGL(k_big_dir_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+                                   S.scratch, S.partR + 2L * nb, mode);
                 nb += 1;
             }
-            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, 0);
-        }
+            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, mode);
+        };
+        dots(x2a, z2a, 0);
+        dir_post(z2a, g2a, S.dssa, S.wdza, 0);
         // combined direction
         hipLaunchKernelGGL(k_comb_rhs, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.dssa, S.wdza, S.rz, S.Sc,
                            S.lds, S.bzc);
@@ -1327,25 +1373,26 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
             hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
         hipLaunchKernelGGL(k_comb_bx, dim3(S.nbN), dim3(256), 0, st, P, S.rx, S.Sc, S.bxc);
-        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, o.refine);
+        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB);
         dots(S.dxc, S.dzc, 1);
-        {
-            int nb = std::max(S.nbC, 1);
-            hipLaunchKernelGGL(k_comb_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.lds, z1, S.dzc, S.Sc, S.ds, S.dz, S.partR);
-            if (P.big) {
-                hipLaunchKernelGGL(k_big_comb_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.lds, z1, S.dzc, S.Sc, S.ds, S.dz,
-                                   S.scratch, S.partR + 2L * nb);
-                nb += 1;
-            }
-            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, 1);
-            hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
-        }
+        dir_post(S.dzc, S.gdxc, S.ds, S.dz, 1);
+        hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
     }
+    const double* xsrc = S.xout;
+    hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xout);
+    if ((status == ST_MAXIT || status == ST_NUMERICAL) && have_best && best_info.pres <= INACC_FEAS &&
+        best_info.dres <= INACC_FEAS && (best_info.relgap <= INACC_GAP || best_info.gap <= o.abstol)) {
+        // the reference accepts CVX's 'Inaccurate/Solved' (fir_ap_cvx.m:176): reduced tolerances
+        int keep_it = info.iters;
+        info = best_info; info.iters = keep_it;
+        status = ST_OPTIMAL_INACCURATE;
+        MBFIR_HIP(hipMemcpyAsync(S.xout, S.xbest, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
+    }
+    (void)xsrc;
     (void)t_begin;
     info.status = status;
     info.ms_assemble = t_assembled - t_begin;
     info.ms_gram = S.gram_ms; info.ms_chol = S.chol_ms;
-    hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xout);
     xout.assign(N, 0.0);
     MBFIR_HIP(hipMemcpyAsync(xout.data(), S.xout, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     MBFIR_HIP(hipStreamSynchronize(st));

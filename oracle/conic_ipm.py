@@ -24,7 +24,6 @@ same step rule, same stopping rule), so the two agree to rounding and the
 parity tests can compare taps at 1e-6 relative l-inf.
 """
 import numpy as np
-import scipy.linalg as sla
 
 STEP = 0.99
 STATUS_OPTIMAL = 0
@@ -228,8 +227,66 @@ def _max_step(c, lam, d):
     return t
 
 
-def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
-          reltol=1e-9, static_reg=0.0, refine=1, verbose=False, history=None):
+MAX_SWEEPS = 8
+REFTOL = 1e-11
+INACC_FEAS = 1e-6
+INACC_GAP = 1e-5
+STATUS_OPTIMAL_INACCURATE = 5
+
+
+PIVTOL = 1e-13
+PIVBIG = 1e128
+CHOL_NB = 64
+
+
+def chol_piv(H):
+    """Blocked right-looking Cholesky (64-wide panels, the device kernel's schedule) with
+    the interior-point pivot rule: a pivot that is not above PIVTOL * H_jj (i.e. pure
+    rounding noise) is replaced by PIVBIG, which removes that column from the
+    factorisation instead of dividing by noise.  Returns (L, number of replaced pivots)."""
+    N = H.shape[0]
+    L = np.tril(H).copy()
+    d0 = np.diag(H).copy()
+    nfix = 0
+    for k0 in range(0, N, CHOL_NB):
+        k1 = min(N, k0 + CHOL_NB)
+        D = L[k0:k1, k0:k1]
+        for j in range(k1 - k0):
+            p = D[j, j]
+            if not (p > PIVTOL * d0[k0 + j]):
+                p = PIVBIG
+                nfix += 1
+            r = np.sqrt(p)
+            D[j, j] = r
+            D[j + 1:, j] /= r
+            D[j + 1:, j + 1:] -= np.tril(np.outer(D[j + 1:, j], D[j + 1:, j]))
+        if k1 < N:
+            # panel by forward substitution X D' = A (multiplying by inv(D) instead is not
+            # backward stable and breaks the factorisation on the near-singular late iterates);
+            # numpy only: mixing numpy's and scipy's OpenBLAS thread pools costs ~30 ms per switch
+            X = L[k1:, k0:k1]
+            for j in range(k1 - k0):
+                X[:, j] = (X[:, j] - X[:, :j] @ D[j, :j]) / D[j, j]
+            L[k1:, k1:] -= np.tril(L[k1:, k0:k1] @ L[k1:, k0:k1].T)
+    return L, nfix
+
+
+def next_sweeps(norm_lists, nsweep, tol):
+    """Refinement-sweep controller shared with the device solver.  norm_lists: for
+    every KKT solve of the iteration the residual norms measured BEFORE each of its
+    `nsweep` sweeps.  If every solve had already converged before sweep k the next
+    iteration uses max(1, k) sweeps, otherwise one more (at most MAX_SWEEPS)."""
+    need = 0
+    for norms in norm_lists:
+        k = next((i for i, v in enumerate(norms) if v <= tol), None)
+        if k is None:
+            return min(MAX_SWEEPS, nsweep + 1)
+        need = max(need, k)
+    return max(1, need)
+
+
+def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
+          reltol=1e-8, refine=2, verbose=False, history=None):
     """Returns dict(status, x, s, z, iters, pcost, dcost, gap, pres, dres).
 
     Stopping rule (all quantities of the de-homogenised point x/tau ...):
@@ -252,48 +309,52 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
     def factor(Wm):
         H = G.T @ (Wm.inv2(G) if Wm is not None else G)
         H = 0.5 * (H + H.T)
-        reg = static_reg * np.max(np.diag(H)) if static_reg else 0.0
-        bump = 0.0
-        for _ in range(20):
-            try:
-                Hr = H + (reg + bump) * np.eye(N) if (reg + bump) else H
-                cf = sla.cho_factor(Hr, lower=True, check_finite=True)
-                return H, cf
-            except (sla.LinAlgError, ValueError):
-                bump = max(1e-14 * np.max(np.diag(H)), 10 * bump)
-        raise FloatingPointError("Cholesky failed")
+        if not np.all(np.isfinite(H)):
+            raise FloatingPointError("non-finite normal matrix")
+        L, nfix = chol_piv(H)
+        chol_fixes[0] += nfix
+        return H, np.linalg.inv(L)          # M = L^-1, as the device solver keeps it
+
+    sweep_log = []
+    chol_fixes = [0]
+
+    def cho_solve(M, b):
+        return M.T @ (M @ b)
 
     def kkt_solve(Wm, H, cf, bx, bz):
-        """[0 G'; G -W^2][dx; dz] = [bx; bz].
+        """[0 G'; G -W^2][dx; dz] = [bx; bz] for one or two right-hand sides (columns);
+        returns (dx, dz, G dx).
 
-        dz is kept as an explicit vector and corrected incrementally, so the
-        dual equation G'dz = bx is driven to rounding level even when
-        ||H|| eps is large (the residual of an increment scales with the
-        increment, not with dx)."""
+        dz is kept as an explicit vector and corrected incrementally, so the dual
+        equation G'dz = bx is driven to rounding level even when ||H|| eps is large
+        (the residual of an increment scales with the increment, not with dx)."""
         wbz = Wm.inv2(bz) if Wm is not None else bz
         rhs = bx + G.T @ wbz
-        dx = sla.cho_solve(cf, rhs)
+        dx = cho_solve(cf, rhs)
         Gdx = G @ dx
         dz = (Wm.inv2(Gdx) if Wm is not None else Gdx) - wbz
-        nb = max(np.linalg.norm(bx), 1e-300)
-        for _ in range(refine):
+        norms = []
+        for _ in range(nsweep[0]):
             r = bx - G.T @ dz
-            if np.linalg.norm(r) <= 1e-14 * nb:
-                break
-            ddx = sla.cho_solve(cf, r)
+            norms.append(float(np.max(np.sqrt(np.sum(r * r, axis=0)))))
+            ddx = cho_solve(cf, r)
             dx = dx + ddx
             Gd = G @ ddx
+            Gdx = Gdx + Gd
             dz = dz + (Wm.inv2(Gd) if Wm is not None else Gd)
-        return dx, dz
+        sweep_log.append(norms)
+        return dx, dz, Gdx
 
     # ---- initial point (W = I) ------------------------------------------
+    nsweep = [int(refine)]
     H, cf = factor(None)
-    x, r_ = kkt_solve(None, H, cf, np.zeros(N), h)          # min ||Gx-h||
-    s = -r_                                                 # h - Gx
+    X0, Z0, _ = kkt_solve(None, H, cf, np.stack([np.zeros(N), -c], 1), np.stack([h, np.zeros(R)], 1))
+    x = X0[:, 0]                                            # min ||Gx-h||
+    s = -Z0[:, 0]                                           # h - Gx
     ts = cone.min_residual(s)
     if ts >= -1e-8 * max(1.0, np.linalg.norm(s)):
         s = s + (1.0 + ts) * e
-    _, z = kkt_solve(None, H, cf, -c, np.zeros(R))          # G'z=-c, least norm
+    z = Z0[:, 1]                                            # G'z=-c, least norm
     tz = cone.min_residual(z)
     if tz >= -1e-8 * max(1.0, np.linalg.norm(z)):
         z = z + (1.0 + tz) * e
@@ -301,6 +362,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
     status = STATUS_MAXIT
     it = 0
     info = {}
+    best = (np.inf, None, None)
     for it in range(max_iter + 1):
         rx = G.T @ z + c * tau
         rz = G @ x + s - h * tau
@@ -326,44 +388,57 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
         if verbose:
             print("%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e"
                   % (it, pcost, dcost, gap, pres, dres, kappa / tau, mu))
+        finite = np.isfinite(pres) and np.isfinite(dres) and np.isfinite(gap) and tau > 0
+        if not finite:
+            status = STATUS_NUMERICAL
+            break
         if pres <= feastol and dres <= feastol and (gap <= abstol or relgap <= reltol):
             status = STATUS_OPTIMAL
             break
-        if pinfres <= feastol:
+        # Farkas certificates; when tau has collapsed relative to kappa a looser
+        # certificate is accepted (the dual residual has a rounding floor ~1e-10)
+        collapsed = kappa / tau >= 1e6
+        if pinfres <= feastol or (collapsed and pinfres <= 1e-5):
             status = STATUS_PRIMAL_INFEASIBLE
             break
-        if dinfres <= feastol:
+        if dinfres <= feastol or (collapsed and dinfres <= 1e-5):
             status = STATUS_DUAL_INFEASIBLE
             break
+        # best iterate so far, for the reduced-accuracy exit
+        merit = max(pres, dres, min(relgap, gap / max(abstol, 1e-300) * reltol))
+        if merit < best[0]:
+            best = (merit, x / tau, dict(info))
         if it == max_iter:
             break
         try:
             Wm = _Scaling(cone, s, z)
             lam = Wm.apply(z)
             H, cf = factor(Wm)
-            x1, z1 = kkt_solve(Wm, H, cf, -c, h)
+            sweep_log.clear()
+            # constant system [x1 z1] and affine system in one two-column solve
+            XB, ZB, GB = kkt_solve(Wm, H, cf, np.stack([-c, -rx], 1), np.stack([h, s - rz], 1))
         except FloatingPointError:
             status = STATUS_NUMERICAL
             break
-        if not (np.all(np.isfinite(x1)) and np.all(np.isfinite(z1))):
+        x1, z1, Gx1 = XB[:, 0], ZB[:, 0], GB[:, 0]
+        if not (np.all(np.isfinite(XB)) and np.all(np.isfinite(ZB))):
             status = STATUS_NUMERICAL
             break
         wz1 = Wm.apply(z1)
         den_t = kappa / tau + wz1 @ wz1
 
-        def direction(sigma, ds_c, dk_c):
-            # ds_c, dk_c: right-hand sides of the (scaled) complementarity rows
-            lds = _cone_div(cone, lam, ds_c)
-            bx = -(1 - sigma) * rx
-            bz = -(1 - sigma) * rz - Wm.apply(lds)
-            x2, z2 = kkt_solve(Wm, H, cf, bx, bz)
+        def direction(sigma, dk_c, x2, z2, Gx2):
             bt = -(1 - sigma) * rt
             dtau = (dk_c / tau - bt + c @ x2 + h @ z2) / den_t
             dx = x2 + dtau * x1
             dz = z2 + dtau * z1
+            # ds from the primal equation G dx + ds - h dtau = -(1-sigma) rz: the primal
+            # residual then shrinks by exactly (1 - alpha (1-sigma)) per step and the
+            # rounding of the scaled solve lands in the complementarity row, where it
+            # is harmless.
+            ds = -(1 - sigma) * rz - Gx2 - dtau * (Gx1 - h)
             wdz = Wm.apply(dz)
-            dss = lds - wdz                                   # W^-1 ds
-            ds = Wm.apply(dss)
+            dss = Wm.apply(ds, inverse=True)                  # W^-1 ds
             dkap = (dk_c - kappa * dtau) / tau
             return dx, ds, dz, dtau, dkap, dss, wdz
 
@@ -373,13 +448,21 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
             return 1.0 if t == 0.0 else min(1.0, frac / t)
 
         ll = _cone_prod(cone, lam, lam)
-        dxa, dsa, dza, dta, dka, dssa, wdza = direction(0.0, -ll, -kappa * tau)
+        # affine direction: lam \ (-lam o lam) = -lam, W lam = s  ->  bz = s - rz (in the batch above)
+        dxa, dsa, dza, dta, dka, dssa, wdza = direction(0.0, -kappa * tau, XB[:, 1], ZB[:, 1], GB[:, 1])
         alpha_a = step_of(dssa, wdza, dta, dka, 1.0)
         sigma = (1.0 - alpha_a) ** 3
         ds_c = sigma * mu * e - ll - _cone_prod(cone, dssa, wdza)
         dk_c = sigma * mu - kappa * tau - dka * dta
-        dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, ds_c, dk_c)
+        lds = _cone_div(cone, lam, ds_c)
+        try:
+            x2, z2, Gx2 = kkt_solve(Wm, H, cf, -(1 - sigma) * rx, -(1 - sigma) * rz - Wm.apply(lds))
+        except FloatingPointError:
+            status = STATUS_NUMERICAL
+            break
+        dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, dk_c, x2, z2, Gx2)
         alpha = step_of(dss, wdz, dtau, dkap, STEP)
+        nsweep[0] = next_sweeps(sweep_log, nsweep[0], REFTOL * nrm_c)
         if history is not None:
             sl_, zl_ = s[:cone.l], z[:cone.l]
             history[-1].update(alpha=alpha, alpha_a=alpha_a, sigma=sigma,
@@ -393,6 +476,13 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=100, feastol=1e-9, abstol=1e-10,
         if not (np.isfinite(tau) and tau > 0 and np.all(np.isfinite(x))):
             status = STATUS_NUMERICAL
             break
-    out = dict(status=status, x=x / tau, s=s / tau, z=z / tau)
+    out = dict(status=status, x=x / tau, s=s / tau, z=z / tau, chol_fixes=chol_fixes[0])
     out.update(info)
+    if status in (STATUS_MAXIT, STATUS_NUMERICAL) and best[1] is not None:
+        bi = best[2]
+        # the reference accepts CVX's 'Inaccurate/Solved' (fir_ap_cvx.m:176): reduced tolerances
+        if bi["pres"] <= INACC_FEAS and bi["dres"] <= INACC_FEAS and (bi["relgap"] <= INACC_GAP or bi["gap"] <= abstol):
+            out.update(bi)
+            out["status"] = STATUS_OPTIMAL_INACCURATE
+            out["x"] = best[1]
     return out
