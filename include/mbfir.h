@@ -106,6 +106,12 @@ int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f,
                           const double* dc_re, const double* dc_im, const mbfir_opts* opts,
                           double* h_re, double* h_im, mbfir_info* info);
 
+/* Conic solution z = [x ; y] / tau of the last solve on this context (n_unknowns doubles of
+ * mbfir_info; returns the count copied, or <0).  For fir_ap_cvx x is the autocorrelation
+ * [r(0), Re r(1..n-1), Im r(1..n-1)] (fir_ap_cvx.m:185-186), for the others [Re h ; Im h] or the
+ * half filter.  Lets callers check feasibility / optimality of what the solver returned. */
+int mbfir_last_solution(mbfir_ctx* ctx, double* z, int capacity);
+
 /* ---- introspection / test hooks (host only unless stated) --------------------------------
  * mbfir_assemble(): run the product's problem assembly for designer `which`
  *   (0 ap, 1 qp, 2 linprog, 3 qprog_phs) WITHOUT touching the GPU and return an opaque

@@ -68,6 +68,7 @@ SYMBOLS = {
     "mbfir_default_opts": (None, [C.POINTER(Opts)]),
     "mbfir_set_allreduce": (None, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mbfir_version": (C.c_char_p, []),
+    "mbfir_last_solution": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "mbfir_ap_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double,
                                  C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
     "mbfir_qp_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, C.c_int,
@@ -142,6 +143,14 @@ class Context:
 
     def last_error(self):
         return load_library().mbfir_last_error(self._h).decode()
+
+    def last_solution(self, n_unknowns):
+        """Conic solution [x ; y] / tau of the last solve (mbfir_last_solution)."""
+        z = np.zeros(int(n_unknowns))
+        k = load_library().mbfir_last_solution(self._h, _ptr(z), len(z))
+        if k < 0:
+            raise MbfirError("mbfir_last_solution failed")
+        return z[:k]
 
     def set_allreduce(self, fn):
         """fn(ptr:int, count:int, op:int) -> int ; op 0 = sum, 1 = max (device pointer)."""

@@ -11,6 +11,7 @@ using namespace mbfir;
 
 struct mbfir_ctx {
     std::unique_ptr<Solver> solver;
+    std::vector<double> last_x;
     std::string err;
     mbfir_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -81,6 +82,7 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         std::vector<double> x;
         SolveOpts so = to_opts(opts);
         int st = ctx->solver->solve(P, so, x, si);
+        ctx->last_x = x;
         double t_solved = now_ms();
         int rc = status_to_rc(st);
         if (rc == MBFIR_SOLVED) post(x);
@@ -124,6 +126,14 @@ void mbfir_set_allreduce(mbfir_ctx* ctx, mbfir_allreduce_fn fn, void* user) {
     if (!ctx) return;
     ctx->allreduce = fn;
     ctx->allreduce_user = user;
+}
+
+int mbfir_last_solution(mbfir_ctx* ctx, double* z, int capacity) {
+    if (!ctx || !z) return MBFIR_E_ARG;
+    int n = int(ctx->last_x.size());
+    if (capacity < n) n = capacity;
+    std::memcpy(z, ctx->last_x.data(), sizeof(double) * n);
+    return n;
 }
 
 int mbfir_ap_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,

@@ -82,9 +82,10 @@ void gram_launch(const GramPlan& gp, const double* A, const double* d, double* s
 void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 
 // Cholesky + inverse of the Cholesky factor.  H is np x np row-major (np multiple of 64), lower
-// triangle referenced; on exit H holds L (upper zeroed), M = L^-1 (lower), Mt = M'.
-// W1, W2 are np x np workspaces.  flag[0] != 0 on a non-positive pivot.
-void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st);
+// triangle referenced; on exit M = L^-1 (lower, one Newton correction applied), Mt = M'.
+// W1 is a workspace of np*np + 65*np doubles.  flag[0] counts replaced (noise-level) pivots.
+void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
+                     double* Lcopy = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
 // y[v] = Lo * b[v] for a row-major lower (upper=0) or upper (upper=1) triangular np x np matrix.
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,

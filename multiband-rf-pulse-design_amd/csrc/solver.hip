@@ -1223,7 +1223,7 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(Mpad * ld);
     S.T = ar.get<double>(nw * ld * ld);
-    S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np);
+    S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
     S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
@@ -1458,10 +1458,11 @@ void Solver::test_chol(int n, const double* Hh, double* out_l, double* out_m) {
     for (size_t i = 0; i < np; ++i) Hp[i * np + i] = 1.0;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) Hp[i * np + j] = Hh[(size_t)i * n + j];
-    DevBuf dH(np * np * 8), dM(np * np * 8), dMt(np * np * 8), dW(np * np * 8), df(16);
+    DevBuf dH(np * np * 8), dM(np * np * 8), dMt(np * np * 8), dW((np * np + 65 * np) * 8), df(16), dL(np * np * 8);
     MBFIR_HIP(hipMemcpyAsync(dH.p, Hp.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
-    chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st);
-    MBFIR_HIP(hipMemcpy2DAsync(out_l, (size_t)n * 8, dH.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+    chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st,
+                    dL.as<double>());
+    MBFIR_HIP(hipMemcpy2DAsync(out_l, (size_t)n * 8, dL.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpy2DAsync(out_m, (size_t)n * 8, dM.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));
     MBFIR_HIP(hipGetLastError());

@@ -1,0 +1,85 @@
+"""GPU tests of the individual HIP kernels through the C ABI test hooks (include/mbfir.h)."""
+import numpy as np
+import pytest
+from conftest import relinf
+
+import mbfir
+from oracle import specfact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,nt,nw", [(7, 5, 1), (100, 37, 1), (1000, 200, 3), (5000, 399, 1), (3001, 129, 3), (20000, 260, 1)])
+def test_gram_matches_numpy(m, nt, nw):
+    """K2: T_w = A' diag(d_w) A on the fp64 matrix cores; fp64 reference A.T*d @ A, tol 1e-13."""
+    rng = np.random.default_rng(m + nt)
+    A = rng.standard_normal((m, nt))
+    d = rng.random((nw, m)) * 10.0 ** rng.integers(-6, 6, size=(nw, m))      # wide dynamic range like z/s
+    T = mbfir.test_gram(A, d)
+    ref = np.stack([(A.T * d[w]) @ A for w in range(nw)])
+    assert relinf(T, ref) <= 1e-13
+    assert np.abs(T - np.transpose(T, (0, 2, 1))).max() == 0.0              # exactly symmetric
+
+
+def test_gram_of_trig_rows_is_toeplitz_plus_hankel():
+    """Structural oracle for K2: cos/cos block = (C(j-k)+C(j+k))/2 computed from 2N moments."""
+    n, m = 40, 2500
+    w = np.sort(np.random.default_rng(5).uniform(-np.pi, np.pi, m))
+    j = np.arange(n)
+    A = np.cos(np.outer(w, j))
+    d = np.random.default_rng(6).random(m) + 0.01
+    T = mbfir.test_gram(A, d)[0]
+    C = np.array([np.sum(d * np.cos(l * w)) for l in range(2 * n)])
+    ref = 0.5 * (C[np.abs(j[:, None] - j[None, :])] + C[j[:, None] + j[None, :]])
+    assert relinf(T, ref) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 50, 64, 65, 200, 449, 1023])
+def test_cholesky_and_inverse(n):
+    """K4: H = L L', M = L^-1 (blocked Cholesky + recursive-doubling inverse)."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n + 20, n))
+    H = B.T @ B + 0.1 * np.eye(n)
+    L, M = mbfir.test_chol(H)
+    Lr = np.linalg.cholesky(H)
+    assert relinf(L, Lr) <= 1e-12
+    assert np.abs(np.triu(L, 1)).max() == 0 and np.abs(np.triu(M, 1)).max() == 0
+    assert np.abs(M @ Lr - np.eye(n)).max() <= 1e-11
+    b = rng.standard_normal(n)
+    x = M.T @ (M @ b)
+    assert np.linalg.norm(H @ x - b) <= 1e-10 * np.linalg.norm(b)
+
+
+def test_cholesky_ill_conditioned_scaling():
+    """IPM-like matrix: A' D A with D spanning ten decades (cond ~1e9)."""
+    rng = np.random.default_rng(11)
+    n, m = 300, 4000
+    A = np.cos(np.outer(rng.uniform(-3, 3, m), np.arange(n)))
+    d = 10.0 ** rng.uniform(-5, 5, m)
+    H = (A.T * d) @ A
+    H += 1e-9 * np.abs(H).max() * np.eye(n)
+    L, M = mbfir.test_chol(H)
+    Lr = np.linalg.cholesky(H)
+    assert relinf(L @ L.T, H) <= 1e-12
+    assert relinf(L, Lr) <= 1e-6
+    b = rng.standard_normal(n)
+    x = M.T @ (M @ b)
+    # explicit-inverse solve: eps*cond(H) ~ 3e-7 at best; LAPACK trtri gives 2e-5 on this matrix
+    assert np.linalg.norm(H @ x - b) <= 2e-4 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n", [2, 16, 58, 100, 257])
+def test_spectral_factorisation_matches_oracle(n):
+    """K7: device fmp2/mag2mp (fir_ap_cvx.m:264-304) against the numpy restatement."""
+    rng = np.random.default_rng(n)
+    h0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    r = np.correlate(h0, h0, mode="full")[n - 1:]
+    x = np.concatenate([[r[0].real], r[1:].real, r[1:].imag])
+    hg = mbfir.test_specfact(x, n)
+    ho = specfact.fmp2(specfact.x_to_r(x, n))
+    assert relinf(hg, ho) <= 1e-10
+
+
+def test_fp64_peak_microbenchmark_runs():
+    mf, va = mbfir.mfma_peak()
+    assert 5.0 < mf < 200.0 and 5.0 < va < 200.0
