@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FIR designs/sec (and IPM iterations/sec) of the arbitrary-phase SOCP designer
+at n=512 taps, m=16384 grid points (BASELINE.json metric), on N GPUs of one node.
+
+A "step" is one complete design through the C ABI (mbfir_ap_solve: host assembly, trig matrix
+generation, every IPM iteration on the GPU, spectral factorisation) of the S-C13 bSSFP spec
+(bSSFP_pulse_sb_mb.m:9-52) in the fixed-duration regime, obj=0.1, Peak=1e-3.  Inputs are a few
+dozen doubles, so "inputs resident in HBM" is trivially true; the timed region includes the
+PCIe hand-over of the spec and of the taps.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the default mode gives every
+rank its own design (independent designs -- bisection probes / parameter sweeps shard with no
+data-path collective, SURVEY 8e "replicas only"), so scaling is weak and
+value = N * K / max-over-ranks time.
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F100 = [-0.241994, -0.233994, -0.152431, -0.144431, -0.083851, -0.075851, -0.052798, -0.044798, -0.004, 0.004]
+A_C13 = [0.0] * 8 + [0.500125, 0.500125]
+D_C13 = [0.00250001] * 4 + [0.00866503]
+PEAK_FP64_MATRIX_TF = 78.6     # AMD's public MI355X fp64 matrix figure; the local hardware guide lists none
+
+
+def workload(n):
+    s = 100.0 / n                     # fixed duration T = 4 ms: fs = n/T, band edges scale with 100/n
+    return [x * s for x in F100], A_C13, D_C13
+
+
+def cpu_baseline(n, grid_m, gpu_iters, iters_cpu):
+    """The oracle (NumPy/OpenBLAS port of the same algorithm) on this box's host cores, on a bounded
+    sample: assembly + the first `iters_cpu` IPM iterations; per-iteration cost is constant, so the
+    per-design time is extrapolated to the iteration count the GPU run needed."""
+    from oracle import assemble, conic_ipm
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    f, a, d = workload(n)
+    t0 = time.perf_counter()
+    P = assemble.assemble_fir_ap_cvx(n, f, a, d, 0.1, 1e-3, grid_m)
+    t1 = time.perf_counter()
+    conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"], max_iter=iters_cpu)
+    t2 = time.perf_counter()
+    t_iter = (t2 - t1) / (iters_cpu + 1)            # the initial point costs one factorisation + solve
+    t_design = (t1 - t0) + t_iter * (gpu_iters + 1)
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": 1.0 / t_design, "unit": "designs/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle (NumPy/OpenBLAS dense conic IPM, same algorithm): assembly %.1f s + first %d of %d IPM "
+                      "iterations (%.2f s each), extrapolated to the full design" % (t1 - t0, iters_cpu, gpu_iters, t_iter),
+            "s_per_iteration": t_iter, "iters_per_s": 1.0 / t_iter}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--grid-m", type=int, default=16384)
+    ap.add_argument("--mode", choices=["batch", "shard"], default="batch")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="oracle iterations for the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run\n" % (args.gpus, world))
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if args.mode == "shard":
+        sys.stderr.write("bench.py: the row-sharded mode is not wired into this round's build\n")
+        sys.exit(2)
+
+    import mbfir
+    ctx = mbfir.Context(local_rank)
+    f, a, d = workload(args.n)
+    opts = mbfir.make_opts(grid_m=args.grid_m)
+
+    def step():
+        h, status, info = mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)
+        if status != "Solved":
+            raise RuntimeError("benchmark design did not solve: %r" % (info,))
+        return info
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    infos = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        iters = sum(i["iters"] for i in infos)
+        launches = sum(i["gram_launches"] for i in infos)
+        gram_ms = sum(i["ms_gram"] for i in infos)
+        flop_per_launch = infos[0]["gram_flop"] / max(1, infos[0]["gram_launches"] // max(1, infos[0]["iters"] + 1))
+        ach = flop_per_launch / (gram_ms / launches * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+        try:
+            peak_mfma, peak_valu = mbfir.mfma_peak(ctx)
+        except Exception:
+            peak_mfma = peak_valu = float("nan")
+        out = {
+            "metric": "FIR designs/sec, n=%d taps m=%d arbitrary-phase SOCP (fir_ap_cvx form)" % (args.n, args.grid_m),
+            "value": world * args.steps / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "S-C13 bSSFP 5-band spec, fixed-duration regime, fir_ap_cvx(n=%d, obj=0.1, Peak=1e-3), "
+                                   "grid_m=%d (+10 band edges), one design per rank per step" % (args.n, args.grid_m),
+                       "n_taps": args.n, "grid_m": args.grid_m, "unknowns": infos[0]["n_unknowns"], "rows": infos[0]["n_rows"],
+                       "mode": args.mode, "parallelism": "independent designs x%d" % world},
+            "ipm_iters_per_design": iters / args.steps,
+            "ipm_iters_per_s": world * iters / elapsed,
+            "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / args.steps,
+                                        "solve": sum(i["ms_solve"] for i in infos) / args.steps,
+                                        "gram_kernel": gram_ms / args.steps,
+                                        "cholesky_inverse": sum(i["ms_chol"] for i in infos) / args.steps,
+                                        "spectral_factor": sum(i["ms_post"] for i in infos) / args.steps},
+            "roofline": {"kernel": "k_gram (A' D A, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
+                         "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MATRIX_TF,
+                         "traffic": None, "flop_per_launch": flop_per_launch, "launches": launches,
+                         "avg_launch_ms": gram_ms / max(1, launches),
+                         "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
+                         "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu},
+        }
+        if world == 1 and args.cpu_iters > 0:
+            out["cpu_baseline"] = cpu_baseline(args.n, args.grid_m, int(round(iters / args.steps)), args.cpu_iters)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,8 +72,11 @@ typedef struct mbfir_info {
     int n_lp, n_q3, n_big;
     double pcost, dcost, gap, relgap, pres, dres;
     double ms_assemble, ms_solve, ms_post, ms_total;   /* host wall-clock */
-    double ms_gram, ms_chol;                           /* device time (HIP events), summed over iterations */
-    double gram_flop;                                  /* algorithmic flop of ONE scaled-Gram launch set */
+    double ms_gram;      /* device time of the k_gram launches alone (HIP events on the solver stream), summed */
+    double ms_chol;      /* device time of the Cholesky + inverse phase, summed                              */
+    double gram_flop;    /* algorithmic flop of the k_gram launches of ONE build: nw * Mf * Nt * (Nt+1)      */
+    int gram_launches;   /* k_gram launches behind ms_gram (= builds * nw; builds = iterations + 1)          */
+    int reserved_;
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to

@@ -48,7 +48,7 @@ class Info(C.Structure):
                 ("pres", C.c_double), ("dres", C.c_double),
                 ("ms_assemble", C.c_double), ("ms_solve", C.c_double), ("ms_post", C.c_double),
                 ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
-                ("gram_flop", C.c_double)]
+                ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("reserved_", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -59,6 +59,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->ms_assemble = (t_asm - t0) + si.ms_assemble; info->ms_solve = si.ms_solve;
     info->ms_post = t_end - t_solved; info->ms_total = t_end - t0;
     info->ms_gram = si.ms_gram; info->ms_chol = si.ms_chol; info->gram_flop = si.gram_flop;
+    info->gram_launches = si.h_builds * (P.quad ? 3 : 1);
 }
 
 // Common driver: `asm_rc` is the assembly result, `post` maps the solution vector to taps.

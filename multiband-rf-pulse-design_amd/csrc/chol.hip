@@ -1,8 +1,7 @@
-// K4: dense KKT factorisation.  H = L L' (blocked right-looking Cholesky, 64-wide panels) and
-// M = L^-1 (diagonal 64 x 64 inverses from the panel kernel, off-diagonal blocks by recursive
-// doubling  X21 = -inv22 * L21 * inv11 -- log2(N/64) levels of batched MFMA GEMMs), so that every
-// later solve is two triangular GEMVs (x = M'(M b)) instead of two latency-bound substitutions.
-// All fp64; products on v_mfma_f64_16x16x4_f64.
+// K4: dense KKT factorisation.  H = L L' (blocked right-looking Cholesky, 64-wide panels) with
+// M = L^-1 carried along by forward substitution on the identity, so that every later solve is
+// two triangular GEMVs (x = M'(M b)) instead of two latency-bound substitutions.
+// All fp64; tile products on v_mfma_f64_16x16x4_f64.
 #include "dev_common.h"
 
 namespace mbfir {
@@ -54,176 +53,166 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) S[e >> 6][e & 63] = src[(long)(e >> 6) * ld + (e & 63)];
 }
 
-// Panel step k: every block factorises the 64x64 diagonal block in LDS (redundantly -- 87 kflop);
-// block 0 publishes L_kk and its inverse (a diagonal block of M); block b>0 forms
-// L_ik = A_ik L_kk^-T by forward substitution (multiplying by the explicit inverse is not
-// backward stable and breaks the factorisation on the near-singular late IPM iterates).
-// Pivot rule: a pivot that is not above pivtol * H_jj is rounding noise; it is replaced by 1e128,
-// which removes that column from the factorisation (flag counts the replacements).
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ H, double* __restrict__ M, int np,
+// =================================================================================================
+// Right-looking blocked Cholesky that carries M = L^-1 along (two launches per 64-wide panel):
+//
+//   step A_k : (a) panel blocks -- every block factorises A_kk in LDS (redundantly, 87 kflop);
+//                  block 0 publishes L_kk (side buffer Dfac), block b>0 solves  L_ik L_kk' = A_ik
+//                  by forward substitution (NOT by multiplying with inv(L_kk): that is not backward
+//                  stable and breaks the factorisation on the near-singular late IPM iterates);
+//              (b) R-update tiles of the previous panel:  M_ij -= L_i,k-1 M_k-1,j   (i >= k, j < k)
+//   step B_k : (a) trailing tiles  A_ij -= L_ik L_jk'   (k < j <= i);
+//              (b) row block k of the inverse:  M_kj = L_kk^-1 R_kj  (j <= k) by forward substitution
+//                  over the 64 columns of each tile (R lives in the M buffer, initialised to I).
+// M computed this way has the accuracy of a substitution-based inverse (measured: solve residual
+// 3e-5 at cond(H)=3e9, same as LAPACK trtri; multiplying explicit 64x64 inverses gives 2e-3).
+// Pivot rule: a pivot not above pivtol * H_jj is rounding noise and is replaced by H_jj itself; by
+// Cauchy-Schwarz the rest of that Schur-complement column is at noise level too, so the column is
+// effectively decoupled and M'M stays a non-singular preconditioner (flag counts the replacements).
+// =================================================================================================
+constexpr int CLDP = 65;     // odd LDS stride: lanes = rows is conflict free
+
+// Forward substitution  S x = a  for one right-hand side per group of 4 adjacent lanes.
+// Lane q (= lane & 3) holds a[t] / x[t] for t = 4*i + q in v[i].  S is lower triangular in LDS.
+__device__ __forceinline__ void subst64(const double (*S)[CLDP], double v[16]) {
+    const int q = threadIdx.x & 3;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        double part = 0;
+#pragma unroll
+        for (int i = 0; i * 4 < j; ++i) {
+            const int t = i * 4 + q;
+            if (t < j) part += v[i] * S[j][t];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (q == (j & 3)) v[j >> 2] = (v[j >> 2] - part) / S[j][j];
+    }
+}
+
+__device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
+    ti = int((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while ((long)ti * (ti + 1) / 2 > t) --ti;
+    tj = t - ti * (ti + 1) / 2;
+}
+
+// C_tile (64x64 at dst) -= A_tile * B_tile (TRANSB: B_tile') through the MFMA helper
+template <bool TRANSB>
+__device__ __forceinline__ void tile_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ Bg,
+                                            double* __restrict__ dst, int np) {
+    double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
+    load_block(P, Ag, np);
+    load_block(Q, Bg, np);
+    __syncthreads();
+    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    mma64<TRANSB>(P, Q, 0, CB, acc);
+    acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
+}
+
+__global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
                                                     int k, const double* __restrict__ d0, double pivtol,
                                                     double* __restrict__ Dfac, int* __restrict__ flag) {
-    __shared__ double S[CB][CLD];
-    __shared__ double X[CB][CLD];
+    __shared__ double smem[2 * CB * CLD];
     const int tid = threadIdx.x;
+    const int npanel = nblk - k;
+    if ((int)blockIdx.x >= npanel) {
+        // (b) R-update of panel k-1:  M_ij -= L_i,k-1 * M_k-1,j   for i >= k, j < k
+        const int t = blockIdx.x - npanel;
+        const int i = k + t / k, j = t % k;
+        const long km = (long)(k - 1) * CB;
+        tile_update<false>(smem, H + (long)i * CB * np + km, M + km * np + (long)j * CB,
+                           M + (long)i * CB * np + (long)j * CB, np);
+        return;
+    }
+    // (a) panel
+    double(*S)[CLDP] = reinterpret_cast<double(*)[CLDP]>(smem);
     const long kk = (long)k * CB;
     for (int e = tid; e < CB * CB; e += 256) {
         int i = e >> 6, j = e & 63;
         S[i][j] = j <= i ? H[(kk + i) * np + kk + j] : 0.0;
     }
-    // unblocked right-looking Cholesky of S
+    const int tx = tid & 63, ty = tid >> 6;
     for (int j = 0; j < CB; ++j) {
         __syncthreads();
         double p = S[j][j];
         if (!(p > pivtol * d0[kk + j])) {
             if (tid == 0 && blockIdx.x == 0) atomicAdd(flag, 1);
-            p = 1e128;
+            p = fmax(d0[kk + j], 1e-300);
         }
-        const double r = sqrt(p), rinv = 1.0 / r;
+        const double pinv = 1.0 / p;
+        const double a = S[tx][j];
+        if (tx > j)
+            for (int c = j + 1 + ty; c <= tx; c += 4) S[tx][c] -= a * (S[c][j] * pinv);
         __syncthreads();
-        if (tid == 0) S[j][j] = r;
-        for (int i = j + 1 + tid; i < CB; i += 256) S[i][j] *= rinv;
-        __syncthreads();
-        const int nrem = CB - 1 - j;
-        for (int e = tid; e < nrem * nrem; e += 256) {
-            int ii = e / nrem, cc = e - ii * nrem;
-            if (cc <= ii) S[j + 1 + ii][j + 1 + cc] -= S[j + 1 + ii][j] * S[j + 1 + cc][j];
+        if (ty == 0) {
+            const double r = sqrt(p);
+            if (tx > j) S[tx][j] = a / r;
+            else if (tx == j) S[j][j] = r;
         }
     }
     __syncthreads();
     if (blockIdx.x == 0) {
-        // X = S^-1 (lower): thread c solves S x = e_c by forward substitution
-        for (int e = tid; e < CB * CB; e += 256) X[e >> 6][e & 63] = 0.0;
-        __syncthreads();
-        if (tid < CB) {
-            const int c = tid;
-            for (int i = c; i < CB; ++i) {
-                double sum = (i == c) ? 1.0 : 0.0;
-                for (int j = c; j < i; ++j) sum -= S[i][j] * X[j][c];
-                X[i][c] = sum / S[i][i];
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < CB * CB; e += 256) {
-            int i = e >> 6, j = e & 63;
-            // L_kk goes to a side buffer: the other blocks of this launch may still be reading A_kk
-            // from H; k_finish_L copies it into H after the last panel
-            Dfac[(kk + i) * CB + j] = S[i][j];
-            M[(kk + i) * np + kk + j] = X[i][j];
-        }
+        // L_kk goes to a side buffer: the other blocks of this launch may still be reading A_kk from H
+        for (int e = tid; e < CB * CB; e += 256) Dfac[kk * CB + e] = S[e >> 6][e & 63];
         return;
     }
-    // rows of A_ik: 4 threads per row (same wave), x_j = (a_j - sum_{t<j} x_t S[j][t]) / S[j][j]
+    // rows of A_ik: X L_kk' = A_ik  <=>  L_kk x_r' = a_r' ; row r = tid/4, lane q holds columns t = 4i+q
     const long ii = (long)(k + blockIdx.x) * CB;
-    load_block(X, H + ii * np + kk, np);
-    __syncthreads();
     const int r = tid >> 2, q = tid & 3;
-    for (int j = 0; j < CB; ++j) {
-        double part = 0;
-        for (int t = q; t < j; t += 4) part += X[r][t] * S[j][t];
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        if (q == 0) X[r][j] = (X[r][j] - part) / S[j][j];
-        __syncthreads();                      // the row's 4 lanes (and the compiler) see the new x_j
+    double* row = H + (ii + r) * np + kk;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = row[4 * i + q];
+    subst64(S, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) row[4 * i + q] = v[i];
+}
+
+__global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
+                                                    int k, const double* __restrict__ Dfac) {
+    __shared__ double smem[2 * CB * CLD];
+    const int tid = threadIdx.x;
+    const int nrem = nblk - k - 1;
+    const int ntrail = nrem * (nrem + 1) / 2;
+    const long kk = (long)k * CB;
+    if ((int)blockIdx.x < ntrail) {
+        // (a) trailing update  A_ij -= L_ik L_jk'
+        int ti, tj;
+        tile_decode(blockIdx.x, ti, tj);
+        const long i0 = (long)(k + 1 + ti) * CB, j0 = (long)(k + 1 + tj) * CB;
+        tile_update<true>(smem, H + i0 * np + kk, H + j0 * np + kk, H + i0 * np + j0, np);
+        return;
     }
-    double* dst = H + ii * np + kk;
-    for (int e = tid; e < CB * CB; e += 256) dst[(long)(e >> 6) * np + (e & 63)] = X[e >> 6][e & 63];
-}
-
-// Trailing update after panel k:  A_ij -= L_ik L_jk'   for k < j <= i.
-__global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ H, int np, int k) {
-    __shared__ double P[CB][CLD];
-    __shared__ double Q[CB][CLD];
-    // decode lower-triangular tile index
-    int t = blockIdx.x;
-    int ti = int((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while ((long)ti * (ti + 1) / 2 > t) --ti;
-    int tj = t - ti * (ti + 1) / 2;
-    const long kk = (long)k * CB, i0 = (long)(k + 1 + ti) * CB, j0 = (long)(k + 1 + tj) * CB;
-    load_block(P, H + i0 * np + kk, np);
-    load_block(Q, H + j0 * np + kk, np);
+    // (b) M_kj = L_kk^-1 R_kj : column c = tid/4 of the tile is one right-hand side
+    const int j = blockIdx.x - ntrail;
+    double(*S)[CLDP] = reinterpret_cast<double(*)[CLDP]>(smem);
+    for (int e = tid; e < CB * CB; e += 256) S[e >> 6][e & 63] = Dfac[kk * CB + e];
     __syncthreads();
-    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    mma64<true>(P, Q, 0, CB, acc);
-    double* dst = H + i0 * np + j0;
-    acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
+    const int c = tid >> 2, q = tid & 3;
+    double* col = M + kk * np + (long)j * CB + c;
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = col[(long)(4 * i + q) * np];
+    subst64(S, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) col[(long)(4 * i + q) * np] = v[i];
 }
 
-// Zero the strict upper triangle of H and drop in the diagonal-block factors (H then holds a clean L).
-__global__ void k_finish_L(double* __restrict__ H, int np, const double* __restrict__ Dfac) {
+__global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < np) { d0[j] = H[(long)j * np + j]; M[(long)j * np + j] = 1.0; }      // R starts as the identity
+}
+
+// L (np x np, clean lower triangle) from the factored H and the diagonal-block side buffer
+__global__ void k_extract_L(const double* __restrict__ H, int np, const double* __restrict__ Dfac, double* __restrict__ Lout) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)np * np) return;
     long i = e / np, j = e - i * np;
-    if (j > i) H[e] = 0.0;
-    else if ((i / CB) == (j / CB)) H[e] = Dfac[i * CB + (j % CB)];
-}
-
-// Batched GEMM used by the inverse assembly.  For pair z at level `u` (unit size in elements):
-//   o = z*2u, b1 = u, b2 = min(u, np-o-u)   (skipped when o+u >= np)
-//   stage 0:  W[o+u.., o..]  =  L21 * inv11          (L21 = H[o+u.., o..], inv11 = M[o.., o..])
-//   stage 1:  M[o+u.., o..]  = -inv22 * W[o+u.., o..] (inv22 = M[o+u.., o+u..])
-// inv11 / inv22 are lower triangular, so the k range is clipped to the non-zero tiles.
-__global__ __launch_bounds__(256) void k_inv_gemm(const double* __restrict__ H, double* __restrict__ M,
-                                                  double* __restrict__ W, int np, int u, int stage) {
-    __shared__ double As[CB][CLD];
-    __shared__ double Bs[CB][CLD];
-    const long o = (long)blockIdx.z * 2 * u;
-    if (o + u >= np) return;
-    const int b1 = u, b2 = int(np - o - u < u ? np - o - u : u);
-    const int tj = blockIdx.x, ti = blockIdx.y;      // tile (ti,tj) of the b2 x b1 result
-    if (ti * CB >= b2 || tj * CB >= b1) return;
-    const double *A, *B;
-    double* C;
-    int kbeg, kend;                                   // in tiles
-    if (stage == 0) {
-        A = H + (o + u) * np + o;                     // L21 (b2 x b1)
-        B = M + o * np + o;                           // inv11 (b1 x b1), lower: B[k][j]!=0 for k>=j
-        C = W + (o + u) * np + o;
-        kbeg = tj; kend = b1 / CB;
-    } else {
-        A = M + (o + u) * np + (o + u);               // inv22 (b2 x b2), lower: A[i][k]!=0 for k<=i
-        B = W + (o + u) * np + o;                     // T (b2 x b1)
-        C = M + (o + u) * np + o;
-        kbeg = 0; kend = ti + 1;
-    }
-    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    for (int kt = kbeg; kt < kend; ++kt) {
-        __syncthreads();
-        load_block(As, A + (long)ti * CB * np + (long)kt * CB, np);
-        load_block(Bs, B + (long)kt * CB * np + (long)tj * CB, np);
-        __syncthreads();
-        mma64<false>(As, Bs, 0, CB, acc);
-    }
-    double* dst = C + (long)ti * CB * np + (long)tj * CB;
-    const double sgn = stage == 0 ? 1.0 : -1.0;
-    acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = sgn * v; });
-}
-
-// Lower-triangular tile products for the Newton correction of M = L^-1:
-//   mode 0:  C = I - A B     (E = I - L M)
-//   mode 1:  C = A + A B     (M_new = M + M E)
-// A, B, C lower triangular np x np; tile (ti,tj), ti >= tj, sums k = tj..ti.
-__global__ __launch_bounds__(256) void k_tri_gemm(const double* __restrict__ A, const double* __restrict__ B,
-                                                  double* __restrict__ C, int np, int mode) {
-    __shared__ double As[CB][CLD];
-    __shared__ double Bs[CB][CLD];
-    const int tj = blockIdx.x, ti = blockIdx.y;
-    if (tj > ti) return;
-    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-    for (int kt = tj; kt <= ti; ++kt) {
-        __syncthreads();
-        load_block(As, A + (long)ti * CB * np + (long)kt * CB, np);
-        load_block(Bs, B + (long)kt * CB * np + (long)tj * CB, np);
-        __syncthreads();
-        mma64<false>(As, Bs, 0, CB, acc);
-    }
-    const long base = (long)ti * CB * np + (long)tj * CB;
-    acc_foreach(acc, [&](int i, int j, double v) {
-        const long o = base + (long)i * np + j;
-        if (mode == 0) C[o] = ((ti == tj && i == j) ? 1.0 : 0.0) - v;
-        else C[o] = A[o] + v;
-    });
+    double v = 0.0;
+    if (j <= i) v = ((i / CB) == (j / CB)) ? Dfac[(i / CB) * CB * CB + (i % CB) * CB + (j % CB)] : H[e];
+    Lout[e] = v;
 }
 
 __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ Mt, int np) {
@@ -234,43 +223,22 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
     for (int r = threadIdx.y; r < 32; r += blockDim.y) Mt[(long)(bx + r) * np + by + threadIdx.x] = tile[threadIdx.x][r];
 }
 
-__global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < np) d0[j] = H[(long)j * np + j];
-}
-
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
                      double* Lcopy) {
     const int nblk = np / CB;
     const double pivtol = 1e-13;                 // oracle/conic_ipm.py PIVTOL
-    // W1 layout: [0, np^2) GEMM workspace | np doubles: original diagonal | 64 np doubles: L_kk blocks
-    double* d0 = W1 + (size_t)np * np;
-    double* Dfac = d0 + np;
+    // W1 layout: np doubles: original diagonal | 64 np doubles: L_kk blocks
+    double* d0 = W1;
+    double* Dfac = W1 + np;
     hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
     hipMemsetAsync(flag, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, d0);
+    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, d0, M);
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, st, H, M, np, k, d0, pivtol, Dfac, flag);
-        int nrem = nblk - k - 1;
-        if (nrem > 0)
-            hipLaunchKernelGGL(k_chol_trail, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, st, H, np, k);
+        const int npanel = nblk - k, nrem = nblk - k - 1;
+        hipLaunchKernelGGL(k_chol_stepA, dim3(npanel + npanel * k), dim3(256), 0, st, H, M, np, nblk, k, d0, pivtol, Dfac, flag);
+        hipLaunchKernelGGL(k_chol_stepB, dim3(nrem * (nrem + 1) / 2 + k + 1), dim3(256), 0, st, H, M, np, nblk, k, Dfac);
     }
-    hipLaunchKernelGGL(k_finish_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, Dfac);
-    for (int u = CB; u < np; u *= 2) {
-        int pairs = cdiv(np, 2 * u);
-        dim3 grid(u / CB, u / CB, pairs);
-        hipLaunchKernelGGL(k_inv_gemm, grid, dim3(256), 0, st, H, M, W1, np, u, 0);
-        hipLaunchKernelGGL(k_inv_gemm, grid, dim3(256), 0, st, H, M, W1, np, u, 1);
-    }
-    if (Lcopy) hipMemcpyAsync(Lcopy, H, sizeof(double) * np * np, hipMemcpyDeviceToDevice, st);
-    // One Newton step  M <- M + M (I - L M): the recursive-doubling products lose ~30x accuracy
-    // against a substitution-based inverse on the ill-conditioned late IPM factors; the correction
-    // restores it (measured: solve residual 6.5e-4 -> 2.5e-5 at cond(H) = 3e9, same as LAPACK trtri).
-    hipMemsetAsync(W1, 0, sizeof(double) * np * np, st);
-    hipLaunchKernelGGL(k_tri_gemm, dim3(nblk, nblk), dim3(256), 0, st, H, M, W1, np, 0);     // E = I - L M
-    hipMemsetAsync(H, 0, sizeof(double) * np * np, st);
-    hipLaunchKernelGGL(k_tri_gemm, dim3(nblk, nblk), dim3(256), 0, st, M, W1, H, np, 1);     // H <- M + M E
-    hipMemcpyAsync(M, H, sizeof(double) * np * np, hipMemcpyDeviceToDevice, st);
+    if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, Dfac, Lcopy);
     hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32), dim3(32, 8), 0, st, M, Mt, np);
 }
 

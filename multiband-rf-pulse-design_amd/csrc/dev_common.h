@@ -78,12 +78,12 @@ struct GramPlan {
 GramPlan gram_plan(int Mf, int Nt, int nw);
 // T[w] (ld x ld, full symmetric) = A' diag(d[w]) A ; A is Mpad x ld row-major, d is nw x Mpad.
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
-                 const int* tile_ij, hipStream_t st);
+                 const int* tile_ij, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 
 // Cholesky + inverse of the Cholesky factor.  H is np x np row-major (np multiple of 64), lower
-// triangle referenced; on exit M = L^-1 (lower, one Newton correction applied), Mt = M'.
-// W1 is a workspace of np*np + 65*np doubles.  flag[0] counts replaced (noise-level) pivots.
+// triangle referenced; on exit M = L^-1 (lower), Mt = M'.
+// W1 is a workspace of 65*np doubles.  flag[0] counts replaced (noise-level) pivots.
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
                      double* Lcopy = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 

@@ -13,13 +13,14 @@ struct SolveOpts {
     double feastol = 1e-8, abstol = 1e-10, reltol = 1e-8;
     int refine = 2;
     int verbose = 0;
-    bool timing = true;     // HIP-event timing of the Gram / Cholesky phases (adds two event syncs per iteration)
+    bool timing = true;     // HIP-event timing of the k_gram launches and the Cholesky phase (events read at the end)
 };
 
 struct SolveInfo {
     int status = 0, iters = 0, n_unknowns = 0, n_rows = 0, n_freq = 0;
     double pcost = 0, dcost = 0, gap = 0, relgap = 0, pres = 0, dres = 0;
     double ms_assemble = 0, ms_solve = 0, ms_gram = 0, ms_chol = 0, gram_flop = 0;
+    int h_builds = 0;       // number of (Gram, Cholesky) builds = iterations + 1 (initial point)
 };
 
 class Solver {

@@ -33,7 +33,8 @@ enum {
     S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
     S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
     S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
-    S_RNA = 40 /* 8 sweep norms, batch solve */, S_RNB = 48 /* 8 sweep norms, combined solve */, S_COUNT = 64
+    S_RNA = 40 /* 8 sweep norms, batch solve */, S_RNB = 48 /* 8 sweep norms, combined solve */,
+    S_CG_RZ = 56 /* 2 */, S_CG_ALPHA = 58 /* 2 */, S_CG_BETA = 60 /* 2 */, S_COUNT = 64
 };
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
@@ -188,23 +189,25 @@ __global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, 
     }
 }
 
-// K3 step 3: fold the split partials, apply the quadrature permutation, add identity rows.
+// K3 step 3a: fold the split partials: TT[v][j] = sum_s partial[s][v][j]   (grid: columns x vectors)
+__global__ void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld, int ldo,
+                                double* __restrict__ TT) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (j >= ld) return;
+    double t = 0;
+    for (int s = 0; s < nsplit; ++s) t += partial[((long)s * nvv + v) * ld + j];
+    TT[(long)v * ldo + j] = t;
+}
+// K3 step 3b: apply the quadrature permutation and add the identity rows.
 template <int NV>
-__global__ void k_gt_combine(DProg P, const double* __restrict__ partial, int nsplit,
-                             const double* __restrict__ val, double* __restrict__ out) {
+__global__ void k_gt_combine(DProg P, const double* __restrict__ TT, const double* __restrict__ val,
+                             double* __restrict__ out) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
-    const int NVV = P.quad ? 2 * NV : NV;
-    const int pj = P.quad ? P.pcol[j] : 0;
-    const double sj = P.quad ? P.psign[j] : 0.0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        double t1 = 0, t2 = 0;
-        for (int s = 0; s < nsplit; ++s) {
-            t1 += partial[((long)s * NVV + v) * P.ld + j];
-            if (P.quad) t2 += partial[((long)s * NVV + NV + v) * P.ld + pj];
-        }
-        double g = t1 + sj * t2;
+        double g = TT[(long)v * P.LDV + j];
+        if (P.quad) g += P.psign[j] * TT[(long)(NV + v) * P.LDV + P.pcol[j]];
         for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
             int r = P.c_rows[q];
             g += P.alpha[r] * val[(long)v * P.Rp + r];
@@ -517,6 +520,79 @@ __global__ void k_axpy_n(DProg P, const double* __restrict__ a, double* __restri
     if (j >= P.N) return;
 #pragma unroll
     for (int v = 0; v < NV; ++v) out[(long)v * P.LDV + j] += a[(long)v * P.LDV + j];
+}
+
+// ---- preconditioned conjugate gradients on (G' W^-2 G) dx = rhs (refinement of the KKT solve) ----
+template <int NV>
+__global__ __launch_bounds__(256) void k_dot_nn(DProg P, const double* __restrict__ a, const double* __restrict__ b,
+                                                double* __restrict__ part) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = (j < P.N) ? a[(long)q * P.LDV + j] * b[(long)q * P.LDV + j] : 0.0;
+    block_partials<NV>(v, part, false);
+}
+// mode 0: rz = sum, beta = 0 ; mode 1: alpha = rz / sum (0 when sum <= 0) ; mode 2: beta = sum / rz, rz = sum
+__global__ __launch_bounds__(256) void k_scal_cg(double* __restrict__ Sc, const double* __restrict__ part, int nb, int nv, int mode) {
+    __shared__ double sh[17];
+    for (int v = 0; v < nv; ++v) {
+        double t = fold_partials(part, nb, nv, v, false, sh);
+        if (threadIdx.x == 0) {
+            if (mode == 0) { Sc[S_CG_RZ + v] = t; Sc[S_CG_BETA + v] = 0.0; }
+            else if (mode == 1) Sc[S_CG_ALPHA + v] = t > 0 ? Sc[S_CG_RZ + v] / t : 0.0;
+            else {
+                double rz = Sc[S_CG_RZ + v];
+                Sc[S_CG_BETA + v] = rz > 0 ? t / rz : 0.0;
+                Sc[S_CG_RZ + v] = t;
+            }
+        }
+    }
+}
+// dx += alpha p ; r -= alpha Hp ; partial ||r||^2
+template <int NV>
+__global__ __launch_bounds__(256) void k_cg_update_n(DProg P, const double* __restrict__ Sc, const double* __restrict__ p,
+                                                     const double* __restrict__ Hp, double* __restrict__ dx,
+                                                     double* __restrict__ r, double* __restrict__ part) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        v[q] = 0;
+        if (j < P.N) {
+            long o = (long)q * P.LDV + j;
+            double al = Sc[S_CG_ALPHA + q];
+            dx[o] += al * p[o];
+            double rr = r[o] - al * Hp[o];
+            r[o] = rr;
+            v[q] = rr * rr;
+        }
+    }
+    block_partials<NV>(v, part, false);
+}
+// gdx += alpha Gp ; dz += alpha Wp
+template <int NV>
+__global__ void k_cg_update_r(DProg P, const double* __restrict__ Sc, const double* __restrict__ Gp,
+                              const double* __restrict__ Wp, double* __restrict__ gdx, double* __restrict__ dz) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.R) return;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        long o = (long)q * P.Rp + t;
+        double al = Sc[S_CG_ALPHA + q];
+        gdx[o] += al * Gp[o];
+        dz[o] += al * Wp[o];
+    }
+}
+// p = z + beta p
+template <int NV>
+__global__ void k_cg_p(DProg P, const double* __restrict__ Sc, const double* __restrict__ z, double* __restrict__ p) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.N) return;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        long o = (long)q * P.LDV + j;
+        p[o] = z[o] + Sc[S_CG_BETA + q] * p[o];
+    }
 }
 
 // dots needed for dtau: c'x1, c'x2 (N space) ; h'z1, h'z2, ||W z1||^2 (R space)
@@ -1020,8 +1096,8 @@ struct Solver::Impl {
     double *A1, *T, *slab, *H, *M, *Mt, *W1, *Sc;
     int *tile_ij, *flag;
     double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
-    double *XX, *UU, *PP, *partial, *TT, *Dw, *BB, *qv;
-    double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz;
+    double *XX, *UU, *PP, *partial, *TT, *TT2, *Dw, *BB, *qv;
+    double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
     double *partR, *partN, *xout, *hout, *sfwork;
@@ -1073,7 +1149,8 @@ struct Solver::Impl {
         const int NVV = P.quad ? 2 * NV : NV;
         hipLaunchKernelGGL(k_freq_agg<NV>, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, val, PP);
         atmulti(NVV, PP);
-        hipLaunchKernelGGL(k_gt_combine<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, partial, nsplit_at, val, out);
+        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), NVV), dim3(64), 0, st, partial, nsplit_at, NVV, P.ld, P.LDV, TT2);
+        hipLaunchKernelGGL(k_gt_combine<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, TT2, val, out);
         if (P.Ne > 0) hipLaunchKernelGGL(k_gt_y<NV>, dim3(1), dim3(256), 0, st, P, val, out);
     }
     template <int NV>
@@ -1086,39 +1163,61 @@ struct Solver::Impl {
         trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st);
         trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
     }
-    // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  `nsweep` refinement sweeps on the dual
-    // equation; the residual norm measured before sweep k goes to Sc[slot + k].
+    // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  The Cholesky solve is refined by `nsweep`
+    // iterations of preconditioned CG on (G' W^-2 G) dx = rhs with the operator applied exactly
+    // through G (K1 + K3 passes) and M'M as preconditioner; dz and gdx are carried along, so the
+    // dual equation G'dz = bx ends at the CG residual.  The residual norm measured before
+    // iteration k goes to Sc[slot + k] (sweep controller).  Mirrors oracle/conic_ipm.py kkt_solve.
     template <int NV>
     void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot) {
+        const dim3 gN(nbN), gR(cdiv(P.R, 256)), b256(256);
         winv2<NV>(bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
-        hipLaunchKernelGGL(k_add_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, bx, tmpN, 1.0, rhsN);
+        hipLaunchKernelGGL(k_add_n<NV>, gN, b256, 0, st, P, bx, tmpN, 1.0, rhsN);
         hsolve<NV>(rhsN, dx);
         apply_G<NV>(dx, gdx);
         winv2<NV>(gdx, wbz, dz, 0);
+        if (nsweep <= 0) return;
+        double* r = rhsN;
+        apply_GT<NV>(dz, tmpN);
+        hipLaunchKernelGGL(k_resid_n<NV>, gN, b256, 0, st, P, bx, tmpN, r, partN);         // r = bx - G'dz, ||r||^2
+        hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
-            apply_GT<NV>(dz, tmpN);
-            hipLaunchKernelGGL(k_resid_n<NV>, dim3(nbN), dim3(256), 0, st, P, bx, tmpN, rhsN, partN);
-            if (it < MAX_SWEEPS) hipLaunchKernelGGL(k_scal_rnorm, dim3(1), dim3(256), 0, st, Sc, partN, nbN, NV, slot + it);
-            hsolve<NV>(rhsN, tmpN2);
-            hipLaunchKernelGGL(k_axpy_n<NV>, dim3(cdiv(P.N, 256)), dim3(256), 0, st, P, tmpN2, dx);
-            apply_G<NV>(tmpN2, tmpR);
-            hipLaunchKernelGGL(k_axpy_r<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, tmpR, gdx);
-            winv2<NV>(tmpR, nullptr, dz, 1);
+            if (it < MAX_SWEEPS) hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot + it);
+            hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, r, tmpN2, partN);          // r'z
+            hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, it == 0 ? 0 : 2);
+            hipLaunchKernelGGL(k_cg_p<NV>, gN, b256, 0, st, P, Sc, tmpN2, pN);              // p = z + beta p
+            apply_G<NV>(pN, tmpR);                                                          // G p
+            winv2<NV>(tmpR, nullptr, wpR, 0);                                               // W^-2 G p
+            apply_GT<NV>(wpR, tmpN);                                                        // H p
+            hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, pN, tmpN, partN);          // p'Hp
+            hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, 1);     // alpha
+            hipLaunchKernelGGL(k_cg_update_n<NV>, gN, b256, 0, st, P, Sc, pN, tmpN, dx, r, partN);
+            hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
+            if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
         }
     }
-    // H = G' W^-2 G from the current scaling, then Cholesky + inverse
-    float gram_ms = 0, chol_ms = 0;
+    // H = G' W^-2 G from the current scaling, then Cholesky + inverse.  Timing events are pooled
+    // and read once at the end of the solve, so measuring does not serialise the host.
     bool timing = true;
+    std::vector<hipEvent_t> evpool;
+    size_t evused = 0;
+    hipEvent_t next_event() {
+        if (evused == evpool.size()) {
+            hipEvent_t e;
+            MBFIR_HIP(hipEventCreate(&e));
+            evpool.push_back(e);
+        }
+        return evpool[evused++];
+    }
     void build_H() {
         hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dl, w3, Dw, BB);
-        if (timing) hipEventRecord(ev0, st);
-        gram_launch(gp, A1, Dw, slab, T, tile_ij, st);
-        if (timing) { hipEventRecord(ev1, st); }
+        hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
+        gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti(nvv, BB);
-            hipLaunchKernelGGL(k_fold_tt, dim3(cdiv(P.ld, 256), nvv), dim3(256), 0, st, P, partial, nsplit_at, nvv, TT);
+            hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
         }
         hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H);
         hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
@@ -1128,10 +1227,21 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
             hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
         }
-        float g = 0;
-        if (timing) { hipEventSynchronize(ev1); hipEventElapsedTime(&g, ev0, ev1); gram_ms += g; hipEventRecord(ev0, st); }
+        hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
+        if (c0) hipEventRecord(c0, st);
         chol_inv_launch(H, M, Mt, W1, P.np, flag, st);
-        if (timing) { hipEventRecord(ev1, st); hipEventSynchronize(ev1); hipEventElapsedTime(&g, ev0, ev1); chol_ms += g; }
+        if (c1) hipEventRecord(c1, st);
+    }
+    // events are recorded as (gram begin, gram end, chol begin, chol end) per build_H
+    void collect_times(double& gram_ms, double& chol_ms, int& builds) {
+        gram_ms = chol_ms = 0;
+        builds = int(evused / 4);
+        for (size_t i = 0; i + 3 < evused; i += 4) {
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, evpool[i], evpool[i + 1]);
+            hipEventElapsedTime(&b, evpool[i + 2], evpool[i + 3]);
+            gram_ms += a; chol_ms += b;
+        }
     }
 };
 
@@ -1152,6 +1262,7 @@ Solver::~Solver() {
     if (impl->ar.base) hipFree(impl->ar.base);
     if (impl->hostSc) hipHostFree(impl->hostSc);
     if (impl->hostFlag) hipHostFree(impl->hostFlag);
+    for (hipEvent_t e : impl->evpool) hipEventDestroy(e);
     if (impl->ev0) hipEventDestroy(impl->ev0);
     if (impl->ev1) hipEventDestroy(impl->ev1);
     if (impl->st) hipStreamDestroy(impl->st);
@@ -1226,13 +1337,13 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
-    S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
+    S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.pN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
     S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV);
     S.bxc = ar.get<double>(LDV); S.dxc = ar.get<double>(LDV); S.qv = ar.get<double>(2 * LDV);
-    S.XX = ar.get<double>(4 * LDV); S.TT = ar.get<double>(6 * LDV); S.xout = ar.get<double>(LDV);
+    S.XX = ar.get<double>(4 * LDV); S.TT = ar.get<double>(6 * LDV); S.TT2 = ar.get<double>(4 * LDV); S.xout = ar.get<double>(LDV);
     S.s = ar.get<double>(Rp); S.z = ar.get<double>(Rp); S.lam = ar.get<double>(Rp); S.dl = ar.get<double>(Rp);
     S.wl = ar.get<double>(Rp); S.w3 = ar.get<double>(4 * (size_t)std::max(P.nq3, 1)); S.wbb = ar.get<double>(std::max(P.big, 1));
-    S.tmpR = ar.get<double>(2 * Rp); S.wbz = ar.get<double>(2 * Rp); S.bz2 = ar.get<double>(2 * Rp); S.dz2 = ar.get<double>(2 * Rp);
+    S.tmpR = ar.get<double>(2 * Rp); S.wbz = ar.get<double>(2 * Rp); S.wpR = ar.get<double>(2 * Rp); S.bz2 = ar.get<double>(2 * Rp); S.dz2 = ar.get<double>(2 * Rp);
     S.gdx2 = ar.get<double>(2 * Rp); S.gdxc = ar.get<double>(Rp); S.xbest = ar.get<double>(LDV);
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
@@ -1257,7 +1368,7 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     hipLaunchKernelGGL(k_norms_hc, dim3(1), dim3(256), 0, st, P, S.Sc);
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_assembled = now_ms();
-    S.gram_ms = S.chol_ms = 0;
+    S.evused = 0;
     S.timing = o.timing;
 
     const int nbRc = S.nbC + (P.big ? 1 : 0);      // cone-indexed reductions (+1 row for the big cone)
@@ -1324,9 +1435,10 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
         if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { status = ST_PRIMAL_INFEASIBLE; break; }
         if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { status = ST_DUAL_INFEASIBLE; break; }
-        {
-            double merit = std::max(std::max(hs[S_PRES], hs[S_DRES]),
-                                    std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol));
+        if (hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
+            // best iterate for the reduced-accuracy exit: residuals within the reduced tolerance,
+            // smallest gap measure (mirrors oracle/conic_ipm.py)
+            double merit = std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol);
             if (merit < best_merit) {
                 best_merit = merit; best_info = info; have_best = true;
                 hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
@@ -1392,11 +1504,11 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     (void)t_begin;
     info.status = status;
     info.ms_assemble = t_assembled - t_begin;
-    info.ms_gram = S.gram_ms; info.ms_chol = S.chol_ms;
     xout.assign(N, 0.0);
     MBFIR_HIP(hipMemcpyAsync(xout.data(), S.xout, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     MBFIR_HIP(hipStreamSynchronize(st));
     info.ms_solve = now_ms() - t_assembled;
+    S.collect_times(info.ms_gram, info.ms_chol, info.h_builds);
     info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
     info.gram_flop = double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
     return status;

@@ -235,15 +235,16 @@ STATUS_OPTIMAL_INACCURATE = 5
 
 
 PIVTOL = 1e-13
-PIVBIG = 1e128
 CHOL_NB = 64
 
 
 def chol_piv(H):
     """Blocked right-looking Cholesky (64-wide panels, the device kernel's schedule) with
     the interior-point pivot rule: a pivot that is not above PIVTOL * H_jj (i.e. pure
-    rounding noise) is replaced by PIVBIG, which removes that column from the
-    factorisation instead of dividing by noise.  Returns (L, number of replaced pivots)."""
+    rounding noise) is replaced by H_jj itself.  By Cauchy-Schwarz the rest of that column of
+    the Schur complement is then at noise level too, so the column is effectively decoupled
+    and the factor stays a non-singular (CG-usable) preconditioner instead of dividing by
+    noise.  Returns (L, number of replaced pivots)."""
     N = H.shape[0]
     L = np.tril(H).copy()
     d0 = np.diag(H).copy()
@@ -254,7 +255,7 @@ def chol_piv(H):
         for j in range(k1 - k0):
             p = D[j, j]
             if not (p > PIVTOL * d0[k0 + j]):
-                p = PIVBIG
+                p = max(d0[k0 + j], 1e-300)
                 nfix += 1
             r = np.sqrt(p)
             D[j, j] = r
@@ -333,15 +334,34 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         dx = cho_solve(cf, rhs)
         Gdx = G @ dx
         dz = (Wm.inv2(Gdx) if Wm is not None else Gdx) - wbz
+        # Preconditioned conjugate gradients on (G' W^-2 G) dx = rhs with the operator applied
+        # exactly through G (two passes over the rows) and M'M as preconditioner; dz and G dx
+        # are carried along, so the dual equation G'dz = bx ends at the CG residual.
+        vec = bx.ndim == 1
+        col = (lambda v: v[:, None]) if vec else (lambda v: v)
+        r = col(bx - G.T @ dz).copy()
+        DX, DZ, GDX = col(dx).copy(), col(dz).copy(), col(Gdx).copy()
+        z_ = cho_solve(cf, r)
+        p = z_.copy()
+        rz_ = np.sum(r * z_, axis=0)
         norms = []
         for _ in range(nsweep[0]):
-            r = bx - G.T @ dz
             norms.append(float(np.max(np.sqrt(np.sum(r * r, axis=0)))))
-            ddx = cho_solve(cf, r)
-            dx = dx + ddx
-            Gd = G @ ddx
-            Gdx = Gdx + Gd
-            dz = dz + (Wm.inv2(Gd) if Wm is not None else Gd)
+            Gp = G @ p
+            Wp = Wm.inv2(Gp) if Wm is not None else Gp
+            Hp = G.T @ Wp
+            pHp = np.sum(p * Hp, axis=0)
+            alpha_ = np.where(pHp > 0, rz_ / np.where(pHp > 0, pHp, 1.0), 0.0)
+            DX += alpha_ * p
+            GDX += alpha_ * Gp
+            DZ += alpha_ * Wp
+            r -= alpha_ * Hp
+            z_ = cho_solve(cf, r)
+            rz_new = np.sum(r * z_, axis=0)
+            beta_ = np.where(rz_ > 0, rz_new / np.where(rz_ > 0, rz_, 1.0), 0.0)
+            p = z_ + beta_ * p
+            rz_ = rz_new
+        dx, dz, Gdx = (DX[:, 0], DZ[:, 0], GDX[:, 0]) if vec else (DX, DZ, GDX)
         sweep_log.append(norms)
         return dx, dz, Gdx
 
@@ -404,10 +424,12 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         if dinfres <= feastol or (collapsed and dinfres <= 1e-5):
             status = STATUS_DUAL_INFEASIBLE
             break
-        # best iterate so far, for the reduced-accuracy exit
-        merit = max(pres, dres, min(relgap, gap / max(abstol, 1e-300) * reltol))
-        if merit < best[0]:
-            best = (merit, x / tau, dict(info))
+        # best iterate so far for the reduced-accuracy exit: among the iterates whose residuals
+        # meet the reduced feasibility tolerance, the one with the smallest gap measure
+        if pres <= INACC_FEAS and dres <= INACC_FEAS:
+            merit = min(relgap, gap / max(abstol, 1e-300) * reltol)
+            if merit < best[0]:
+                best = (merit, x / tau, dict(info))
         if it == max_iter:
             break
         try:

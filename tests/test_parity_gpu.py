@@ -71,7 +71,7 @@ def test_context_reuse_like_a_bisection():
     """fir_ap.m:143-176 calls the designer ~10 times in a row on one context, feasible and not."""
     f, a, d = c13(64)
     ctx = mbfir.Context(0)
-    verdicts = [mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, ctx=ctx)[1] for n in (64, 33, 49, 56, 61, 59, 57)]
+    verdicts = [mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, ctx=ctx)[1] for n in (64, 33, 49, 56, 61, 59, 57)]  # 57 = smallest feasible order
     assert verdicts == ["Solved", "Failed", "Failed", "Failed", "Solved", "Solved", "Solved"]
     ctx.close()
 
