@@ -144,6 +144,9 @@ int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, cons
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m);
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im);
 int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tflops_f64_mfma, double* tflops_f64_valu);
+/* Device time (ms per call, HIP events, averaged over reps) of the Cholesky+inverse phase on a random SPD
+ * n x n matrix, and of the Gram launches on a random m x nt matrix -- kernel tuning aid. */
+int mbfir_test_time_kernels(mbfir_ctx* ctx, int n, int m, int nt, int reps, double* ms_chol, double* ms_gram);
 
 #ifdef __cplusplus
 }

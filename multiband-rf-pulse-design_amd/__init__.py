@@ -87,6 +87,7 @@ SYMBOLS = {
     "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_specfact": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_mfma_peak": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "mbfir_test_time_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
 }
 
 
@@ -351,6 +352,14 @@ def test_specfact(x, n, ctx=None):
     hre, him = np.zeros(n), np.zeros(n)
     _check(ctx, load_library().mbfir_test_specfact(ctx._h, int(n), _ptr(x), _ptr(hre), _ptr(him)))
     return hre + 1j * him
+
+
+def time_kernels(n=1024, m=16394, nt=1023, reps=20, ctx=None):
+    """ms per Cholesky+inverse phase (n x n) and per k_gram launch (m x nt) -- tuning aid."""
+    ctx = ctx or get_context()
+    a, b = C.c_double(), C.c_double()
+    _check(ctx, load_library().mbfir_test_time_kernels(ctx._h, n, m, nt, reps, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def mfma_peak(ctx=None):

@@ -221,4 +221,8 @@ int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tf_mfma, double* tf_valu) {
     MBFIR_TRY(ctx, ctx->solver->test_mfma_peak(tf_mfma, tf_valu));
 }
 
+int mbfir_test_time_kernels(mbfir_ctx* ctx, int n, int m, int nt, int reps, double* ms_chol, double* ms_gram) {
+    MBFIR_TRY(ctx, ctx->solver->test_time_kernels(n, m, nt, reps, ms_chol, ms_gram));
+}
+
 }  // extern "C"

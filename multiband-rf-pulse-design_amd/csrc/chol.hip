@@ -72,22 +72,112 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
 // =================================================================================================
 constexpr int CLDP = 65;     // odd LDS stride: lanes = rows is conflict free
 
-// Forward substitution  S x = a  for one right-hand side per group of 4 adjacent lanes.
-// Lane q (= lane & 3) holds a[t] / x[t] for t = 4*i + q in v[i].  S is lower triangular in LDS.
-__device__ __forceinline__ void subst64(const double (*S)[CLDP], double v[16]) {
-    const int q = threadIdx.x & 3;
-#pragma unroll
+// sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
+__device__ __forceinline__ double quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo1 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    v += __hiloint2double(hi1, lo1);                      // + lane ^ 1
+    lo = __double2loint(v); hi = __double2hiint(v);
+    lo1 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi1 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+    return v + __hiloint2double(hi1, lo1);                // + lane ^ 2
+}
+
+// Column permutation used for the LDS images below: column t is stored at position
+// perm(t) = (t & 3) * 16 + (t >> 2), so the 16 columns {q, q+4, ...} that one lane needs are
+// contiguous (wide LDS reads, no per-element address math).
+__device__ __forceinline__ int cperm(int t) { return (t & 3) * 16 + (t >> 2); }
+constexpr int SLD = 66;      // row stride of the permuted images (16-byte aligned rows)
+constexpr int PANEL_LDS = 2 * CB * SLD + 4 * CB;     // Sp | Xs | dsh | dinv | colbuf(2 x 64)
+
+// NOTE on code shape: these loops are deliberately ROLLED with LDS-resident data.  A fully
+// unrolled register-resident version (64 steps of straight-line code, ~10k instructions executed
+// once) ran 4x slower: it is instruction-fetch bound.
+
+// Forward substitution  S x = a  for 64 right-hand sides, one per group of 4 adjacent lanes
+// (rhs index r = tid >> 2).  Xs[r][q*16 + i] holds a[t] on entry and x[t] on exit for t = 4 i + q;
+// lane q only ever touches its own 16-element segment, so the loop needs no barrier.
+__device__ __forceinline__ void subst64(const double (*Sp)[SLD], const double* dinv, double (*Xs)[SLD]) {
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    double* xrow = &Xs[r][q * 16];
     for (int j = 0; j < CB; ++j) {
-        double part = 0;
-#pragma unroll
-        for (int i = 0; i * 4 < j; ++i) {
-            const int t = i * 4 + q;
-            if (t < j) part += v[i] * S[j][t];
+        const double* srow = &Sp[j][q * 16];
+        const int ni = (j - q + 3) >> 2;                  // number of t = 4 i + q below j
+        double p0 = 0, p1 = 0, p2 = 0, p3 = 0;            // four chains hide the FMA latency
+        int i = 0;
+        for (; i + 4 <= ni; i += 4) {
+            p0 += xrow[i] * srow[i]; p1 += xrow[i + 1] * srow[i + 1];
+            p2 += xrow[i + 2] * srow[i + 2]; p3 += xrow[i + 3] * srow[i + 3];
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        if (q == (j & 3)) v[j >> 2] = (v[j >> 2] - part) / S[j][j];
+        for (; i < ni; ++i) p0 += xrow[i] * srow[i];
+        double part = quad_sum((p0 + p1) + (p2 + p3));
+        if (q == (j & 3)) xrow[j >> 2] = (xrow[j >> 2] - part) * dinv[j];
     }
+}
+
+// Unblocked right-looking Cholesky of the 64x64 block in Sp (column-permuted, LDS).  Thread
+// (tx = tid & 63, ty = tid >> 6) owns the segment Sp[tx][ty*16 .. +16) = columns ty + 4 i of row tx.
+// Column j is broadcast through the double-buffered vector cb, one barrier per step.
+// A dependent fp64 VALU op costs ~40 cycles on gfx950 (measured), so the pivot chain is kept as
+// short as possible: the loop is square-root free (S_ic -= S_ij S_cj / p_j, with 1/p from v_rcp_f64
+// + one Newton step) and the column scaling L_ij = S_ij / sqrt(p_j) is applied in one parallel pass
+// afterwards.  Only the lower triangle of the result is meaningful.
+__device__ __forceinline__ void potf2_lds(double (*Sp)[SLD], double* colbuf, const double* dsh, double* dinv,
+                                          double pivtol, int* flag, bool count) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ptx = cperm(tx);
+    double* seg = &Sp[tx][ty * 16];
+    double* piv = dinv;                                   // pivots first, 1/sqrt(pivot) after the loop
+    for (int j = 0; j < CB; ++j) {
+        double* cb = colbuf + (j & 1) * CB;
+        const int jg = j >> 2, jq = j & 3;
+        if (ty == jq) cb[ptx] = seg[jg];                  // element (tx, j) of the Schur complement
+        __syncthreads();
+        double p = cb[cperm(j)];
+        const double dj = dsh[j];
+        if (!(p > pivtol * dj)) {
+            if (count && threadIdx.x == 0) atomicAdd(flag, 1);
+            p = fmax(dj, 1e-300);
+        }
+        double rcp = __builtin_amdgcn_rcp(p);             // ~26 bits
+        rcp = rcp * fma(-p, rcp, 2.0);                    // 1/p to rounding
+        const double a = cb[ptx] * rcp;
+        const double* mine = cb + ty * 16;                // elements (c, j), c = ty + 4 i
+        const int i0 = ty > jq ? jg : jg + 1;             // columns c = ty + 4 i > j
+        // Three phases (all loads, all FMAs, all stores): interleaving them serialises on LDS latency
+        // because the compiler cannot prove seg and mine disjoint (measured 1290 vs ~300 cycles).
+        // Finished column groups are skipped (wave-uniform tests).
+        double rv[16], cv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (4 * g + 3 >= i0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rv[4 * g + u] = seg[4 * g + u]; cv[4 * g + u] = mine[4 * g + u]; }
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (4 * g + 3 >= i0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rv[4 * g + u] -= (4 * g + u >= i0 ? a : 0.0) * cv[4 * g + u];
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (4 * g + 3 >= i0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) seg[4 * g + u] = rv[4 * g + u];
+            }
+        if (ty == jq && tx == j) { seg[jg] = p; piv[j] = p; }
+    }
+    __syncthreads();
+    if (threadIdx.x < CB) {
+        const double p = piv[threadIdx.x];
+        double y = __builtin_amdgcn_rsq(p);
+        y = y * (1.5 - 0.5 * p * y * y);
+        y = y * (1.5 - 0.5 * p * y * y);
+        dinv[threadIdx.x] = y;                            // 1 / L_jj
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) seg[i] *= dinv[ty + 4 * i];    // L_ij = S_ij / sqrt(p_j)  (L_jj = p_j / sqrt(p_j))
 }
 
 __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
@@ -114,7 +204,7 @@ __device__ __forceinline__ void tile_update(double* smem, const double* __restri
 __global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
                                                     int k, const double* __restrict__ d0, double pivtol,
                                                     double* __restrict__ Dfac, int* __restrict__ flag) {
-    __shared__ double smem[2 * CB * CLD];
+    __shared__ __attribute__((aligned(16))) double smem[PANEL_LDS];
     const int tid = threadIdx.x;
     const int npanel = nblk - k;
     if ((int)blockIdx.x >= npanel) {
@@ -127,52 +217,41 @@ __global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, doub
         return;
     }
     // (a) panel
-    double(*S)[CLDP] = reinterpret_cast<double(*)[CLDP]>(smem);
+    double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
+    double(*Xs)[SLD] = reinterpret_cast<double(*)[SLD]>(smem + CB * SLD);
+    double* dsh = smem + 2 * CB * SLD;                    // original diagonal of this block (64)
+    double* dinv = dsh + CB;                              // 1 / L_jj (64)
+    double* colbuf = dinv + CB;                           // 2 x 64
     const long kk = (long)k * CB;
     for (int e = tid; e < CB * CB; e += 256) {
         int i = e >> 6, j = e & 63;
-        S[i][j] = j <= i ? H[(kk + i) * np + kk + j] : 0.0;
+        Sp[i][cperm(j)] = j <= i ? H[(kk + i) * np + kk + j] : 0.0;
     }
-    const int tx = tid & 63, ty = tid >> 6;
-    for (int j = 0; j < CB; ++j) {
-        __syncthreads();
-        double p = S[j][j];
-        if (!(p > pivtol * d0[kk + j])) {
-            if (tid == 0 && blockIdx.x == 0) atomicAdd(flag, 1);
-            p = fmax(d0[kk + j], 1e-300);
-        }
-        const double pinv = 1.0 / p;
-        const double a = S[tx][j];
-        if (tx > j)
-            for (int c = j + 1 + ty; c <= tx; c += 4) S[tx][c] -= a * (S[c][j] * pinv);
-        __syncthreads();
-        if (ty == 0) {
-            const double r = sqrt(p);
-            if (tx > j) S[tx][j] = a / r;
-            else if (tx == j) S[j][j] = r;
-        }
-    }
+    if (tid < CB) dsh[tid] = d0[kk + tid];
+    __syncthreads();
+    potf2_lds(Sp, colbuf, dsh, dinv, pivtol, flag, blockIdx.x == 0);
     __syncthreads();
     if (blockIdx.x == 0) {
         // L_kk goes to a side buffer: the other blocks of this launch may still be reading A_kk from H
-        for (int e = tid; e < CB * CB; e += 256) Dfac[kk * CB + e] = S[e >> 6][e & 63];
+        for (int e = tid; e < CB * CB; e += 256) {
+            int i = e >> 6, j = e & 63;
+            Dfac[kk * CB + e] = j <= i ? Sp[i][cperm(j)] : 0.0;
+        }
         return;
     }
-    // rows of A_ik: X L_kk' = A_ik  <=>  L_kk x_r' = a_r' ; row r = tid/4, lane q holds columns t = 4i+q
+    // rows of A_ik:  X L_kk' = A_ik  <=>  L_kk x_r' = a_r'   (rhs r = row r of the tile)
     const long ii = (long)(k + blockIdx.x) * CB;
-    const int r = tid >> 2, q = tid & 3;
-    double* row = H + (ii + r) * np + kk;
-    double v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = row[4 * i + q];
-    subst64(S, v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) row[4 * i + q] = v[i];
+    double* tile = H + ii * np + kk;
+    for (int e = tid; e < CB * CB; e += 256) Xs[e >> 6][cperm(e & 63)] = tile[(long)(e >> 6) * np + (e & 63)];
+    __syncthreads();
+    subst64(Sp, dinv, Xs);
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) tile[(long)(e >> 6) * np + (e & 63)] = Xs[e >> 6][cperm(e & 63)];
 }
 
 __global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
                                                     int k, const double* __restrict__ Dfac) {
-    __shared__ double smem[2 * CB * CLD];
+    __shared__ __attribute__((aligned(16))) double smem[PANEL_LDS];
     const int tid = threadIdx.x;
     const int nrem = nblk - k - 1;
     const int ntrail = nrem * (nrem + 1) / 2;
@@ -185,19 +264,22 @@ __global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, doub
         tile_update<true>(smem, H + i0 * np + kk, H + j0 * np + kk, H + i0 * np + j0, np);
         return;
     }
-    // (b) M_kj = L_kk^-1 R_kj : column c = tid/4 of the tile is one right-hand side
+    // (b) M_kj = L_kk^-1 R_kj : column c of the tile is one right-hand side (Xs row c)
     const int j = blockIdx.x - ntrail;
-    double(*S)[CLDP] = reinterpret_cast<double(*)[CLDP]>(smem);
-    for (int e = tid; e < CB * CB; e += 256) S[e >> 6][e & 63] = Dfac[kk * CB + e];
+    double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
+    double(*Xs)[SLD] = reinterpret_cast<double(*)[SLD]>(smem + CB * SLD);
+    double* dinv = smem + 2 * CB * SLD;
+    double* tile = M + kk * np + (long)j * CB;
+    for (int e = tid; e < CB * CB; e += 256) {
+        Sp[e >> 6][cperm(e & 63)] = Dfac[kk * CB + e];
+        Xs[e & 63][cperm(e >> 6)] = tile[(long)(e >> 6) * np + (e & 63)];      // transposed: rhs = column
+    }
     __syncthreads();
-    const int c = tid >> 2, q = tid & 3;
-    double* col = M + kk * np + (long)j * CB + c;
-    double v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = col[(long)(4 * i + q) * np];
-    subst64(S, v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) col[(long)(4 * i + q) * np] = v[i];
+    if (tid < CB) dinv[tid] = 1.0 / Sp[tid][cperm(tid)];
+    __syncthreads();
+    subst64(Sp, dinv, Xs);
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) tile[(long)(e >> 6) * np + (e & 63)] = Xs[e & 63][cperm(e >> 6)];
 }
 
 __global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M) {

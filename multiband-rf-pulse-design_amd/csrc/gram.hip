@@ -144,7 +144,9 @@ GramPlan gram_plan(int Mf, int Nt, int nw) {
     gp.ntile = gp.ld / GT;
     gp.ntiles = gp.ntile * (gp.ntile + 1) / 2;
     int total_chunks = cdiv(Mf, GKB);
-    int want = cdiv(512, gp.ntiles);
+    // two workgroups fit on a CU (74 KB LDS, 196 VGPRs): 512 slots on 256 CUs.  Pick the split so
+    // that ntiles * nsplit fills ONE round of slots -- one workgroup too many doubles the run time.
+    int want = 512 / gp.ntiles;
     gp.nsplit = std::max(1, std::min(want, total_chunks));
     gp.chunks = cdiv(total_chunks, gp.nsplit);
     gp.nsplit = cdiv(total_chunks, gp.chunks);

@@ -38,6 +38,7 @@ public:
     void test_chol(int n, const double* H, double* out_l, double* out_m);
     void test_specfact(int n, const double* x, double* h_re, double* h_im);
     void test_mfma_peak(double* tf_mfma, double* tf_valu);
+    void test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, double* ms_gram);
     void* stream() const;
 
 private:

@@ -33,8 +33,8 @@ enum {
     S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
     S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
     S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
-    S_RNA = 40 /* 8 sweep norms, batch solve */, S_RNB = 48 /* 8 sweep norms, combined solve */,
-    S_CG_RZ = 56 /* 2 */, S_CG_ALPHA = 58 /* 2 */, S_CG_BETA = 60 /* 2 */, S_COUNT = 64
+    S_RNA = 40 /* 9 residual norms, batch solve */, S_RNB = 49 /* 9 residual norms, combined solve */,
+    S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */, S_COUNT = 64
 };
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
@@ -189,14 +189,23 @@ __global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, 
     }
 }
 
-// K3 step 3a: fold the split partials: TT[v][j] = sum_s partial[s][v][j]   (grid: columns x vectors)
-__global__ void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld, int ldo,
-                                double* __restrict__ TT) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
-    if (j >= ld) return;
+// K3 step 3a: fold the split partials: TT[v][j] = sum_s partial[s][v][j].  Block = 64 columns x 16
+// split groups; each thread adds its strided splits, a fixed-order LDS pass adds the 16 groups.
+__global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld,
+                                                        int ldo, double* __restrict__ TT) {
+    __shared__ double sh[16][65];
+    const int c = threadIdx.x, sg = threadIdx.y, j = blockIdx.x * 64 + c, v = blockIdx.y;
     double t = 0;
-    for (int s = 0; s < nsplit; ++s) t += partial[((long)s * nvv + v) * ld + j];
-    TT[(long)v * ldo + j] = t;
+    if (j < ld)
+        for (int s = sg; s < nsplit; s += 16) t += partial[((long)s * nvv + v) * ld + j];
+    sh[sg][c] = t;
+    __syncthreads();
+    if (sg == 0 && j < ld) {
+        double a = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += sh[q][c];
+        TT[(long)v * ldo + j] = a;
+    }
 }
 // K3 step 3b: apply the quadrature permutation and add the identity rows.
 template <int NV>
@@ -1149,7 +1158,7 @@ struct Solver::Impl {
         const int NVV = P.quad ? 2 * NV : NV;
         hipLaunchKernelGGL(k_freq_agg<NV>, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, val, PP);
         atmulti(NVV, PP);
-        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), NVV), dim3(64), 0, st, partial, nsplit_at, NVV, P.ld, P.LDV, TT2);
+        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), NVV), dim3(64, 16), 0, st, partial, nsplit_at, NVV, P.ld, P.LDV, TT2);
         hipLaunchKernelGGL(k_gt_combine<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, TT2, val, out);
         if (P.Ne > 0) hipLaunchKernelGGL(k_gt_y<NV>, dim3(1), dim3(256), 0, st, P, val, out);
     }
@@ -1166,8 +1175,8 @@ struct Solver::Impl {
     // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  The Cholesky solve is refined by `nsweep`
     // iterations of preconditioned CG on (G' W^-2 G) dx = rhs with the operator applied exactly
     // through G (K1 + K3 passes) and M'M as preconditioner; dz and gdx are carried along, so the
-    // dual equation G'dz = bx ends at the CG residual.  The residual norm measured before
-    // iteration k goes to Sc[slot + k] (sweep controller).  Mirrors oracle/conic_ipm.py kkt_solve.
+    // dual equation G'dz = bx ends at the CG residual.  Residual norms n_0 (after the Cholesky solve)
+    // .. n_nsweep go to Sc[slot ..] for the sweep controller.  Mirrors oracle/conic_ipm.py kkt_solve.
     template <int NV>
     void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot) {
         const dim3 gN(nbN), gR(cdiv(P.R, 256)), b256(256);
@@ -1177,13 +1186,13 @@ struct Solver::Impl {
         hsolve<NV>(rhsN, dx);
         apply_G<NV>(dx, gdx);
         winv2<NV>(gdx, wbz, dz, 0);
-        if (nsweep <= 0) return;
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
         hipLaunchKernelGGL(k_resid_n<NV>, gN, b256, 0, st, P, bx, tmpN, r, partN);         // r = bx - G'dz, ||r||^2
+        hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot);   // n_0
+        if (nsweep <= 0) return;
         hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
-            if (it < MAX_SWEEPS) hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot + it);
             hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, r, tmpN2, partN);          // r'z
             hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, it == 0 ? 0 : 2);
             hipLaunchKernelGGL(k_cg_p<NV>, gN, b256, 0, st, P, Sc, tmpN2, pN);              // p = z + beta p
@@ -1193,6 +1202,7 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, pN, tmpN, partN);          // p'Hp
             hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, 1);     // alpha
             hipLaunchKernelGGL(k_cg_update_n<NV>, gN, b256, 0, st, P, Sc, pN, tmpN, dx, r, partN);
+            hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot + it + 1);   // n_{it+1}
             hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
             if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
         }
@@ -1217,7 +1227,7 @@ struct Solver::Impl {
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti(nvv, BB);
-            hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
+            hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
         }
         hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H);
         hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
@@ -1413,12 +1423,12 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
             bool unconverged = false;
             for (int slot : {int(S_RNA), int(S_RNB)}) {
                 int k = -1;
-                for (int q = 0; q < std::min(nsweep, MAX_SWEEPS); ++q)
+                for (int q = 0; q <= std::min(nsweep, MAX_SWEEPS); ++q)      // n_0 .. n_nsweep
                     if (hs[slot + q] <= tol) { k = q; break; }
                 if (k < 0) unconverged = true;
                 else need = std::max(need, k);
             }
-            nsweep = unconverged ? std::min(MAX_SWEEPS, nsweep + 1) : std::max(1, need);
+            nsweep = unconverged ? std::min(MAX_SWEEPS, nsweep + 1) : need;
         }
         info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
         info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
@@ -1644,6 +1654,50 @@ void Solver::test_mfma_peak(double* tf_mfma, double* tf_valu) {
         hipEventElapsedTime(&ms, S.ev0, S.ev1);
     }
     *tf_valu = double(blocks) * 256 * iters * 16 * 2.0 / (ms * 1e-3) / 1e12;
+    MBFIR_HIP(hipGetLastError());
+}
+
+__global__ void k_fill_spd(double* H, int np, int n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)np * np) return;
+    long i = e / np, j = e - i * np;
+    double v = 0;
+    if (i < n && j < n) v = 1.0 / (1.0 + double(i > j ? i - j : j - i)) + (i == j ? 2.0 : 0.0);   // SPD (diagonally dominant-ish)
+    else if (i == j) v = 1.0;
+    H[e] = v;
+}
+void Solver::test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, double* ms_gram) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const size_t np = round_up(n, 64);
+    DevBuf dH(np * np * 8), dH0(np * np * 8), dM(np * np * 8), dMt(np * np * 8), dW((np * np + 65 * np) * 8), df(16);
+    hipLaunchKernelGGL(k_fill_spd, dim3(cdiv((long)np * np, 256)), dim3(256), 0, S.st, dH0.as<double>(), int(np), n);
+    float ms = 0, tot = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        MBFIR_HIP(hipMemcpyAsync(dH.p, dH0.p, np * np * 8, hipMemcpyDeviceToDevice, S.st));
+        hipEventRecord(S.ev0, S.st);
+        chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st);
+        hipEventRecord(S.ev1, S.st);
+        MBFIR_HIP(hipEventSynchronize(S.ev1));
+        hipEventElapsedTime(&ms, S.ev0, S.ev1);
+        if (r > 0) tot += ms;
+    }
+    *ms_chol = tot / reps;
+    GramPlan gp = gram_plan(m, nt, 1);
+    DevBuf dA((size_t)gp.Mpad * gp.ld * 8), dd((size_t)gp.Mpad * 8), dslab(gp.slab_doubles * 8), dT((size_t)gp.ld * gp.ld * 8), dt(2 * gp.ntiles * 4);
+    MBFIR_HIP(hipMemsetAsync(dA.p, 0x3c, (size_t)gp.Mpad * gp.ld * 8, S.st));      // arbitrary finite doubles
+    MBFIR_HIP(hipMemsetAsync(dd.p, 0x3c, (size_t)gp.Mpad * 8, S.st));
+    std::vector<int> tiles(2 * gp.ntiles);
+    gram_tiles_host(gp, tiles.data());
+    MBFIR_HIP(hipMemcpyAsync(dt.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, S.st));
+    tot = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        gram_launch(gp, dA.as<double>(), dd.as<double>(), dslab.as<double>(), dT.as<double>(), dt.as<int>(), S.st, S.ev0, S.ev1);
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+        hipEventElapsedTime(&ms, S.ev0, S.ev1);
+        if (r > 0) tot += ms;
+    }
+    *ms_gram = tot / reps;
     MBFIR_HIP(hipGetLastError());
 }
 

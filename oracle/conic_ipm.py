@@ -273,17 +273,18 @@ def chol_piv(H):
 
 
 def next_sweeps(norm_lists, nsweep, tol):
-    """Refinement-sweep controller shared with the device solver.  norm_lists: for
-    every KKT solve of the iteration the residual norms measured BEFORE each of its
-    `nsweep` sweeps.  If every solve had already converged before sweep k the next
-    iteration uses max(1, k) sweeps, otherwise one more (at most MAX_SWEEPS)."""
+    """Refinement controller shared with the device solver.  norm_lists: for every KKT
+    solve of the iteration the dual-equation residual norms [n_0 .. n_nsweep] (n_0 after the
+    Cholesky solve, n_k after CG iteration k).  If every solve reached `tol` after k
+    iterations the next IPM iteration runs k of them (possibly none), otherwise one more
+    (at most MAX_SWEEPS)."""
     need = 0
     for norms in norm_lists:
         k = next((i for i, v in enumerate(norms) if v <= tol), None)
         if k is None:
             return min(MAX_SWEEPS, nsweep + 1)
         need = max(need, k)
-    return max(1, need)
+    return need
 
 
 def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
@@ -344,9 +345,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         z_ = cho_solve(cf, r)
         p = z_.copy()
         rz_ = np.sum(r * z_, axis=0)
-        norms = []
+        norms = [float(np.max(np.sqrt(np.sum(r * r, axis=0))))]
         for _ in range(nsweep[0]):
-            norms.append(float(np.max(np.sqrt(np.sum(r * r, axis=0)))))
             Gp = G @ p
             Wp = Wm.inv2(Gp) if Wm is not None else Gp
             Hp = G.T @ Wp
@@ -356,6 +356,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             GDX += alpha_ * Gp
             DZ += alpha_ * Wp
             r -= alpha_ * Hp
+            norms.append(float(np.max(np.sqrt(np.sum(r * r, axis=0)))))
             z_ = cho_solve(cf, r)
             rz_new = np.sum(r * z_, axis=0)
             beta_ = np.where(rz_ > 0, rz_new / np.where(rz_ > 0, rz_, 1.0), 0.0)
