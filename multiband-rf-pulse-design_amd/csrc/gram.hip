@@ -43,37 +43,47 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int 
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[w][a][b] = (v4d){0, 0, 0, 0};
 
-    double2 ra[4], rb[4];
+    // Staging registers for the next chunk (explicit scalars + macros: lambdas capturing the arrays
+    // by reference kept them in scratch memory -- 144 B/lane, 1 GB of spill traffic per launch).
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     double rd = 0;
-    auto gload = [&](int c) {
-        const long kb = k0 + (long)c * GKB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = tid + 256 * q;
-            int row = idx >> 6, c2 = idx & 63;
-            const double* p = A + (kb + row) * ld;
-            ra[q] = *reinterpret_cast<const double2*>(p + I0 + 2 * c2);
-            if (!diag) rb[q] = *reinterpret_cast<const double2*>(p + J0 + 2 * c2);
-        }
-        if (tid < NW * GKB) rd = d[(long)(tid / GKB) * Mpad + kb + (tid % GKB)];
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int idx = tid + 256 * q;
-            int row = idx >> 6, c2 = idx & 63;
-            *reinterpret_cast<double2*>(&As[buf][row][2 * c2]) = ra[q];
-            if (!diag) *reinterpret_cast<double2*>(&Bs[buf][row][2 * c2]) = rb[q];
-        }
-        if (tid < NW * GKB) Ds[buf][tid / GKB][tid % GKB] = rd;
-    };
+    const int lrow = tid >> 6, lc2 = tid & 63;          // this thread loads rows lrow + 4 q, columns 2 lc2..+1
+#define GRAM_GLOAD(c)                                                                              \
+    {                                                                                              \
+        const double* p_ = A + (k0 + (long)(c) * GKB + lrow) * ld + 2 * lc2;                       \
+        ra0 = *reinterpret_cast<const double2*>(p_ + I0);                                          \
+        ra1 = *reinterpret_cast<const double2*>(p_ + 4L * ld + I0);                                \
+        ra2 = *reinterpret_cast<const double2*>(p_ + 8L * ld + I0);                                \
+        ra3 = *reinterpret_cast<const double2*>(p_ + 12L * ld + I0);                               \
+        if (!diag) {                                                                               \
+            rb0 = *reinterpret_cast<const double2*>(p_ + J0);                                      \
+            rb1 = *reinterpret_cast<const double2*>(p_ + 4L * ld + J0);                            \
+            rb2 = *reinterpret_cast<const double2*>(p_ + 8L * ld + J0);                            \
+            rb3 = *reinterpret_cast<const double2*>(p_ + 12L * ld + J0);                           \
+        }                                                                                          \
+        if (tid < NW * GKB) rd = d[(long)(tid / GKB) * Mpad + k0 + (long)(c) * GKB + (tid % GKB)]; \
+    }
+#define GRAM_SSTORE(buf)                                                                           \
+    {                                                                                              \
+        *reinterpret_cast<double2*>(&As[buf][lrow][2 * lc2]) = ra0;                                \
+        *reinterpret_cast<double2*>(&As[buf][lrow + 4][2 * lc2]) = ra1;                            \
+        *reinterpret_cast<double2*>(&As[buf][lrow + 8][2 * lc2]) = ra2;                            \
+        *reinterpret_cast<double2*>(&As[buf][lrow + 12][2 * lc2]) = ra3;                           \
+        if (!diag) {                                                                               \
+            *reinterpret_cast<double2*>(&Bs[buf][lrow][2 * lc2]) = rb0;                            \
+            *reinterpret_cast<double2*>(&Bs[buf][lrow + 4][2 * lc2]) = rb1;                        \
+            *reinterpret_cast<double2*>(&Bs[buf][lrow + 8][2 * lc2]) = rb2;                        \
+            *reinterpret_cast<double2*>(&Bs[buf][lrow + 12][2 * lc2]) = rb3;                       \
+        }                                                                                          \
+        if (tid < NW * GKB) Ds[buf][tid / GKB][tid % GKB] = rd;                                    \
+    }
 
-    gload(0);
-    sstore(0);
+    GRAM_GLOAD(0)
+    GRAM_SSTORE(0)
     __syncthreads();
     for (int c = 0; c < chunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < chunks) gload(c + 1);
+        if (c + 1 < chunks) GRAM_GLOAD(c + 1)
         const double(*Bsrc)[GLDP] = diag ? As[buf] : Bs[buf];
 #pragma unroll
         for (int kk = 0; kk < GKB / 4; ++kk) {
@@ -95,9 +105,11 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int 
                         acc[w][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bw, acc[w][a][b], 0, 0, 0);
                 }
         }
-        if (c + 1 < chunks) sstore(buf ^ 1);
+        if (c + 1 < chunks) GRAM_SSTORE(buf ^ 1)
         __syncthreads();
     }
+#undef GRAM_GLOAD
+#undef GRAM_SSTORE
     // D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
 #pragma unroll
     for (int w = 0; w < NW; ++w) {

@@ -1635,7 +1635,7 @@ void Solver::test_mfma_peak(double* tf_mfma, double* tf_valu) {
     MBFIR_HIP(hipSetDevice(S.device));
     hipDeviceProp_t prop;
     MBFIR_HIP(hipGetDeviceProperties(&prop, S.device));
-    const int blocks = prop.multiProcessorCount * 2, iters = 20000;
+    const int blocks = prop.multiProcessorCount * 4, iters = 20000;      // 4 waves per SIMD
     DevBuf dout((size_t)blocks * 256 * 8);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
