@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
 // Cauchy-Schwarz the rest of that Schur-complement column is at noise level too, so the column is
 // effectively decoupled and M'M stays a non-singular preconditioner (flag counts the replacements).
 // =================================================================================================
-constexpr int CLDP = 65;     // odd LDS stride: lanes = rows is conflict free
+typedef double v16d __attribute__((ext_vector_type(16)));   // register-resident 16-vector (an array would go to scratch)
 
 // sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
 __device__ __forceinline__ double quad_sum(double v) {
@@ -87,97 +87,104 @@ __device__ __forceinline__ double quad_sum(double v) {
 // contiguous (wide LDS reads, no per-element address math).
 __device__ __forceinline__ int cperm(int t) { return (t & 3) * 16 + (t >> 2); }
 constexpr int SLD = 66;      // row stride of the permuted images (16-byte aligned rows)
-constexpr int PANEL_LDS = 2 * CB * SLD + 4 * CB;     // Sp | Xs | dsh | dinv | colbuf(2 x 64)
+constexpr int PANEL_LDS = 2 * CB * CLD;              // Sp | dsh | dinv | colbuf (panel) or two MFMA tiles
 
-// NOTE on code shape: these loops are deliberately ROLLED with LDS-resident data.  A fully
-// unrolled register-resident version (64 steps of straight-line code, ~10k instructions executed
-// once) ran 4x slower: it is instruction-fetch bound.
+// NOTE on code shape (all measured on MI355X with tools/exp/chol_exp.hip):
+//  * a dependent fp64 VALU op costs ~40 cycles, an LDS round trip ~130, so the per-pivot chain is
+//    what matters; a read-modify-write loop over LDS serialises on that latency because the
+//    compiler cannot prove the arrays disjoint;
+//  * fully unrolling the 64 steps (straight-line code executed once, ~10k instructions) is
+//    instruction-fetch bound and 2x slower still;
+//  * so: operands live in registers with static indices, the outer loop over groups of 4 pivots
+//    is rolled, the 4 steps inside are unrolled, and the one register that must be picked by the
+//    loop counter is selected / put back once per group with wave-uniform compares.
+__device__ __forceinline__ double sel16(const v16d& v, int idx) {
+    double r = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = (i == idx) ? v[i] : r;
+    return r;
+}
+__device__ __forceinline__ void put16(v16d& v, int idx, double x) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (i == idx) ? x : v[i];
+}
 
-// Forward substitution  S x = a  for 64 right-hand sides, one per group of 4 adjacent lanes
-// (rhs index r = tid >> 2).  Xs[r][q*16 + i] holds a[t] on entry and x[t] on exit for t = 4 i + q;
-// lane q only ever touches its own 16-element segment, so the loop needs no barrier.
-__device__ __forceinline__ void subst64(const double (*Sp)[SLD], const double* dinv, double (*Xs)[SLD]) {
-    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
-    double* xrow = &Xs[r][q * 16];
-    for (int j = 0; j < CB; ++j) {
-        const double* srow = &Sp[j][q * 16];
-        const int ni = (j - q + 3) >> 2;                  // number of t = 4 i + q below j
-        double p0 = 0, p1 = 0, p2 = 0, p3 = 0;            // four chains hide the FMA latency
-        int i = 0;
-        for (; i + 4 <= ni; i += 4) {
-            p0 += xrow[i] * srow[i]; p1 += xrow[i + 1] * srow[i + 1];
-            p2 += xrow[i + 2] * srow[i + 2]; p3 += xrow[i + 3] * srow[i + 3];
+// Forward substitution  S x = a  for 64 right-hand sides, one per group of 4 adjacent lanes.
+// Lane q (= lane & 3) holds a[t] on entry / x[t] on exit for t = 4 i + q in v[i].
+// Sp is the column-permuted lower-triangular factor in LDS, dinv[j] = 1 / S[j][j].
+// Per group of 4 unknowns: the contribution of all earlier groups ("hist") is formed for the 4 rows
+// at once (64 independent FMAs), then the 4 in-group steps run the short chain
+// term -> quad_sum -> (a - part) * dinv.
+__device__ __forceinline__ void subst64(const double (*Sp)[SLD], const double* dinv, v16d& v) {
+    const int q = threadIdx.x & 3;
+#pragma unroll 1
+    for (int jg = 0; jg < 16; ++jg) {
+        const double acur = sel16(v, jg);                 // a_{4 jg + q}
+        v16d vm;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vm[i] = (i < jg) ? v[i] : 0.0;
+        double hist0 = 0, hist1 = 0, hist2 = 0, hist3 = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const double* srow = &Sp[4 * jg + jj][q * 16];
+            double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                h0 += vm[i] * srow[i]; h1 += vm[i + 1] * srow[i + 1];
+                h2 += vm[i + 2] * srow[i + 2]; h3 += vm[i + 3] * srow[i + 3];
+            }
+            const double hh = (h0 + h1) + (h2 + h3);
+            if (jj == 0) hist0 = hh; else if (jj == 1) hist1 = hh; else if (jj == 2) hist2 = hh; else hist3 = hh;
         }
-        for (; i < ni; ++i) p0 += xrow[i] * srow[i];
-        double part = quad_sum((p0 + p1) + (p2 + p3));
-        if (q == (j & 3)) xrow[j >> 2] = (xrow[j >> 2] - part) * dinv[j];
+        double vn = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * jg + jj;
+            const double term = (q < jj) ? vn * Sp[j][q * 16 + jg] : 0.0;
+            const double hj = jj == 0 ? hist0 : jj == 1 ? hist1 : jj == 2 ? hist2 : hist3;
+            const double part = quad_sum(hj + term);
+            if (q == jj) vn = (acur - part) * dinv[j];
+        }
+        put16(v, jg, vn);
     }
 }
 
-// Unblocked right-looking Cholesky of the 64x64 block in Sp (column-permuted, LDS).  Thread
-// (tx = tid & 63, ty = tid >> 6) owns the segment Sp[tx][ty*16 .. +16) = columns ty + 4 i of row tx.
-// Column j is broadcast through the double-buffered vector cb, one barrier per step.
-// A dependent fp64 VALU op costs ~40 cycles on gfx950 (measured), so the pivot chain is kept as
-// short as possible: the loop is square-root free (S_ic -= S_ij S_cj / p_j, with 1/p from v_rcp_f64
-// + one Newton step) and the column scaling L_ij = S_ij / sqrt(p_j) is applied in one parallel pass
-// afterwards.  Only the lower triangle of the result is meaningful.
-__device__ __forceinline__ void potf2_lds(double (*Sp)[SLD], double* colbuf, const double* dsh, double* dinv,
-                                          double pivtol, int* flag, bool count) {
+// Unblocked right-looking Cholesky of a 64x64 block held in registers: thread (tx = tid & 63,
+// ty = tid >> 6) owns row tx, columns ty + 4 i in rv[i].  Column j is broadcast through the
+// double-buffered, column-permuted LDS vector cb (one barrier per pivot).  Square-root free inner
+// loop (S_ic -= S_ij S_cj / p_j, 1/p from v_rcp_f64 + one Newton step); the pivots go to piv[] and
+// the caller applies L_ij = S_ij / sqrt(p_j) in one parallel pass.  Only the lower triangle of the
+// result is meaningful.
+__device__ __forceinline__ void potf2_regs(v16d& rv, double* colbuf, const double* dsh, double* piv,
+                                           double pivtol, int* flag, bool count) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int ptx = cperm(tx);
-    double* seg = &Sp[tx][ty * 16];
-    double* piv = dinv;                                   // pivots first, 1/sqrt(pivot) after the loop
-    for (int j = 0; j < CB; ++j) {
-        double* cb = colbuf + (j & 1) * CB;
-        const int jg = j >> 2, jq = j & 3;
-        if (ty == jq) cb[ptx] = seg[jg];                  // element (tx, j) of the Schur complement
-        __syncthreads();
-        double p = cb[cperm(j)];
-        const double dj = dsh[j];
-        if (!(p > pivtol * dj)) {
-            if (count && threadIdx.x == 0) atomicAdd(flag, 1);
-            p = fmax(dj, 1e-300);
+#pragma unroll 1
+    for (int jg = 0; jg < 16; ++jg) {
+        double cur = sel16(rv, jg);                       // element (tx, 4 jg + ty)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * jg + jj;
+            double* cb = colbuf + (jj & 1) * CB;
+            if (ty == jj) cb[ptx] = cur;                  // publish column j of the Schur complement
+            __syncthreads();
+            double p = cb[jj * 16 + jg];                  // cperm(j)
+            const double dj = dsh[j];
+            if (!(p > pivtol * dj)) {
+                if (count && threadIdx.x == 0) atomicAdd(flag, 1);
+                p = fmax(dj, 1e-300);
+            }
+            double rcp = __builtin_amdgcn_rcp(p);         // ~26 bits
+            rcp = rcp * fma(-p, rcp, 2.0);                // 1/p to rounding
+            const double a = cb[ptx] * rcp;
+            const double* mine = cb + ty * 16;            // elements (c, j), c = ty + 4 i
+            if (ty > jj) cur -= a * mine[jg];             // this thread's element of column group jg
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] -= ((i > jg) ? a : 0.0) * mine[i];
+            if (ty == jj && tx == j) { cur = p; piv[j] = p; }
         }
-        double rcp = __builtin_amdgcn_rcp(p);             // ~26 bits
-        rcp = rcp * fma(-p, rcp, 2.0);                    // 1/p to rounding
-        const double a = cb[ptx] * rcp;
-        const double* mine = cb + ty * 16;                // elements (c, j), c = ty + 4 i
-        const int i0 = ty > jq ? jg : jg + 1;             // columns c = ty + 4 i > j
-        // Three phases (all loads, all FMAs, all stores): interleaving them serialises on LDS latency
-        // because the compiler cannot prove seg and mine disjoint (measured 1290 vs ~300 cycles).
-        // Finished column groups are skipped (wave-uniform tests).
-        double rv[16], cv[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (4 * g + 3 >= i0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { rv[4 * g + u] = seg[4 * g + u]; cv[4 * g + u] = mine[4 * g + u]; }
-            }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (4 * g + 3 >= i0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rv[4 * g + u] -= (4 * g + u >= i0 ? a : 0.0) * cv[4 * g + u];
-            }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (4 * g + 3 >= i0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) seg[4 * g + u] = rv[4 * g + u];
-            }
-        if (ty == jq && tx == j) { seg[jg] = p; piv[j] = p; }
+        put16(rv, jg, cur);
     }
-    __syncthreads();
-    if (threadIdx.x < CB) {
-        const double p = piv[threadIdx.x];
-        double y = __builtin_amdgcn_rsq(p);
-        y = y * (1.5 - 0.5 * p * y * y);
-        y = y * (1.5 - 0.5 * p * y * y);
-        dinv[threadIdx.x] = y;                            // 1 / L_jj
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) seg[i] *= dinv[ty + 4 * i];    // L_ij = S_ij / sqrt(p_j)  (L_jj = p_j / sqrt(p_j))
 }
 
 __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
@@ -218,35 +225,50 @@ __global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, doub
     }
     // (a) panel
     double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
-    double(*Xs)[SLD] = reinterpret_cast<double(*)[SLD]>(smem + CB * SLD);
-    double* dsh = smem + 2 * CB * SLD;                    // original diagonal of this block (64)
-    double* dinv = dsh + CB;                              // 1 / L_jj (64)
+    double* dsh = smem + CB * SLD;                        // original diagonal of this block (64)
+    double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
     double* colbuf = dinv + CB;                           // 2 x 64
     const long kk = (long)k * CB;
-    for (int e = tid; e < CB * CB; e += 256) {
-        int i = e >> 6, j = e & 63;
-        Sp[i][cperm(j)] = j <= i ? H[(kk + i) * np + kk + j] : 0.0;
+    const int tx = tid & 63, ty = tid >> 6;
+    v16d rv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = ty + 4 * i;
+        rv[i] = c <= tx ? H[(kk + tx) * np + kk + c] : 0.0;
     }
     if (tid < CB) dsh[tid] = d0[kk + tid];
     __syncthreads();
-    potf2_lds(Sp, colbuf, dsh, dinv, pivtol, flag, blockIdx.x == 0);
+    potf2_regs(rv, colbuf, dsh, dinv, pivtol, flag, blockIdx.x == 0);
+    __syncthreads();
+    if (tid < CB) {                                       // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
+        const double p = dinv[tid];
+        double y = __builtin_amdgcn_rsq(p);
+        y = y * (1.5 - 0.5 * p * y * y);
+        y = y * (1.5 - 0.5 * p * y * y);
+        dinv[tid] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                        // L_ij = S_ij / sqrt(p_j), image position cperm(c)
+        const int c = ty + 4 * i;
+        Sp[tx][ty * 16 + i] = c <= tx ? rv[i] * dinv[c] : 0.0;
+    }
     __syncthreads();
     if (blockIdx.x == 0) {
         // L_kk goes to a side buffer: the other blocks of this launch may still be reading A_kk from H
-        for (int e = tid; e < CB * CB; e += 256) {
-            int i = e >> 6, j = e & 63;
-            Dfac[kk * CB + e] = j <= i ? Sp[i][cperm(j)] : 0.0;
-        }
+        for (int e = tid; e < CB * CB; e += 256) Dfac[kk * CB + e] = Sp[e >> 6][cperm(e & 63)];
         return;
     }
-    // rows of A_ik:  X L_kk' = A_ik  <=>  L_kk x_r' = a_r'   (rhs r = row r of the tile)
+    // rows of A_ik:  X L_kk' = A_ik  <=>  L_kk x_r' = a_r'   (rhs r = tid / 4, lane q holds t = 4 i + q)
     const long ii = (long)(k + blockIdx.x) * CB;
-    double* tile = H + ii * np + kk;
-    for (int e = tid; e < CB * CB; e += 256) Xs[e >> 6][cperm(e & 63)] = tile[(long)(e >> 6) * np + (e & 63)];
-    __syncthreads();
-    subst64(Sp, dinv, Xs);
-    __syncthreads();
-    for (int e = tid; e < CB * CB; e += 256) tile[(long)(e >> 6) * np + (e & 63)] = Xs[e >> 6][cperm(e & 63)];
+    const int r = tid >> 2, q = tid & 3;
+    double* row = H + (ii + r) * np + kk;
+    v16d v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = row[4 * i + q];
+    subst64(Sp, dinv, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) row[4 * i + q] = v[i];
 }
 
 __global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
@@ -264,22 +286,22 @@ __global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, doub
         tile_update<true>(smem, H + i0 * np + kk, H + j0 * np + kk, H + i0 * np + j0, np);
         return;
     }
-    // (b) M_kj = L_kk^-1 R_kj : column c of the tile is one right-hand side (Xs row c)
+    // (b) M_kj = L_kk^-1 R_kj : column c = tid / 4 of the tile is one right-hand side
     const int j = blockIdx.x - ntrail;
     double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
-    double(*Xs)[SLD] = reinterpret_cast<double(*)[SLD]>(smem + CB * SLD);
-    double* dinv = smem + 2 * CB * SLD;
-    double* tile = M + kk * np + (long)j * CB;
-    for (int e = tid; e < CB * CB; e += 256) {
-        Sp[e >> 6][cperm(e & 63)] = Dfac[kk * CB + e];
-        Xs[e & 63][cperm(e >> 6)] = tile[(long)(e >> 6) * np + (e & 63)];      // transposed: rhs = column
-    }
+    double* dinv = smem + CB * SLD;
+    for (int e = tid; e < CB * CB; e += 256) Sp[e >> 6][cperm(e & 63)] = Dfac[kk * CB + e];
     __syncthreads();
     if (tid < CB) dinv[tid] = 1.0 / Sp[tid][cperm(tid)];
     __syncthreads();
-    subst64(Sp, dinv, Xs);
-    __syncthreads();
-    for (int e = tid; e < CB * CB; e += 256) tile[(long)(e >> 6) * np + (e & 63)] = Xs[e & 63][cperm(e >> 6)];
+    const int c = tid >> 2, q = tid & 3;
+    double* col = M + kk * np + (long)j * CB + c;
+    v16d v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = col[(long)(4 * i + q) * np];
+    subst64(Sp, dinv, v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) col[(long)(4 * i + q) * np] = v[i];
 }
 
 __global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M) {
