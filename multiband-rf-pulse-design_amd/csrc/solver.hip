@@ -127,41 +127,56 @@ __global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* _
     }
 }
 
-// K3 step 1: p1[i] = sum_{rows at i} alpha_r val_r, p2 likewise with beta
-template <int NV>
-__global__ void k_freq_agg(DProg P, const double* __restrict__ val, double* __restrict__ PP) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.Mf) return;
-    double p1[NV], p2[NV];
+// K3: G'v.  Two launches:
+//  k_atmulti<NVV, AGG>: partial[split][v][j] = sum_{i in split} A1[i][j] PP[v][i].  Block = 64 x 4
+//     threads: 4 waves share 128 columns and interleave the 256 rows of the split; with AGG the
+//     per-frequency operands p1[i] = sum_{rows at i} alpha_r val_r, p2[i] = sum beta_r val_r are
+//     formed in LDS first from the CSR map (each of the ld/128 column blocks redoes that cheap walk),
+//     otherwise they are read from the array PP (border products of the H assembly).
+//  k_gt_finish<NV>: folds the split partials (fixed order), applies the quadrature permutation,
+//     adds the identity rows and the y block.
+constexpr int AT_ROWS = 256;
+template <int NVV, bool AGG>
+__global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restrict__ A1, const double* __restrict__ src,
+                                                 double* __restrict__ partial) {
+    __shared__ double sh[4][NVV][128];
+    __shared__ double pp[NVV][AT_ROWS];
+    const int lane = threadIdx.x, wq = threadIdx.y, tid = wq * 64 + lane;
+    const int col0 = blockIdx.x * 128 + 2 * lane, split = blockIdx.y;
+    const int ld = P.ld, Mpad = P.Mpad;
+    const int r0 = split * AT_ROWS, r1 = min(r0 + AT_ROWS, Mpad);
+    {
+        const int i = r0 + tid;                        // one frequency row per thread
+        if (AGG) {
+            constexpr int NV = NVV;                    // upper bound; the real NV is NVV or NVV/2
+            const int nv = P.quad ? NVV / 2 : NVV;
+            double p1[NV], p2[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
-    for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
-        int r = P.f_rows[q];
-        double al = P.alpha[r], be = P.beta[r];
+            for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
+            if (i < P.Mf)
+                for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
+                    const int r = P.f_rows[q];
+                    const double al = P.alpha[r], be = P.beta[r];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            double x = val[(long)v * P.Rp + r];
-            p1[v] += al * x;
-            p2[v] += be * x;
+                    for (int v = 0; v < NV; ++v)
+                        if (v < nv) {
+                            const double x = src[(long)v * P.Rp + r];
+                            p1[v] += al * x;
+                            p2[v] += be * x;
+                        }
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (v < nv) {
+                    pp[v][tid] = p1[v];
+                    if (P.quad) pp[nv + v][tid] = p2[v];
+                }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NVV; ++v) pp[v][tid] = i < Mpad ? src[(long)v * Mpad + i] : 0.0;
         }
     }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        PP[(long)v * P.Mpad + i] = p1[v];
-        if (P.quad) PP[(long)(NV + v) * P.Mpad + i] = p2[v];
-    }
-}
-
-// K3 step 2: partial[split][v][j] = sum_{i in split} A1[i][j] PP[v][i].  Block = 64 x 4 threads:
-// 4 waves share 128 columns and interleave rows; partial sums are combined through LDS.
-constexpr int AT_ROWS = 256;
-template <int NVV>
-__global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, int ld, int Mpad,
-                                                 const double* __restrict__ PP, double* __restrict__ partial) {
-    __shared__ double sh[4][NVV][128];
-    const int lane = threadIdx.x, wq = threadIdx.y;
-    const int col0 = blockIdx.x * 128 + 2 * lane, split = blockIdx.y;
-    const int r0 = split * AT_ROWS, r1 = min(r0 + AT_ROWS, Mpad);
+    __syncthreads();
     double2 acc[NVV];
 #pragma unroll
     for (int v = 0; v < NVV; ++v) acc[v] = make_double2(0, 0);
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, 
         double2 t = *reinterpret_cast<const double2*>(A1 + (long)i * ld + col0);
 #pragma unroll
         for (int v = 0; v < NVV; ++v) {
-            double p = PP[(long)v * Mpad + i];
+            const double p = pp[v][i - r0];
             acc[v].x += t.x * p;
             acc[v].y += t.y * p;
         }
@@ -181,16 +196,14 @@ __global__ __launch_bounds__(256) void k_atmulti(const double* __restrict__ A1, 
         sh[wq][v][2 * lane + 1] = acc[v].y;
     }
     __syncthreads();
-    const int tid = wq * 64 + lane;
     for (int e = tid; e < NVV * 128; e += 256) {
         int v = e >> 7, cc = e & 127;
-        double s = sh[0][v][cc] + sh[1][v][cc] + sh[2][v][cc] + sh[3][v][cc];
-        partial[((long)split * NVV + v) * ld + blockIdx.x * 128 + cc] = s;
+        double t = sh[0][v][cc] + sh[1][v][cc] + sh[2][v][cc] + sh[3][v][cc];
+        partial[((long)split * NVV + v) * ld + blockIdx.x * 128 + cc] = t;
     }
 }
 
-// K3 step 3a: fold the split partials: TT[v][j] = sum_s partial[s][v][j].  Block = 64 columns x 16
-// split groups; each thread adds its strided splits, a fixed-order LDS pass adds the 16 groups.
+// fold the split partials: TT[v][j] = sum_s partial[s][v][j].  Block = 64 columns x 16 split groups.
 __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld,
                                                         int ldo, double* __restrict__ TT) {
     __shared__ double sh[16][65];
@@ -207,37 +220,66 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
         TT[(long)v * ldo + j] = a;
     }
 }
-// K3 step 3b: apply the quadrature permutation and add the identity rows.
+
+// Block x < nblk_cols: 64 columns x 16 split groups -> out[v][j]; the last block forms the y block.
 template <int NV>
-__global__ void k_gt_combine(DProg P, const double* __restrict__ TT, const double* __restrict__ val,
-                             double* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.Nt) return;
+__global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
+                                                    const double* __restrict__ val, double* __restrict__ out) {
+    __shared__ double sh[2 * NV][16][65];
+    __shared__ double red[17];
+    const int c = threadIdx.x, sg = threadIdx.y;
+    const int NVV = P.quad ? 2 * NV : NV;
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        // y block of G'v:  out[v][Nt+e] = sum_r ey[r][e] val[v][r]
+        const int tid = sg * 64 + c;
+        for (int v = 0; v < NV; ++v)
+            for (int e = 0; e < P.Ne; ++e) {
+                double a = 0;
+                for (int q = tid; q < P.nyrows; q += 1024) {
+                    const int r = P.yrows[q];
+                    a += P.ey[3 * r + e] * val[(long)v * P.Rp + r];
+                }
+                a = wave_sum(a);
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = a;
+                __syncthreads();
+                if (tid == 0) {
+                    double t = 0;
+                    for (int w = 0; w < 16; ++w) t += red[w];
+                    out[(long)v * P.LDV + P.Nt + e] = t;
+                }
+            }
+        return;
+    }
+    const int j = blockIdx.x * 64 + c;
+    const bool ok = j < P.Nt;
+    const int pj = (ok && P.quad) ? P.pcol[j] : 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        double g = TT[(long)v * P.LDV + j];
-        if (P.quad) g += P.psign[j] * TT[(long)(NV + v) * P.LDV + P.pcol[j]];
-        for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
-            int r = P.c_rows[q];
-            g += P.alpha[r] * val[(long)v * P.Rp + r];
-        }
-        out[(long)v * P.LDV + j] = g;
-    }
-}
-// y block of G'v:  out[v][Nt+e] = sum_r ey[r][e] val[v][r]   (one block)
-template <int NV>
-__global__ __launch_bounds__(256) void k_gt_y(DProg P, const double* __restrict__ val, double* __restrict__ out) {
-    __shared__ double sh[17];
-    for (int v = 0; v < NV; ++v)
-        for (int e = 0; e < P.Ne; ++e) {
-            double a = 0;
-            for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
-                int r = P.yrows[q];
-                a += P.ey[3 * r + e] * val[(long)v * P.Rp + r];
+        double t1 = 0, t2 = 0;
+        if (ok)
+            for (int s = sg; s < nsplit; s += 16) {
+                t1 += partial[((long)s * NVV + v) * P.ld + j];
+                if (P.quad) t2 += partial[((long)s * NVV + NV + v) * P.ld + pj];
             }
-            a = block_sum(a, sh);
-            if (threadIdx.x == 0) out[(long)v * P.LDV + P.Nt + e] = a;
+        sh[v][sg][c] = t1;
+        sh[NV + v][sg][c] = t2;
+    }
+    __syncthreads();
+    if (sg == 0 && ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double t1 = 0, t2 = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { t1 += sh[v][q][c]; t2 += sh[NV + v][q][c]; }
+            double g = t1 + (P.quad ? P.psign[j] * t2 : 0.0);
+            for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
+                const int r = P.c_rows[q];
+                g += P.alpha[r] * val[(long)v * P.Rp + r];
+            }
+            out[(long)v * P.LDV + j] = g;
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,32 +477,29 @@ __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __res
     }
     block_partials<4>(v, part, false);
 }
-// columns: rx = G'z + c tau ; bx batch: [0] = -c, [1] = -rx
-__global__ __launch_bounds__(256) void k_resid_cols(DProg P, const double* __restrict__ GTz, const double* __restrict__ x,
-                                                    const double* __restrict__ Sc, double* __restrict__ rx,
-                                                    double* __restrict__ bx2, double* __restrict__ part) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[3] = {0, 0, 0};
-    if (j < P.N) {
-        double tau = Sc[S_TAU], g = GTz[j], cv = P.c[j];
-        double res = g + cv * tau;
+// One workgroup: columns rx = G'z + c tau, bx batch [0] = -c, [1] = -rx, the N-space sums, the fold of
+// the row partials and all residual / gap / certificate scalars.
+__global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict__ Sc, const double* __restrict__ GTz,
+                                                     const double* __restrict__ x, double* __restrict__ rx,
+                                                     double* __restrict__ bx2, const double* __restrict__ partR, int nbR) {
+    __shared__ double sh[17];
+    const double tau0 = Sc[S_TAU];
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
+        double g = GTz[j], cv = P.c[j];
+        double res = g + cv * tau0;
         rx[j] = res;
         bx2[j] = -cv;
         bx2[P.LDV + j] = -res;
-        v[0] = res * res; v[1] = cv * x[j]; v[2] = g * g;
+        a0 += res * res; a1 += cv * x[j]; a2 += g * g;
     }
-    block_partials<3>(v, part, false);
-}
-__global__ __launch_bounds__(256) void k_scal_resid(double* __restrict__ Sc, const double* __restrict__ partR, int nbR,
-                                                    const double* __restrict__ partN, int nbN) {
-    __shared__ double sh[17];
+    double rx2 = block_sum(a0, sh);
+    double cx = block_sum(a1, sh);
+    double gtz2 = block_sum(a2, sh);
     double rz2 = fold_partials(partR, nbR, 4, 0, false, sh);
     double sz = fold_partials(partR, nbR, 4, 1, false, sh);
     double hz = fold_partials(partR, nbR, 4, 2, false, sh);
     double gxs2 = fold_partials(partR, nbR, 4, 3, false, sh);
-    double rx2 = fold_partials(partN, nbN, 3, 0, false, sh);
-    double cx = fold_partials(partN, nbN, 3, 1, false, sh);
-    double gtz2 = fold_partials(partN, nbN, 3, 2, false, sh);
     if (threadIdx.x == 0) {
         double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         Sc[S_RT] = kap + cx + hz;
@@ -491,29 +530,67 @@ __global__ void k_add_n(DProg P, const double* __restrict__ a, const double* __r
         out[o] = a[o] + sb * b[o];
     }
 }
-// r[v] = bx[v] - t[v] with per-vector sum of squares (refinement residual)
+// ---- single-workgroup N-space kernels (N <= a few thousand: one launch does reduce + update) ----
+// r[v] = bx[v] - t[v] ; Sc[slot] = max_v ||r_v||_2
 template <int NV>
-__global__ __launch_bounds__(256) void k_resid_n(DProg P, const double* __restrict__ bx, const double* __restrict__ t,
-                                                 double* __restrict__ out, double* __restrict__ part) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = 0;
-    if (j < P.N) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            long o = (long)q * P.LDV + j;
-            double r = bx[o] - t[o];
-            out[o] = r;
-            v[q] = r * r;
-        }
-    }
-    block_partials<NV>(v, part, false);
-}
-__global__ __launch_bounds__(256) void k_scal_rnorm(double* __restrict__ Sc, const double* __restrict__ part, int nb, int nv, int slot) {
+__global__ __launch_bounds__(1024) void k_resid_norm(DProg P, const double* __restrict__ bx, const double* __restrict__ t,
+                                                     double* __restrict__ out, double* __restrict__ Sc, int slot) {
     __shared__ double sh[17];
     double m = 0;
-    for (int v = 0; v < nv; ++v) m = fmax(m, sqrt(fold_partials(part, nb, nv, v, false, sh)));
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
+            long o = (long)v * P.LDV + j;
+            double r = bx[o] - t[o];
+            out[o] = r;
+            a += r * r;
+        }
+        m = fmax(m, sqrt(block_sum(a, sh)));
+    }
+    if (threadIdx.x == 0) Sc[slot] = m;
+}
+// CG: rz_new = r'z ; beta = first ? 0 : rz_new / rz ; rz = rz_new ; p = z + beta p
+template <int NV>
+__global__ __launch_bounds__(1024) void k_cg_start(DProg P, double* __restrict__ Sc, const double* __restrict__ r,
+                                                   const double* __restrict__ z, double* __restrict__ p, int first) {
+    __shared__ double sh[17];
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) a += r[(long)v * P.LDV + j] * z[(long)v * P.LDV + j];
+        const double rz_new = block_sum(a, sh);
+        const double rz_old = Sc[S_CG_RZ + v];
+        const double beta = first ? 0.0 : (rz_old > 0 ? rz_new / rz_old : 0.0);
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
+            long o = (long)v * P.LDV + j;
+            p[o] = first ? z[o] : z[o] + beta * p[o];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) Sc[S_CG_RZ + v] = rz_new;
+    }
+}
+// CG: alpha = rz / p'Hp (0 if p'Hp <= 0) ; dx += alpha p ; r -= alpha Hp ; Sc[slot] = max_v ||r_v||
+template <int NV>
+__global__ __launch_bounds__(1024) void k_cg_step(DProg P, double* __restrict__ Sc, const double* __restrict__ p,
+                                                  const double* __restrict__ Hp, double* __restrict__ dx,
+                                                  double* __restrict__ r, int slot) {
+    __shared__ double sh[17];
+    double m = 0;
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) a += p[(long)v * P.LDV + j] * Hp[(long)v * P.LDV + j];
+        const double pHp = block_sum(a, sh);
+        const double al = pHp > 0 ? Sc[S_CG_RZ + v] / pHp : 0.0;
+        double rr2 = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
+            long o = (long)v * P.LDV + j;
+            dx[o] += al * p[o];
+            double rr = r[o] - al * Hp[o];
+            r[o] = rr;
+            rr2 += rr * rr;
+        }
+        m = fmax(m, sqrt(block_sum(rr2, sh)));
+        if (threadIdx.x == 0) Sc[S_CG_ALPHA + v] = al;
+    }
     if (threadIdx.x == 0) Sc[slot] = m;
 }
 template <int NV>
@@ -531,53 +608,7 @@ __global__ void k_axpy_n(DProg P, const double* __restrict__ a, double* __restri
     for (int v = 0; v < NV; ++v) out[(long)v * P.LDV + j] += a[(long)v * P.LDV + j];
 }
 
-// ---- preconditioned conjugate gradients on (G' W^-2 G) dx = rhs (refinement of the KKT solve) ----
-template <int NV>
-__global__ __launch_bounds__(256) void k_dot_nn(DProg P, const double* __restrict__ a, const double* __restrict__ b,
-                                                double* __restrict__ part) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] = (j < P.N) ? a[(long)q * P.LDV + j] * b[(long)q * P.LDV + j] : 0.0;
-    block_partials<NV>(v, part, false);
-}
-// mode 0: rz = sum, beta = 0 ; mode 1: alpha = rz / sum (0 when sum <= 0) ; mode 2: beta = sum / rz, rz = sum
-__global__ __launch_bounds__(256) void k_scal_cg(double* __restrict__ Sc, const double* __restrict__ part, int nb, int nv, int mode) {
-    __shared__ double sh[17];
-    for (int v = 0; v < nv; ++v) {
-        double t = fold_partials(part, nb, nv, v, false, sh);
-        if (threadIdx.x == 0) {
-            if (mode == 0) { Sc[S_CG_RZ + v] = t; Sc[S_CG_BETA + v] = 0.0; }
-            else if (mode == 1) Sc[S_CG_ALPHA + v] = t > 0 ? Sc[S_CG_RZ + v] / t : 0.0;
-            else {
-                double rz = Sc[S_CG_RZ + v];
-                Sc[S_CG_BETA + v] = rz > 0 ? t / rz : 0.0;
-                Sc[S_CG_RZ + v] = t;
-            }
-        }
-    }
-}
-// dx += alpha p ; r -= alpha Hp ; partial ||r||^2
-template <int NV>
-__global__ __launch_bounds__(256) void k_cg_update_n(DProg P, const double* __restrict__ Sc, const double* __restrict__ p,
-                                                     const double* __restrict__ Hp, double* __restrict__ dx,
-                                                     double* __restrict__ r, double* __restrict__ part) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        v[q] = 0;
-        if (j < P.N) {
-            long o = (long)q * P.LDV + j;
-            double al = Sc[S_CG_ALPHA + q];
-            dx[o] += al * p[o];
-            double rr = r[o] - al * Hp[o];
-            r[o] = rr;
-            v[q] = rr * rr;
-        }
-    }
-    block_partials<NV>(v, part, false);
-}
+// ---- preconditioned conjugate gradients on (G' W^-2 G) dx = rhs: R-space update -------------------
 // gdx += alpha Gp ; dz += alpha Wp
 template <int NV>
 __global__ void k_cg_update_r(DProg P, const double* __restrict__ Sc, const double* __restrict__ Gp,
@@ -592,26 +623,7 @@ __global__ void k_cg_update_r(DProg P, const double* __restrict__ Sc, const doub
         dz[o] += al * Wp[o];
     }
 }
-// p = z + beta p
-template <int NV>
-__global__ void k_cg_p(DProg P, const double* __restrict__ Sc, const double* __restrict__ z, double* __restrict__ p) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.N) return;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        long o = (long)q * P.LDV + j;
-        p[o] = z[o] + Sc[S_CG_BETA + q] * p[o];
-    }
-}
-
 // dots needed for dtau: c'x1, c'x2 (N space) ; h'z1, h'z2, ||W z1||^2 (R space)
-__global__ __launch_bounds__(256) void k_dots_n(DProg P, const double* __restrict__ x1, const double* __restrict__ x2,
-                                                double* __restrict__ part) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double v[2] = {0, 0};
-    if (j < P.N) { v[0] = P.c[j] * x1[j]; v[1] = P.c[j] * x2[j]; }
-    block_partials<2>(v, part, false);
-}
 __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                                                 const double* __restrict__ z1, const double* __restrict__ z2,
                                                 double* __restrict__ part) {
@@ -643,12 +655,16 @@ __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __rest
     if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; part_row[2] = c; }
 }
 
-// dtau for the affine (mode 0) or the combined (mode 1) direction
-__global__ __launch_bounds__(256) void k_scal_dtau(double* __restrict__ Sc, const double* __restrict__ partN, int nbN,
-                                                   const double* __restrict__ partR, int nbR, int mode) {
+// dtau for the affine (mode 0) or the combined (mode 1) direction.  One workgroup: the N-space dots
+// c'x1, c'x2 are formed here, the R-space sums come as block partials.
+__global__ __launch_bounds__(1024) void k_scal_dtau(DProg P, double* __restrict__ Sc, const double* __restrict__ x1,
+                                                    const double* __restrict__ x2, const double* __restrict__ partR,
+                                                    int nbR, int mode) {
     __shared__ double sh[17];
-    double cx1 = fold_partials(partN, nbN, 2, 0, false, sh);
-    double cx2 = fold_partials(partN, nbN, 2, 1, false, sh);
+    double a1 = 0, a2 = 0;
+    for (int j = threadIdx.x; j < P.N; j += blockDim.x) { a1 += P.c[j] * x1[j]; a2 += P.c[j] * x2[j]; }
+    double cx1 = block_sum(a1, sh);
+    double cx2 = block_sum(a2, sh);
     double hz1 = fold_partials(partR, nbR, 3, 0, false, sh);
     double hz2 = fold_partials(partR, nbR, 3, 1, false, sh);
     double wz1 = fold_partials(partR, nbR, 3, 2, false, sh);
@@ -741,7 +757,8 @@ __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __
     if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; }
 }
 // step length + sigma (mode 0, affine) or final alpha and tau/kappa update (mode 1)
-__global__ __launch_bounds__(256) void k_scal_step(double* __restrict__ Sc, const double* __restrict__ part, int nb, int mode) {
+__global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict__ Sc, const double* __restrict__ part, int nb,
+                                                    int mode, const double* __restrict__ rx, double* __restrict__ bxc) {
     __shared__ double sh[17];
     double ts = fold_partials(part, nb, 2, 0, true, sh);
     double tz = fold_partials(part, nb, 2, 1, true, sh);
@@ -755,6 +772,7 @@ __global__ __launch_bounds__(256) void k_scal_step(double* __restrict__ Sc, cons
             double a = t == 0.0 ? 1.0 : fmin(1.0, 1.0 / t);
             Sc[S_ALPHA_A] = a;
             Sc[S_SIGMA] = (1 - a) * (1 - a) * (1 - a);
+            sh[16] = Sc[S_SIGMA];
         } else {
             double a = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
             Sc[S_ALPHA] = a;
@@ -762,10 +780,15 @@ __global__ __launch_bounds__(256) void k_scal_step(double* __restrict__ Sc, cons
             Sc[S_KAPPA] = kap + a * dkap;
         }
     }
+    if (mode == 0) {                                     // bx of the combined system: -(1 - sigma) rx
+        __syncthreads();
+        const double oms = 1.0 - sh[16];
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) bxc[j] = -oms * rx[j];
+    }
 }
 
 // combined right-hand side: ds_c = sigma mu e - lam o lam - dssa o wdza ; lds = lam \ ds_c ;
-// bz = -(1-sigma) rz - W lds ;  (bx = -(1-sigma) rx is formed by k_comb_bx)
+// bz = -(1-sigma) rz - W lds ;  (bx = -(1-sigma) rx is formed by k_scal_step)
 __global__ void k_comb_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                            const double* __restrict__ lam, const double* __restrict__ dssa,
                            const double* __restrict__ wdza, const double* __restrict__ rz,
@@ -822,11 +845,6 @@ __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __
     big_apply(P.big, wbb, Sc[S_ETAB], lds + ob, scratch, false, sh);
     for (int i = threadIdx.x; i < P.big; i += blockDim.x) bz[ob + i] = -(1 - sigma) * rz[ob + i] - scratch[i];
 }
-__global__ void k_comb_bx(DProg P, const double* __restrict__ rx, const double* __restrict__ Sc, double* __restrict__ bx) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P.N) bx[j] = -(1 - Sc[S_SIGMA]) * rx[j];
-}
-
 // x += alpha (x2 + dtau x1) ; s += alpha ds ; z += alpha dz
 __global__ void k_update(DProg P, const double* __restrict__ Sc, const double* __restrict__ x1,
                          const double* __restrict__ x2, double* __restrict__ x, const double* __restrict__ ds,
@@ -1142,25 +1160,24 @@ struct Solver::Impl {
         else hipLaunchKernelGGL(k_amulti<4>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
         hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
     }
-    void atmulti(int nvv, const double* pp) {
+    // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
+    void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
         switch (nvv) {
-            case 1: hipLaunchKernelGGL(k_atmulti<1>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
-            case 2: hipLaunchKernelGGL(k_atmulti<2>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
-            case 3: hipLaunchKernelGGL(k_atmulti<3>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
-            case 4: hipLaunchKernelGGL(k_atmulti<4>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
-            case 6: hipLaunchKernelGGL(k_atmulti<6>, g, b, 0, st, A1, P.ld, P.Mpad, pp, partial); break;
+            case 1: hipLaunchKernelGGL((k_atmulti<1, false>), g, b, 0, st, P, A1, pp, partial); break;
+            case 2: hipLaunchKernelGGL((k_atmulti<2, false>), g, b, 0, st, P, A1, pp, partial); break;
+            case 3: hipLaunchKernelGGL((k_atmulti<3, false>), g, b, 0, st, P, A1, pp, partial); break;
+            case 4: hipLaunchKernelGGL((k_atmulti<4, false>), g, b, 0, st, P, A1, pp, partial); break;
+            case 6: hipLaunchKernelGGL((k_atmulti<6, false>), g, b, 0, st, P, A1, pp, partial); break;
             default: throw HipError("atmulti: unsupported vector count");
         }
     }
     template <int NV>
     void apply_GT(const double* val, double* out) {
-        const int NVV = P.quad ? 2 * NV : NV;
-        hipLaunchKernelGGL(k_freq_agg<NV>, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, val, PP);
-        atmulti(NVV, PP);
-        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), NVV), dim3(64, 16), 0, st, partial, nsplit_at, NVV, P.ld, P.LDV, TT2);
-        hipLaunchKernelGGL(k_gt_combine<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, TT2, val, out);
-        if (P.Ne > 0) hipLaunchKernelGGL(k_gt_y<NV>, dim3(1), dim3(256), 0, st, P, val, out);
+        dim3 g(P.ld / 128, nsplit_at), b(64, 4);
+        if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
+        else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
+        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, 64) + 1), dim3(64, 16), 0, st, P, partial, nsplit_at, val, out);
     }
     template <int NV>
     void winv2(const double* in, const double* sub, double* out, int mode) {
@@ -1188,21 +1205,15 @@ struct Solver::Impl {
         winv2<NV>(gdx, wbz, dz, 0);
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
-        hipLaunchKernelGGL(k_resid_n<NV>, gN, b256, 0, st, P, bx, tmpN, r, partN);         // r = bx - G'dz, ||r||^2
-        hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot);   // n_0
+        hipLaunchKernelGGL(k_resid_norm<NV>, dim3(1), dim3(1024), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
         if (nsweep <= 0) return;
         hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
-            hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, r, tmpN2, partN);          // r'z
-            hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, it == 0 ? 0 : 2);
-            hipLaunchKernelGGL(k_cg_p<NV>, gN, b256, 0, st, P, Sc, tmpN2, pN);              // p = z + beta p
+            hipLaunchKernelGGL(k_cg_start<NV>, dim3(1), dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
             apply_G<NV>(pN, tmpR);                                                          // G p
             winv2<NV>(tmpR, nullptr, wpR, 0);                                               // W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
-            hipLaunchKernelGGL(k_dot_nn<NV>, gN, b256, 0, st, P, pN, tmpN, partN);          // p'Hp
-            hipLaunchKernelGGL(k_scal_cg, dim3(1), b256, 0, st, Sc, partN, nbN, NV, 1);     // alpha
-            hipLaunchKernelGGL(k_cg_update_n<NV>, gN, b256, 0, st, P, Sc, pN, tmpN, dx, r, partN);
-            hipLaunchKernelGGL(k_scal_rnorm, dim3(1), b256, 0, st, Sc, partN, nbN, NV, slot + it + 1);   // n_{it+1}
+            hipLaunchKernelGGL(k_cg_step<NV>, dim3(1), dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
             hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
             if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
         }
@@ -1226,7 +1237,7 @@ struct Solver::Impl {
         gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
-            atmulti(nvv, BB);
+            atmulti_array(nvv, BB);
             hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
         }
         hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H);
@@ -1410,8 +1421,7 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         S.apply_G<1>(S.x, S.Gx);
         S.apply_GT<1>(S.z, S.GTz);
         hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR);
-        hipLaunchKernelGGL(k_resid_cols, dim3(S.nbN), dim3(256), 0, st, P, S.GTz, S.x, S.Sc, S.rx, S.bx2, S.partN);
-        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(256), 0, st, S.Sc, S.partR, S.nbR, S.partN, S.nbN);
+        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR);
         MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
@@ -1466,14 +1476,13 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA);
         double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
         auto dots = [&](const double* xx2, const double* zz2, int mode) {
-            hipLaunchKernelGGL(k_dots_n, dim3(S.nbN), dim3(256), 0, st, P, x1, xx2, S.partN);
             hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
             int nb = std::max(S.nbC, 1);
             if (P.big) {
                 hipLaunchKernelGGL(k_big_dots, dim3(1), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
                 nb += 1;
             }
-            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(256), 0, st, S.Sc, S.partN, S.nbN, S.partR, nb, mode);
+            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode);
         };
         auto dir_post = [&](const double* zz2, const double* gg2, double* outA, double* outB, int mode) {
             int nb = std::max(S.nbC, 1);
@@ -1484,7 +1493,7 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
                                    S.scratch, S.partR + 2L * nb, mode);
                 nb += 1;
             }
-            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(256), 0, st, S.Sc, S.partR, nb, mode);
+            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc);
         };
         dots(x2a, z2a, 0);
         dir_post(z2a, g2a, S.dssa, S.wdza, 0);
@@ -1494,7 +1503,6 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         if (P.big)
             hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
-        hipLaunchKernelGGL(k_comb_bx, dim3(S.nbN), dim3(256), 0, st, P, S.rx, S.Sc, S.bxc);
         S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB);
         dots(S.dxc, S.dzc, 1);
         dir_post(S.dzc, S.gdxc, S.ds, S.dz, 1);
