@@ -87,14 +87,17 @@ def main():
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run\n" % (args.gpus, world))
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    if args.mode == "shard":
-        sys.stderr.write("bench.py: the row-sharded mode is not wired into this round's build\n")
-        sys.exit(2)
-
     import mbfir
     ctx = mbfir.Context(local_rank)
     f, a, d = workload(args.n)
-    opts = mbfir.make_opts(grid_m=args.grid_m)
+    shard = args.mode == "shard" and world > 1
+    if shard:
+        # ONE design, its frequency rows split over the ranks; per iteration RCCL all-reduces the
+        # normal matrix, every G'v and the step / residual scalars (mbfir_set_allreduce hook)
+        ctx.set_allreduce(mbfir.make_torch_allreduce())
+        opts = mbfir.make_opts(grid_m=args.grid_m, shard_rank=rank, shard_size=world)
+    else:
+        opts = mbfir.make_opts(grid_m=args.grid_m)
 
     def step():
         h, status, info = mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)
@@ -132,15 +135,17 @@ def main():
             peak_mfma = peak_valu = float("nan")
         out = {
             "metric": "FIR designs/sec, n=%d taps m=%d arbitrary-phase SOCP (fir_ap_cvx form)" % (args.n, args.grid_m),
-            "value": world * args.steps / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
+            "value": (1 if shard else world) * args.steps / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "S-C13 bSSFP 5-band spec, fixed-duration regime, fir_ap_cvx(n=%d, obj=0.1, Peak=1e-3), "
                                    "grid_m=%d (+10 band edges), one design per rank per step" % (args.n, args.grid_m),
                        "n_taps": args.n, "grid_m": args.grid_m, "unknowns": infos[0]["n_unknowns"], "rows": infos[0]["n_rows"],
-                       "mode": args.mode, "parallelism": "independent designs x%d" % world},
+                       "mode": args.mode,
+                       "parallelism": ("frequency rows of one design sharded x%d, RCCL all-reduce per iteration" % world) if shard
+                       else "independent designs x%d" % world},
             "ipm_iters_per_design": iters / args.steps,
-            "ipm_iters_per_s": world * iters / elapsed,
+            "ipm_iters_per_s": (1 if shard else world) * iters / elapsed,
             "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / args.steps,
                                         "solve": sum(i["ms_solve"] for i in infos) / args.steps,
                                         "gram_kernel": gram_ms / args.steps,

@@ -125,6 +125,9 @@ typedef struct mbfir_program mbfir_program;
 int  mbfir_assemble(int which, int n, int nband, const double* f, const double* a, const double* d,
                     const double* params, int grid_m, mbfir_program** out, char* err, int errlen);
 void mbfir_program_free(mbfir_program* p);
+/* the rows process `rank` of `size` keeps in a row-sharded solve (see mbfir_opts.shard_*): frequencies
+ * i % size == rank with their rows and cones; rows without a frequency go to rank 0 */
+int  mbfir_program_shard(const mbfir_program* p, int rank, int size, mbfir_program** out);
 /* dims[0..9] = Nt, Ne, R, l, nq3, big, Mf, quad(0/1), nnz_id, reserved */
 void mbfir_program_dims(const mbfir_program* p, int* dims);
 /* w[Mf]; col_kind[Nt] (0 cos,1 sin); col_tau[Nt]; col_scale[Nt]; pcol[Nt]; psign[Nt]; c[N]     */

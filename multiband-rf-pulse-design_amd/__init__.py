@@ -80,6 +80,7 @@ SYMBOLS = {
     "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mbfir_program_free": (None, [C.c_void_p]),
+    "mbfir_program_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mbfir_program_dims": (None, [C.c_void_p, _ip]),
     "mbfir_program_trig": (None, [C.c_void_p, _dp, _ip, _dp, _dp, _ip, _dp, _dp]),
     "mbfir_program_rows": (None, [C.c_void_p, _ip, _ip, _dp, _dp, _dp, _dp]),
@@ -97,6 +98,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Whichever is loaded first serves
+    # the whole process, and torch stops seeing the GPU when it is not its own -- so load torch first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise MbfirError("libmbfir.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
                          % LIB_PATH)
@@ -157,6 +164,37 @@ class Context:
         """fn(ptr:int, count:int, op:int) -> int ; op 0 = sum, 1 = max (device pointer)."""
         self._cb = ALLREDUCE_FN(lambda buf, count, op, user: int(fn(buf, count, op)))
         load_library().mbfir_set_allreduce(self._h, self._cb, None)
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of `count` doubles at a raw device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, count):
+    """torch tensor aliasing device memory owned by the solver (zero copy)."""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, count), device="cuda")
+
+
+def make_torch_allreduce(group=None, wrap=None):
+    """All-reduce hook for row-sharded solves: fn(ptr, count, op) over torch.distributed
+    (backend nccl = RCCL over xGMI; op 0 = sum, 1 = max).  `wrap(ptr, count)` makes the tensor
+    (default: a zero-copy view of the device pointer); the hook returns once the result is in place."""
+    import torch
+    import torch.distributed as dist
+    wrap = wrap or device_tensor
+
+    def hook(ptr, count, op):
+        t = wrap(ptr, count)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return 0
+
+    return hook
 
 
 _default_ctx = {}
@@ -270,9 +308,10 @@ def _check_spec(f, a, d):
 
 
 # ---- host-only introspection (no GPU): structured program -> dense (c, G, h) -------------------
-def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0):
+def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None):
     """Run the product's C++ problem assembly for designer `which` (0 ap, 1 qp, 2 linprog,
     3 qprog_phs; for 3 pass complex a, d) and expand the structured rows to dense arrays.
+    shard=(rank, size) returns the rows that rank keeps in a row-sharded solve.
     Returns (rc, dict) -- used by the CPU tests to compare against the oracle."""
     lib = load_library()
     f = _vec(f)
@@ -290,6 +329,13 @@ def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0):
                             C.byref(out), err, 256)
     if rc != 0:
         return rc, err.value.decode()
+    if shard is not None:
+        sub = C.c_void_p()
+        rc2 = lib.mbfir_program_shard(out, int(shard[0]), int(shard[1]), C.byref(sub))
+        lib.mbfir_program_free(out)
+        if rc2 != 0:
+            return rc2, "bad shard"
+        out = sub
     try:
         dims = np.zeros(10, dtype=np.int32)
         lib.mbfir_program_dims(out, dims.ctypes.data_as(_ip))
@@ -317,7 +363,7 @@ def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0):
     idr = np.nonzero(col >= 0)[0]
     G[idr, col[idr]] += al[idr]
     G[:, Nt:] = ey[:, :Ne]
-    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad)
+    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad, freq=freq)
 
 
 # ---- device kernel test hooks --------------------------------------------------------------------

@@ -35,6 +35,8 @@ SolveOpts to_opts(const mbfir_opts* o) {
     if (o->reltol > 0) s.reltol = o->reltol;
     if (o->refine >= 0) s.refine = o->refine;
     s.verbose = o->verbose;
+    s.shard_rank = o->shard_rank;
+    s.shard_size = o->shard_size;
     return s;
 }
 
@@ -52,7 +54,8 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
                double t_solved, double t_end) {
     if (!info) return;
     std::memset(info, 0, sizeof(*info));
-    info->status = rc; info->iters = si.iters; info->n_unknowns = P.N(); info->n_rows = P.R; info->n_freq = P.Mf;
+    info->status = rc; info->iters = si.iters; info->n_unknowns = P.N();
+    info->n_rows = si.n_rows; info->n_freq = si.n_freq;      // of this process's row shard
     info->n_lp = P.l; info->n_q3 = P.nq3; info->n_big = P.big;
     info->pcost = si.pcost; info->dcost = si.dcost; info->gap = si.gap; info->relgap = si.relgap;
     info->pres = si.pres; info->dres = si.dres;
@@ -127,6 +130,7 @@ void mbfir_set_allreduce(mbfir_ctx* ctx, mbfir_allreduce_fn fn, void* user) {
     if (!ctx) return;
     ctx->allreduce = fn;
     ctx->allreduce_user = user;
+    ctx->solver->set_allreduce(fn, user);
 }
 
 int mbfir_last_solution(mbfir_ctx* ctx, double* z, int capacity) {

@@ -37,6 +37,14 @@ int mbfir_assemble(int which, int n, int nband, const double* f, const double* a
 
 void mbfir_program_free(mbfir_program* p) { delete p; }
 
+int mbfir_program_shard(const mbfir_program* p, int rank, int size, mbfir_program** out) {
+    if (!p || !out || size < 1 || rank < 0 || rank >= size) return -1;
+    mbfir_program* q = new mbfir_program();
+    q->P = shard_program(p->P, rank, size);
+    *out = q;
+    return 0;
+}
+
 void mbfir_program_dims(const mbfir_program* p, int* dims) {
     const TrigProgram& P = p->P;
     int nnz_id = 0;

@@ -362,4 +362,38 @@ int assemble_qprog_phs(int n, int nband, const double* f, const double* ac_re, c
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+TrigProgram shard_program(const TrigProgram& Q, int rank, int size) {
+    if (size <= 1) return Q;
+    TrigProgram P;
+    P.which = Q.which; P.n = Q.n; P.Nt = Q.Nt; P.Ne = Q.Ne; P.quad = Q.quad;
+    P.col_kind = Q.col_kind; P.col_tau = Q.col_tau; P.col_scale = Q.col_scale; P.pcol = Q.pcol; P.psign = Q.psign;
+    P.c = Q.c; P.nhalf = Q.nhalf; P.real_filter = Q.real_filter; P.odd_filter = Q.odd_filter;
+    std::vector<int> fmap(Q.Mf, -1);
+    for (int i = 0; i < Q.Mf; ++i)
+        if (i % size == rank) { fmap[i] = int(P.w.size()); P.w.push_back(Q.w[i]); }
+    P.Mf = int(P.w.size());
+    auto owner_of_freq = [&](int f) { return f < 0 ? 0 : f % size; };
+    auto copy_row = [&](int r) {
+        int f = Q.freq[r];
+        P.add_row(f < 0 ? -1 : fmap[f], Q.col[r], Q.alpha[r], Q.beta[r], Q.ey[3 * r], Q.ey[3 * r + 1], Q.ey[3 * r + 2], Q.h[r]);
+    };
+    for (int r = 0; r < Q.l; ++r)
+        if (owner_of_freq(Q.freq[r]) == rank) copy_row(r);
+    P.l = int(P.h.size());
+    for (int c = 0; c < Q.nq3; ++c) {
+        int r0 = Q.l + 3 * c, f = -1;
+        for (int a = 0; a < 3; ++a) if (Q.freq[r0 + a] >= 0) f = Q.freq[r0 + a];
+        if (owner_of_freq(f) != rank) continue;
+        for (int a = 0; a < 3; ++a) copy_row(r0 + a);
+        P.nq3++;
+    }
+    if (Q.big && rank == 0) {
+        for (int r = Q.l + 3 * Q.nq3; r < Q.R; ++r) copy_row(r);
+        P.big = Q.big;
+    }
+    P.R = int(P.h.size());
+    return P;
+}
+
 }  // namespace mbfir

@@ -47,6 +47,13 @@ struct TrigProgram {
     }
 };
 
+// Row sharding for one process per GPU: rank r keeps the frequencies i with
+// i % size == r (interleaved, so every rank gets the same band/transition mix) together with every
+// row / cone attached to them; rows and cones with no frequency (identity rows, spike / per-tap
+// cones, the big cone) all go to rank 0.  x and y stay replicated.  The union of the shards is the
+// original program, no row appears twice.
+TrigProgram shard_program(const TrigProgram& Q, int rank, int size);
+
 // Return 0 ok, 3 early-fail (reference returns 'Failed' before solving), -1 argument error.
 int assemble_ap(int n, int nband, const double* f, const double* a, const double* d,
                 double obj, double peak, int grid_m, TrigProgram& P, std::string& err);

@@ -13,6 +13,7 @@ struct SolveOpts {
     double feastol = 1e-8, abstol = 1e-10, reltol = 1e-8;
     int refine = 2;
     int verbose = 0;
+    int shard_rank = 0, shard_size = 1;     // frequency-row sharding (one process per GPU)
     bool timing = true;     // HIP-event timing of the k_gram launches and the Cholesky phase (events read at the end)
 };
 
@@ -40,6 +41,7 @@ public:
     void test_mfma_peak(double* tf_mfma, double* tf_valu);
     void test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, double* ms_gram);
     void* stream() const;
+    void set_allreduce(int (*fn)(void*, long, int, void*), void* user);
 
 private:
     struct Impl;

@@ -479,10 +479,26 @@ __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __res
 }
 // One workgroup: columns rx = G'z + c tau, bx batch [0] = -c, [1] = -rx, the N-space sums, the fold of
 // the row partials and all residual / gap / certificate scalars.
+// phase 0: fold the local row sums into RB (then the host all-reduces RB over the row shards);
+// phase 1: take the row sums from RB and finish; phase 2: both in one launch (single GPU).
 __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict__ Sc, const double* __restrict__ GTz,
                                                      const double* __restrict__ x, double* __restrict__ rx,
-                                                     double* __restrict__ bx2, const double* __restrict__ partR, int nbR) {
+                                                     double* __restrict__ bx2, const double* __restrict__ partR, int nbR,
+                                                     double* __restrict__ RB, int phase) {
     __shared__ double sh[17];
+    double rz2, sz, hz, gxs2;
+    if (phase != 1) {
+        rz2 = fold_partials(partR, nbR, 4, 0, false, sh);
+        sz = fold_partials(partR, nbR, 4, 1, false, sh);
+        hz = fold_partials(partR, nbR, 4, 2, false, sh);
+        gxs2 = fold_partials(partR, nbR, 4, 3, false, sh);
+        if (phase == 0) {
+            if (threadIdx.x == 0) { RB[0] = rz2; RB[1] = sz; RB[2] = hz; RB[3] = gxs2; }
+            return;
+        }
+    } else {
+        rz2 = RB[0]; sz = RB[1]; hz = RB[2]; gxs2 = RB[3];
+    }
     const double tau0 = Sc[S_TAU];
     double a0 = 0, a1 = 0, a2 = 0;
     for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
@@ -496,10 +512,6 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
     double rx2 = block_sum(a0, sh);
     double cx = block_sum(a1, sh);
     double gtz2 = block_sum(a2, sh);
-    double rz2 = fold_partials(partR, nbR, 4, 0, false, sh);
-    double sz = fold_partials(partR, nbR, 4, 1, false, sh);
-    double hz = fold_partials(partR, nbR, 4, 2, false, sh);
-    double gxs2 = fold_partials(partR, nbR, 4, 3, false, sh);
     if (threadIdx.x == 0) {
         double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         Sc[S_RT] = kap + cx + hz;
@@ -659,15 +671,24 @@ __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __rest
 // c'x1, c'x2 are formed here, the R-space sums come as block partials.
 __global__ __launch_bounds__(1024) void k_scal_dtau(DProg P, double* __restrict__ Sc, const double* __restrict__ x1,
                                                     const double* __restrict__ x2, const double* __restrict__ partR,
-                                                    int nbR, int mode) {
+                                                    int nbR, int mode, double* __restrict__ RB, int phase) {
     __shared__ double sh[17];
+    double hz1, hz2, wz1;
+    if (phase != 1) {
+        hz1 = fold_partials(partR, nbR, 3, 0, false, sh);
+        hz2 = fold_partials(partR, nbR, 3, 1, false, sh);
+        wz1 = fold_partials(partR, nbR, 3, 2, false, sh);
+        if (phase == 0) {
+            if (threadIdx.x == 0) { RB[0] = hz1; RB[1] = hz2; RB[2] = wz1; }
+            return;
+        }
+    } else {
+        hz1 = RB[0]; hz2 = RB[1]; wz1 = RB[2];
+    }
     double a1 = 0, a2 = 0;
     for (int j = threadIdx.x; j < P.N; j += blockDim.x) { a1 += P.c[j] * x1[j]; a2 += P.c[j] * x2[j]; }
     double cx1 = block_sum(a1, sh);
     double cx2 = block_sum(a2, sh);
-    double hz1 = fold_partials(partR, nbR, 3, 0, false, sh);
-    double hz2 = fold_partials(partR, nbR, 3, 1, false, sh);
-    double wz1 = fold_partials(partR, nbR, 3, 2, false, sh);
     if (threadIdx.x == 0) {
         double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         double den = kap / tau + wz1;
@@ -758,10 +779,20 @@ __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __
 }
 // step length + sigma (mode 0, affine) or final alpha and tau/kappa update (mode 1)
 __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict__ Sc, const double* __restrict__ part, int nb,
-                                                    int mode, const double* __restrict__ rx, double* __restrict__ bxc) {
+                                                    int mode, const double* __restrict__ rx, double* __restrict__ bxc,
+                                                    double* __restrict__ RB, int phase) {
     __shared__ double sh[17];
-    double ts = fold_partials(part, nb, 2, 0, true, sh);
-    double tz = fold_partials(part, nb, 2, 1, true, sh);
+    double ts, tz;
+    if (phase != 1) {
+        ts = fold_partials(part, nb, 2, 0, true, sh);
+        tz = fold_partials(part, nb, 2, 1, true, sh);
+        if (phase == 0) {
+            if (threadIdx.x == 0) { RB[0] = ts; RB[1] = tz; }
+            return;
+        }
+    } else {
+        ts = RB[0]; tz = RB[1];
+    }
     if (threadIdx.x == 0) {
         double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
@@ -900,7 +931,7 @@ __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const doub
 
 // H (np x np) from the Gram matrices and the border products.  TT[v][j] = (A1' BB[v])[j].
 __global__ void k_assemble_H(DProg P, const double* __restrict__ T, const double* __restrict__ TT,
-                             double* __restrict__ H) {
+                             double* __restrict__ H, double pad_diag) {
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (k >= P.np || j >= P.np) return;
     double v = 0;
@@ -920,7 +951,7 @@ __global__ void k_assemble_H(DProg P, const double* __restrict__ T, const double
             if (P.quad) v += P.psign[jj] * TT[(long)(P.Ne + e) * P.LDV + P.pcol[jj]];
         }
     } else if (j == k) {
-        v = 1.0;                                          // padding
+        v = pad_diag;                                     // padding (1 on one shard, 0 on the others: H is summed)
     }
     H[(long)j * P.np + k] = v;
 }
@@ -1040,11 +1071,16 @@ __global__ __launch_bounds__(1024) void k_big_cone_resid(DProg P, const double* 
     double n1 = big_dot(v + ob + 1, v + ob + 1, P.big - 1, sh);
     if (threadIdx.x == 0) { part_row[0] = sqrt(n1) - v[ob]; part_row[1] = n1 + v[ob] * v[ob]; }
 }
-// v += (1 + t) e  when  t >= -1e-8 max(1, ||v||)
-__global__ __launch_bounds__(256) void k_cone_shift(DProg P, double* __restrict__ v, const double* __restrict__ part, int nb) {
+// fold the cone-residual partials: RB[0] = max (distance outside), RB[1] = sum ||v||^2
+__global__ __launch_bounds__(256) void k_cone_fold(const double* __restrict__ part, int nb, double* __restrict__ RB) {
     __shared__ double sh[17];
     double tmax = fold_partials(part, nb, 2, 0, true, sh);
-    double nrm = sqrt(fold_partials(part, nb, 2, 1, false, sh));
+    double n2 = fold_partials(part, nb, 2, 1, false, sh);
+    if (threadIdx.x == 0) { RB[0] = tmax; RB[1] = n2; }
+}
+// v += (1 + t) e  when  t >= -1e-8 max(1, ||v||)
+__global__ __launch_bounds__(256) void k_cone_shift(DProg P, double* __restrict__ v, const double* __restrict__ RB) {
+    const double tmax = RB[0], nrm = sqrt(RB[1]);
     if (!(tmax >= -1e-8 * fmax(1.0, nrm))) return;
     const double add = 1.0 + tmax;
     const long ncones = (long)P.l + P.nq3 + (P.big ? 1 : 0);
@@ -1075,20 +1111,6 @@ __global__ void k_finish_x(DProg P, const double* __restrict__ x, const double* 
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < P.N) out[j] = x[j] / Sc[S_TAU];
 }
-__global__ void k_norms_hc(DProg P, double* __restrict__ Sc) {
-    __shared__ double sh[17];
-    double a = 0, b = 0;
-    for (int r = threadIdx.x; r < P.R; r += blockDim.x) a += P.h[r] * P.h[r];
-    for (int j = threadIdx.x; j < P.N; j += blockDim.x) b += P.c[j] * P.c[j];
-    a = block_sum(a, sh); b = block_sum(b, sh);
-    if (threadIdx.x == 0) {
-        Sc[S_NRMH] = fmax(1.0, sqrt(a));
-        Sc[S_NRMC] = fmax(1.0, sqrt(b));
-        Sc[S_DEG] = double(P.l + P.nq3 + (P.big ? 1 : 0));
-        Sc[S_TAU] = 1.0; Sc[S_KAPPA] = 1.0;
-    }
-}
-
 // ================================================================================================
 // host driver
 // ================================================================================================
@@ -1110,6 +1132,16 @@ struct Arena {
 struct Solver::Impl {
     int device = 0;
     hipStream_t st = nullptr;
+    // row sharding (one process per GPU): reductions over the shards go through this hook
+    int shard_rank = 0, shard_size = 1;
+    int (*ar_fn)(void*, long, int, void*) = nullptr;
+    void* ar_user = nullptr;
+    double* RB = nullptr;        // 16 doubles: reduction mailbox
+    void allreduce(double* buf, long count, int op) {
+        if (shard_size <= 1) return;
+        MBFIR_HIP(hipStreamSynchronize(st));
+        if (!ar_fn || ar_fn(buf, count, op, ar_user) != 0) throw HipError("all-reduce hook failed");
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Arena ar;
     double* hostSc = nullptr;    // pinned
@@ -1178,6 +1210,7 @@ struct Solver::Impl {
         if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
         else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
         hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, 64) + 1), dim3(64, 16), 0, st, P, partial, nsplit_at, val, out);
+        allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
     void winv2(const double* in, const double* sub, double* out, int mode) {
@@ -1240,7 +1273,7 @@ struct Solver::Impl {
             atmulti_array(nvv, BB);
             hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
         }
-        hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H);
+        hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
         if (P.Ne > 0 && P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H);
         if (P.big) {
@@ -1248,6 +1281,7 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
             hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
         }
+        allreduce(H, (long)P.np * P.np, 0);               // sum the shards' normal matrices
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
         if (c0) hipEventRecord(c0, st);
         chol_inv_launch(H, M, Mt, W1, P.np, flag, st);
@@ -1290,17 +1324,30 @@ Solver::~Solver() {
     delete impl;
 }
 void* Solver::stream() const { return impl->st; }
+void Solver::set_allreduce(int (*fn)(void*, long, int, void*), void* user) { impl->ar_fn = fn; impl->ar_user = user; }
 
 static double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {
+int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {
     Impl& S = *impl;
     MBFIR_HIP(hipSetDevice(S.device));
     hipStream_t st = S.st;
     const double t_begin = now_ms();
+    // ---- row sharding: this process keeps the frequencies i % size == rank (program.h) ----------
+    S.shard_rank = o.shard_size > 1 ? o.shard_rank : 0;
+    S.shard_size = o.shard_size > 1 ? o.shard_size : 1;
+    if (S.shard_size > 1 && !S.ar_fn) throw HipError("row-sharded solve without an all-reduce hook");
+    const TrigProgram Qlocal = shard_program(Qfull, S.shard_rank, S.shard_size);
+    const TrigProgram& Q = Qlocal;
+    // constants of the WHOLE program (identical on every shard)
+    double nrm_h = 0, nrm_c = 0;
+    for (double v : Qfull.h) nrm_h += v * v;
+    for (double v : Qfull.c) nrm_c += v * v;
+    nrm_h = std::max(1.0, std::sqrt(nrm_h)); nrm_c = std::max(1.0, std::sqrt(nrm_c));
+    const double degree = double(Qfull.l + Qfull.nq3 + (Qfull.big ? 1 : 0));
     // ---- host-side index structures --------------------------------------------------------
     const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;
     std::vector<int> f_ptr(Mf + 1, 0), f_rows, c_ptr(Nt + 1, 0), c_rows, yrows;
@@ -1356,7 +1403,7 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     S.A1 = ar.get<double>(Mpad * ld);
     S.T = ar.get<double>(nw * ld * ld);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
-    S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4);
+    S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
     S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.pN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
     S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV);
@@ -1386,17 +1433,26 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
     MBFIR_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     // ---- build A1, norms -------------------------------------------------------------------
     hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
-    hipLaunchKernelGGL(k_norms_hc, dim3(1), dim3(256), 0, st, P, S.Sc);
+    {
+        std::vector<double> sc0(S_COUNT, 0.0);
+        sc0[S_NRMH] = nrm_h; sc0[S_NRMC] = nrm_c; sc0[S_DEG] = degree; sc0[S_TAU] = 1.0; sc0[S_KAPPA] = 1.0;
+        MBFIR_HIP(hipMemcpyAsync(S.Sc, sc0.data(), sizeof(double) * S_COUNT, hipMemcpyHostToDevice, st));
+    }
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_assembled = now_ms();
     S.evused = 0;
     S.timing = o.timing;
 
     const int nbRc = S.nbC + (P.big ? 1 : 0);      // cone-indexed reductions (+1 row for the big cone)
+    const bool sharded = S.shard_size > 1;
     auto cone_shift = [&](double* v) {
-        hipLaunchKernelGGL(k_cone_resid, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, v, S.partR);
-        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, dim3(1), dim3(1024), 0, st, P, v, S.partR + 2L * std::max(S.nbC, 1));
-        hipLaunchKernelGGL(k_cone_shift, dim3(64), dim3(256), 0, st, P, v, S.partR, std::max(S.nbC, 1) + (P.big ? 1 : 0));
+        const int nb = std::max(S.nbC, 1);
+        hipLaunchKernelGGL(k_cone_resid, dim3(nb), dim3(256), 0, st, P, v, S.partR);
+        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, dim3(1), dim3(1024), 0, st, P, v, S.partR + 2L * nb);
+        hipLaunchKernelGGL(k_cone_fold, dim3(1), dim3(256), 0, st, S.partR, nb + (P.big ? 1 : 0), S.RB);
+        S.allreduce(S.RB, 1, 1);                          // max of the cone distances
+        S.allreduce(S.RB + 1, 1, 0);                      // sum of squares
+        hipLaunchKernelGGL(k_cone_shift, dim3(64), dim3(256), 0, st, P, v, S.RB);
     };
     // ---- initial point (W = I) -------------------------------------------------------------
     hipLaunchKernelGGL(k_unit_scaling, dim3(cdiv(std::max(std::max(P.l, P.nq3), std::max(P.big, 1)), 256)), dim3(256), 0, st,
@@ -1421,7 +1477,11 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
         S.apply_G<1>(S.x, S.Gx);
         S.apply_GT<1>(S.z, S.GTz);
         hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR);
-        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR);
+        if (sharded) {
+            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
+            S.allreduce(S.RB, 4, 0);
+        }
+        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
         MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
@@ -1482,7 +1542,11 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
                 hipLaunchKernelGGL(k_big_dots, dim3(1), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
                 nb += 1;
             }
-            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode);
+            if (sharded) {
+                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 0);
+                S.allreduce(S.RB, 3, 0);
+            }
+            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, sharded ? 1 : 2);
         };
         auto dir_post = [&](const double* zz2, const double* gg2, double* outA, double* outB, int mode) {
             int nb = std::max(S.nbC, 1);
@@ -1493,7 +1557,11 @@ int Solver::solve(const TrigProgram& Q, const SolveOpts& o, std::vector<double>&
                                    S.scratch, S.partR + 2L * nb, mode);
                 nb += 1;
             }
-            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc);
+            if (sharded) {
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc, S.RB, 0);
+                S.allreduce(S.RB, 2, 1);
+            }
+            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc, S.RB, sharded ? 1 : 2);
         };
         dots(x2a, z2a, 0);
         dir_post(z2a, g2a, S.dssa, S.wdza, 0);

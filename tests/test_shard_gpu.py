@@ -1,0 +1,81 @@
+"""GPU test of the row-sharded solve on ONE GPU: two contexts in one process play rank 0 and rank 1,
+the all-reduce hook is a loop-back (both buffers summed in a fixed order), so the complete sharded
+iteration -- partition, local Gram / G'v / step maxima, reductions, replicated Cholesky -- runs without
+a second GPU.  RCCL itself is exercised by `bench.py --gpus N --mode shard` on a multi-GPU node."""
+import threading
+import warnings
+
+import numpy as np
+import pytest
+from conftest import CASES, relinf
+
+import mbfir
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore", category=RuntimeWarning)
+
+
+def _run_sharded(fn, args, size):
+    import torch
+    torch.zeros(1, device="cuda")                   # initialise torch's HIP context on the main thread
+    ctxs = [mbfir.Context(0) for _ in range(size)]
+    barrier = threading.Barrier(size, timeout=120)
+    slots = [None] * size
+    results = [None] * size
+
+    def make_hook(rank):
+        def hook(ptr, count, op):
+            try:
+                t = mbfir.device_tensor(ptr, count)
+                slots[rank] = t.clone()
+                torch.cuda.synchronize()
+                barrier.wait()
+                stacked = torch.stack(slots)
+                res = stacked.max(0).values if op == 1 else stacked.sum(0)     # same order on every rank
+                torch.cuda.synchronize()
+                barrier.wait()
+                t.copy_(res)
+                torch.cuda.synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                barrier.abort()
+                return 1
+        return hook
+
+    def work(rank):
+        ctxs[rank].set_allreduce(make_hook(rank))
+        opts = mbfir.make_opts(shard_rank=rank, shard_size=size)
+        try:
+            results[rank] = getattr(mbfir, fn)(*args, opts=opts, ctx=ctxs[rank], info=True)
+        except Exception as e:                      # noqa: BLE001
+            results[rank] = e
+            barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for c in ctxs:
+        c.close()
+    return results
+
+
+@pytest.mark.parametrize("name,size", [("ap_c13_64", 2), ("ap_c13_58", 2), ("qp_modelB25", 2), ("lin_cplx32", 3),
+                                       ("qphs21", 2), ("ap_c13_50_infeasible", 2)])
+def test_row_sharded_solve_matches_unsharded(name, size):
+    fn, args = CASES[name]
+    h0, s0, i0 = getattr(mbfir, fn)(*args, info=True)
+    res = _run_sharded(fn, args, size)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for h, s, info in res:
+        assert s == s0
+        if s0 == "Solved":
+            assert relinf(h, h0) <= 1e-6
+            assert abs(info["pcost"] - i0["pcost"]) <= 1e-8 * max(1.0, abs(i0["pcost"]))
+            assert np.array_equal(h, res[0][0])      # every rank returns the same taps, bit for bit
+    assert sum(i["n_freq"] for _, _, i in res) == i0["n_freq"]
+    assert sum(i["n_rows"] for _, _, i in res) == i0["n_rows"]
