@@ -49,21 +49,40 @@ __device__ __forceinline__ void acc_foreach(v4d acc[2][2], F f) {
                 f(wi * 32 + a * 16 + (lane >> 4) + 4 * r, wj * 32 + b * 16 + (lane & 15), acc[a][b][r]);
 }
 
+// 64x64 tile -> LDS, all 8 16-byte loads of a thread in flight before the first LDS store
+// (256-thread blocks)
 __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __restrict__ src, int ld) {
-    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) S[e >> 6][e & 63] = src[(long)(e >> 6) * ld + (e & 63)];
+    double2 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        t[u] = *reinterpret_cast<const double2*>(src + (long)(e >> 5) * ld + 2 * (e & 31));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        *reinterpret_cast<double2*>(&S[e >> 5][2 * (e & 31)]) = t[u];
+    }
 }
 
 // =================================================================================================
-// Right-looking blocked Cholesky that carries M = L^-1 along (two launches per 64-wide panel):
+// Right-looking blocked Cholesky that carries M = L^-1 along, ONE launch per 64-wide panel step.
+// Launch k (k = 0 .. nblk) runs four kinds of workgroups side by side:
 //
-//   step A_k : (a) panel blocks -- every block factorises A_kk in LDS (redundantly, 87 kflop);
-//                  block 0 publishes L_kk (side buffer Dfac), block b>0 solves  L_ik L_kk' = A_ik
-//                  by forward substitution (NOT by multiplying with inv(L_kk): that is not backward
-//                  stable and breaks the factorisation on the near-singular late IPM iterates);
-//              (b) R-update tiles of the previous panel:  M_ij -= L_i,k-1 M_k-1,j   (i >= k, j < k)
-//   step B_k : (a) trailing tiles  A_ij -= L_ik L_jk'   (k < j <= i);
-//              (b) row block k of the inverse:  M_kj = L_kk^-1 R_kj  (j <= k) by forward substitution
-//                  over the 64 columns of each tile (R lives in the M buffer, initialised to I).
+//   P  (panel k)        every block first applies the one outstanding update (panel k-1) to A_kk and
+//                       factorises it in LDS (redundantly, 87 kflop; block 0 publishes L_kk); blocks
+//                       b > 0 then take 16 rows of one tile A_ik, apply the panel k-1 update to them and
+//                       solve  X L_kk' = A_ik  by forward substitution (NOT by multiplying with
+//                       inv(L_kk): that is not backward stable and breaks the factorisation on the
+//                       near-singular late IPM iterates);
+//   T  (trailing)       A_ij -= L_i,k-1 L_j,k-1'   for k < j <= i   (panel k-1; column k is done by P);
+//   MS (inverse row)    row block r = k-1 of the inverse:  M_rj = L_rr^-1 (R_rj - L_r,r-1 M_r-1,j),
+//                       16 columns of one tile per block (R lives in the M buffer, initialised to I);
+//   RU (inverse update) R_ij -= L_i,k-2 M_k-2,j    for i >= k, j <= k-2.
+//
+// So every tile sees its updates in order, each launch only reads what earlier launches wrote, and
+// the dependent chain per panel is  tile product -> potf2 -> substitution  (one launch) instead of
+// two launches with two substitutions.
 // M computed this way has the accuracy of a substitution-based inverse (measured: solve residual
 // 3e-5 at cond(H)=3e9, same as LAPACK trtri; multiplying explicit 64x64 inverses gives 2e-3).
 // Pivot rule: a pivot not above pivtol * H_jj is rounding noise and is replaced by H_jj itself; by
@@ -72,32 +91,19 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
 // =================================================================================================
 typedef double v16d __attribute__((ext_vector_type(16)));   // register-resident 16-vector (an array would go to scratch)
 
-// sum over the 4 lanes of a quad (DPP quad_perm, no LDS traffic)
-__device__ __forceinline__ double quad_sum(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    int lo1 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
-    v += __hiloint2double(hi1, lo1);                      // + lane ^ 1
-    lo = __double2loint(v); hi = __double2hiint(v);
-    lo1 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi1 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
-    return v + __hiloint2double(hi1, lo1);                // + lane ^ 2
-}
-
-// Column permutation used for the LDS images below: column t is stored at position
+// Column permutation of the potf2 broadcast buffer: column t is stored at position
 // perm(t) = (t & 3) * 16 + (t >> 2), so the 16 columns {q, q+4, ...} that one lane needs are
 // contiguous (wide LDS reads, no per-element address math).
 __device__ __forceinline__ int cperm(int t) { return (t & 3) * 16 + (t >> 2); }
-constexpr int SLD = 66;      // row stride of the permuted images (16-byte aligned rows)
-constexpr int PANEL_LDS = 2 * CB * CLD;              // Sp | dsh | dinv | colbuf (panel) or two MFMA tiles
 
-// NOTE on code shape (all measured on MI355X with tools/exp/chol_exp.hip):
-//  * a dependent fp64 VALU op costs ~40 cycles, an LDS round trip ~130, so the per-pivot chain is
-//    what matters; a read-modify-write loop over LDS serialises on that latency because the
-//    compiler cannot prove the arrays disjoint;
-//  * fully unrolling the 64 steps (straight-line code executed once, ~10k instructions) is
-//    instruction-fetch bound and 2x slower still;
-//  * so: operands live in registers with static indices, the outer loop over groups of 4 pivots
-//    is rolled, the 4 steps inside are unrolled, and the one register that must be picked by the
-//    loop counter is selected / put back once per group with wave-uniform compares.
+// NOTE on code shape (all measured on MI355X with tools/exp/*.hip):
+//  * one wave issues an independent v_fma_f64 every ~2.9 ns, a (uniform select + fma) pair costs
+//    18 ns (v_cndmask pairs), a ds_read_b128 costs the CU 13.5 ns whatever the address pattern
+//    (the 128 B/clk return path), a dependent mul -> DPP -> fma chain 22 ns, an LDS store ->
+//    barrier -> load round trip ~110 ns;
+//  * so: no per-element selects (finished rows / columns are masked by ZEROS in the broadcast
+//    images instead), operands in registers with static indices, as few LDS bytes per pivot as
+//    possible, and cross-lane traffic on DPP where the layout allows it.
 __device__ __forceinline__ double sel16(const v16d& v, int idx) {
     double r = v[0];
 #pragma unroll
@@ -109,82 +115,120 @@ __device__ __forceinline__ void put16(v16d& v, int idx, double x) {
     for (int i = 0; i < 16; ++i) v[i] = (i == idx) ? x : v[i];
 }
 
-// Forward substitution  S x = a  for 64 right-hand sides, one per group of 4 adjacent lanes.
-// Lane q (= lane & 3) holds a[t] on entry / x[t] on exit for t = 4 i + q in v[i].
-// Sp is the column-permuted lower-triangular factor in LDS, dinv[j] = 1 / S[j][j].
-// Per group of 4 unknowns: the contribution of all earlier groups ("hist") is formed for the 4 rows
-// at once (64 independent FMAs), then the 4 in-group steps run the short chain
-// term -> quad_sum -> (a - part) * dinv.
-__device__ __forceinline__ void subst64(const double (*Sp)[SLD], const double* dinv, v16d& v) {
-    const int q = threadIdx.x & 3;
-#pragma unroll 1
-    for (int jg = 0; jg < 16; ++jg) {
-        const double acur = sel16(v, jg);                 // a_{4 jg + q}
-        v16d vm;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) vm[i] = (i < jg) ? v[i] : 0.0;
-        double hist0 = 0, hist1 = 0, hist2 = 0, hist3 = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const double* srow = &Sp[4 * jg + jj][q * 16];
-            double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                h0 += vm[i] * srow[i]; h1 += vm[i + 1] * srow[i + 1];
-                h2 += vm[i + 2] * srow[i + 2]; h3 += vm[i + 3] * srow[i + 3];
-            }
-            const double hh = (h0 + h1) + (h2 + h3);
-            if (jj == 0) hist0 = hh; else if (jj == 1) hist1 = hh; else if (jj == 2) hist2 = hh; else hist3 = hh;
+// ---- forward substitution, 16 lanes per right-hand side ----------------------------------------
+// A DPP row (16 lanes) owns one right-hand side: lane lam holds a[t] for t = lam + 16 i in v[i].
+// Right-looking: step j forms x_j = a_j / L_jj in lane j & 15, broadcasts it inside the row with
+// one v_mov_b64_dpp row_newbcast, and every lane updates its (at most 4) later entries.  The
+// factor comes from the zero-padded column image  Lz[j][zpos(t)] = t > j ? L[t][j] : 0, so entries
+// that are already final see a zero and need no predicate; they are scaled by 1 / L_tt at the end.
+// Fully unrolled (64 steps x ~7 instructions).
+constexpr int ZLD = 66;
+__device__ __forceinline__ int zpos(int t) { return ((t >> 5) << 5) + 2 * (t & 15) + ((t >> 4) & 1); }
+
+template <int LANE>
+__device__ __forceinline__ double row_bcast(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + LANE, 0xF, 0xF, true);     // row_newbcast:LANE
+}
+
+template <int J>
+__device__ __forceinline__ void subst16_steps(const double* __restrict__ lz, double dm0, double dm1, double dm2, double dm3,
+                                              double& v0, double& v1, double& v2, double& v3) {
+    if constexpr (J < 64) {
+        constexpr int I = J >> 4;
+        const double cur = I == 0 ? v0 * dm0 : I == 1 ? v1 * dm1 : I == 2 ? v2 * dm2 : v3 * dm3;
+        const double x = row_bcast<(J & 15)>(cur);
+        const double* lr = lz + J * ZLD;
+        if constexpr (I < 2) {
+            const double2 lo = *reinterpret_cast<const double2*>(lr);
+            if constexpr (I == 0) v0 -= x * lo.x;
+            v1 -= x * lo.y;
         }
-        double vn = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * jg + jj;
-            const double term = (q < jj) ? vn * Sp[j][q * 16 + jg] : 0.0;
-            const double hj = jj == 0 ? hist0 : jj == 1 ? hist1 : jj == 2 ? hist2 : hist3;
-            const double part = quad_sum(hj + term);
-            if (q == jj) vn = (acur - part) * dinv[j];
-        }
-        put16(v, jg, vn);
+        const double2 hi = *reinterpret_cast<const double2*>(lr + 32);
+        if constexpr (I < 3) v2 -= x * hi.x;
+        v3 -= x * hi.y;
+        subst16_steps<J + 1>(lz, dm0, dm1, dm2, dm3, v0, v1, v2, v3);
     }
 }
 
+// Lz: image base; dinv[j] = 1 / L_jj.  On entry v[i] = a[lam + 16 i], on exit x[lam + 16 i].
+__device__ __forceinline__ void subst16(const double* __restrict__ Lz, const double* __restrict__ dinv, double (&v)[4]) {
+    const int lam = threadIdx.x & 15;
+    const double dm0 = dinv[lam], dm1 = dinv[lam + 16], dm2 = dinv[lam + 32], dm3 = dinv[lam + 48];
+    double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    subst16_steps<0>(Lz + 2 * lam, dm0, dm1, dm2, dm3, v0, v1, v2, v3);
+    v[0] = v0 * dm0; v[1] = v1 * dm1; v[2] = v2 * dm2; v[3] = v3 * dm3;
+}
+
 // Unblocked right-looking Cholesky of a 64x64 block held in registers: thread (tx = tid & 63,
-// ty = tid >> 6) owns row tx, columns ty + 4 i in rv[i].  Column j is broadcast through the
-// double-buffered, column-permuted LDS vector cb (one barrier per pivot).  Square-root free inner
-// loop (S_ic -= S_ij S_cj / p_j, 1/p from v_rcp_f64 + one Newton step); the pivots go to piv[] and
-// the caller applies L_ij = S_ij / sqrt(p_j) in one parallel pass.  Only the lower triangle of the
-// result is meaningful.
+// ty = tid >> 6) owns row tx, columns ty + 4 i in rv[i].  Column j is broadcast through a
+// triple-buffered, column-permuted LDS vector (one barrier per pivot) with the rows up to the pivot
+// written as zeros, which masks every finished row and column without a select; the pivot itself
+// travels in pd[].  The per-pivot dependent chain is only
+//     read (p, S_tx,j, S_c,j for the column published next) -> 1/p -> scale -> one fma -> publish,
+// the 16-column rank-1 update of pivot j ("bulk") is issued one pivot late, behind the chain's LDS
+// reads of pivot j+1, so its 8 wide LDS reads and 16 fmas overlap the next chain instead of
+// delaying the next publish; the element of the next column group that must be current at the
+// group boundary is carried separately (nxt).  Square-root free (S_ic -= S_ij S_cj / p_j, 1/p from
+// v_rcp_f64 + one Newton step); the pivots go to piv[] and the caller applies
+// L_ij = S_ij / sqrt(p_j) in one parallel pass.  Only the lower triangle of the result is meaningful.
+// colbuf: 3 x 64 column slots + 4 pivot slots (200 doubles).
 __device__ __forceinline__ void potf2_regs(v16d& rv, double* colbuf, const double* dsh, double* piv,
                                            double pivtol, int* flag, bool count) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int ptx = cperm(tx);
+    double* pd = colbuf + 3 * CB;
+    if (threadIdx.x < 3 * CB) colbuf[threadIdx.x] = 0.0;
+    __syncthreads();
+    double cur = rv[0], nxt = 0.0;                        // elements (tx, ty) and (tx, 4 + ty)
+    if (ty == 0) { colbuf[ptx] = tx > 0 ? cur : 0.0; if (tx == 0) pd[0] = cur; }
+    __syncthreads();
+    double a_prev = 0.0;
+    int off_prev = ty * 16, slot = 0, nbad = 0;
 #pragma unroll 1
     for (int jg = 0; jg < 16; ++jg) {
-        double cur = sel16(rv, jg);                       // element (tx, 4 jg + ty)
+        const int jg1 = (jg + 1) & 15;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int j = 4 * jg + jj;
-            double* cb = colbuf + (jj & 1) * CB;
-            if (ty == jj) cb[ptx] = cur;                  // publish column j of the Schur complement
-            __syncthreads();
-            double p = cb[jj * 16 + jg];                  // cperm(j)
+            const double* cb = colbuf + slot * CB;
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            double* cbn = colbuf + nslot * CB;
+            // chain operands first, then the late bulk operands of pivot j-1
+            double p = pd[slot];
             const double dj = dsh[j];
-            if (!(p > pivtol * dj)) {
-                if (count && threadIdx.x == 0) atomicAdd(flag, 1);
-                p = fmax(dj, 1e-300);
-            }
+            const double asrc = cb[ptx];
+            const double mjg = cb[ty * 16 + jg];          // S_cj, c = ty + 4 jg (0 unless c > j)
+            const double mj1 = cb[ty * 16 + jg1];         // S_cj, c = ty + 4 (jg + 1)
+#ifndef POTF2_EXP_NOBULK
+            const v16d mp = *reinterpret_cast<const v16d*>(colbuf + off_prev);
+#else
+            v16d mp; for (int i = 0; i < 16; ++i) mp[i] = mj1;
+#endif
+            const bool bad = !(p > pivtol * dj);
+            p = bad ? fmax(dj, 1e-300) : p;
+            nbad += bad;
             double rcp = __builtin_amdgcn_rcp(p);         // ~26 bits
             rcp = rcp * fma(-p, rcp, 2.0);                // 1/p to rounding
-            const double a = cb[ptx] * rcp;
-            const double* mine = cb + ty * 16;            // elements (c, j), c = ty + 4 i
-            if (ty > jj) cur -= a * mine[jg];             // this thread's element of column group jg
-#pragma unroll
-            for (int i = 0; i < 16; ++i) rv[i] -= ((i > jg) ? a : 0.0) * mine[i];
+            const double a = asrc * rcp;                  // 0 for the rows up to the pivot
+            cur -= a * mjg;
+            if (jj >= 2) nxt -= a * mj1;
+            if (jj < 3) {
+                if (ty == jj + 1) { cbn[ptx] = tx > j + 1 ? cur : 0.0; if (tx == j + 1) pd[nslot] = cur; }
+            } else {
+                if (ty == 0) { cbn[ptx] = tx > j + 1 ? nxt : 0.0; if (tx == j + 1) pd[nslot] = nxt; }
+            }
             if (ty == jj && tx == j) { cur = p; piv[j] = p; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rv[i] -= a_prev * mp[i];    // rank-1 update of pivot j-1
+            if (jj == 1) { nxt = sel16(rv, jg1); nxt -= a * mj1; }   // slot jg+1 is now current through pivot 4 jg
+            a_prev = a; off_prev = slot * CB + ty * 16; slot = nslot;
+            __syncthreads();
         }
         put16(rv, jg, cur);
+        cur = nxt;
     }
+    if (count && threadIdx.x == 0 && nbad) atomicAdd(flag, nbad);
 }
 
 __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
@@ -208,38 +252,79 @@ __device__ __forceinline__ void tile_update(double* smem, const double* __restri
     acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
 }
 
-__global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
-                                                    int k, const double* __restrict__ d0, double pivtol,
-                                                    double* __restrict__ Dfac, int* __restrict__ flag) {
-    __shared__ __attribute__((aligned(16))) double smem[PANEL_LDS];
-    const int tid = threadIdx.x;
-    const int npanel = nblk - k;
-    if ((int)blockIdx.x >= npanel) {
-        // (b) R-update of panel k-1:  M_ij -= L_i,k-1 * M_k-1,j   for i >= k, j < k
-        const int t = blockIdx.x - npanel;
-        const int i = k + t / k, j = t % k;
-        const long km = (long)(k - 1) * CB;
-        tile_update<false>(smem, H + (long)i * CB * np + km, M + km * np + (long)j * CB,
-                           M + (long)i * CB * np + (long)j * CB, np);
-        return;
-    }
-    // (a) panel
-    double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
-    double* dsh = smem + CB * SLD;                        // original diagonal of this block (64)
-    double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
-    double* colbuf = dinv + CB;                           // 2 x 64
+#ifdef CHOL_TRACE
+__device__ long long g_trace[16 * 32];
+#define TRACE(slot) if (threadIdx.x == 0 && b == 1) g_trace[a.k * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TRACE(slot)
+#endif
+
+struct CholStep {
+    double* H; double* M; int np, nblk, k;
+    const double* d0; double pivtol;
+    double* Dfac;            // per panel: 64x64 zero-padded column image of L_kk (see subst16)
+    double* dinvG;           // 1 / diag(L)
+    int* flag;
+    int nP, nMS, nT;
+};
+
+constexpr int YLD = 65;                                  // staging tiles that are read one row per lane
+constexpr int R0 = 0, R1 = CB * CLD, R2 = 2 * CB * CLD, R3 = R2 + 1152;
+constexpr int STEP_LDS = R3 + 336;                       // 79.4 KB
+
+__device__ __forceinline__ void panel_block(const CholStep& a, int b, double* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k = a.k, np = a.np;
+    double* H = a.H;
     const long kk = (long)k * CB;
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the image of L_kk
+    double* Y = smem + R1;                                             // staging (stride YLD)
+    double(*AR)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R2);    // 16 rows of L_i,k-1
+    double* dsh = smem + R3;                              // original diagonal of this block (64)
+    double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
+    double* colbuf = dinv + CB;                           // 3 x 64 + 4 (16-byte aligned)
+    const bool rows = b > 0;
+    const long r0 = rows ? (long)(k + 1 + (b - 1) / 4) * CB + 16 * ((b - 1) & 3) : 0;
+    v4d accS[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    v4d accC = {0, 0, 0, 0};
+    TRACE(0)
+    if (k > 0) {
+        const long km = kk - CB;
+        load_block(X, H + kk * np + km, np);
+        if (rows) {
+            const double2 t0 = *reinterpret_cast<const double2*>(H + (r0 + (tid >> 5)) * np + km + 2 * (tid & 31));
+            const double2 t1 = *reinterpret_cast<const double2*>(H + (r0 + 8 + (tid >> 5)) * np + km + 2 * (tid & 31));
+            *reinterpret_cast<double2*>(&AR[tid >> 5][2 * (tid & 31)]) = t0;
+            *reinterpret_cast<double2*>(&AR[8 + (tid >> 5)][2 * (tid & 31)]) = t1;
+        }
+        __syncthreads();
+        TRACE(1)
+        mma64<true>(X, X, 0, CB, accS);
+        if (rows) {
+#pragma unroll 4
+            for (int k0 = 0; k0 < CB; k0 += 4) {
+                const int kx = k0 + (lane >> 4);
+                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(AR[lane & 15][kx], X[16 * wv + (lane & 15)][kx], accC, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    TRACE(2)
+    acc_foreach(accS, [&](int r, int c, double v) { Y[r * YLD + c] = H[(kk + r) * np + kk + c] - v; });
+    if (tid < CB) dsh[tid] = a.d0[kk + tid];
+    __syncthreads();
     const int tx = tid & 63, ty = tid >> 6;
     v16d rv;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int c = ty + 4 * i;
-        rv[i] = c <= tx ? H[(kk + tx) * np + kk + c] : 0.0;
+        rv[i] = c <= tx ? Y[tx * YLD + c] : 0.0;
     }
-    if (tid < CB) dsh[tid] = d0[kk + tid];
     __syncthreads();
-    potf2_regs(rv, colbuf, dsh, dinv, pivtol, flag, blockIdx.x == 0);
+    TRACE(3)
+    potf2_regs(rv, colbuf, dsh, dinv, a.pivtol, a.flag, b == 0);
     __syncthreads();
+    TRACE(4)
     if (tid < CB) {                                       // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
         const double p = dinv[tid];
         double y = __builtin_amdgcn_rsq(p);
@@ -248,60 +333,119 @@ __global__ __launch_bounds__(256) void k_chol_stepA(double* __restrict__ H, doub
         dinv[tid] = y;
     }
     __syncthreads();
+    double* Lz = smem + R0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {                        // L_ij = S_ij / sqrt(p_j), image position cperm(c)
+    for (int i = 0; i < 16; ++i) {                        // L_tc = S_tc / sqrt(p_c), strictly lower part
         const int c = ty + 4 * i;
-        Sp[tx][ty * 16 + i] = c <= tx ? rv[i] * dinv[c] : 0.0;
+        Lz[c * ZLD + zpos(tx)] = tx > c ? rv[i] * dinv[c] : 0.0;
+    }
+    if (rows) {                                           // updated rows of A_ik (MFMA layout -> one row per DPP row)
+        const int cc = 16 * wv + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = (lane >> 4) + 4 * r;
+            Y[rr * YLD + cc] = H[(r0 + rr) * np + kk + cc] - accC[r];
+        }
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        // L_kk goes to a side buffer: the other blocks of this launch may still be reading A_kk from H
-        for (int e = tid; e < CB * CB; e += 256) Dfac[kk * CB + e] = Sp[e >> 6][cperm(e & 63)];
+    if (!rows) {
+        for (int e = tid; e < CB * CB; e += 256) a.Dfac[kk * CB + e] = Lz[(e >> 6) * ZLD + (e & 63)];
+        if (tid < CB) a.dinvG[kk + tid] = dinv[tid];
         return;
     }
-    // rows of A_ik:  X L_kk' = A_ik  <=>  L_kk x_r' = a_r'   (rhs r = tid / 4, lane q holds t = 4 i + q)
-    const long ii = (long)(k + blockIdx.x) * CB;
-    const int r = tid >> 2, q = tid & 3;
-    double* row = H + (ii + r) * np + kk;
-    v16d v;
+    const int rho = tid >> 4, lam = tid & 15;
+    double v[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = row[4 * i + q];
-    subst64(Sp, dinv, v);
+    for (int i = 0; i < 4; ++i) v[i] = Y[rho * YLD + lam + 16 * i];
+    TRACE(5)
+    subst16(Lz, dinv, v);
+    TRACE(6)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) row[4 * i + q] = v[i];
+    for (int i = 0; i < 4; ++i) H[(r0 + rho) * np + kk + lam + 16 * i] = v[i];
+    TRACE(7)
 }
 
-__global__ __launch_bounds__(256) void k_chol_stepB(double* __restrict__ H, double* __restrict__ M, int np, int nblk,
-                                                    int k, const double* __restrict__ Dfac) {
-    __shared__ __attribute__((aligned(16))) double smem[PANEL_LDS];
-    const int tid = threadIdx.x;
-    const int nrem = nblk - k - 1;
-    const int ntrail = nrem * (nrem + 1) / 2;
-    const long kk = (long)k * CB;
-    if ((int)blockIdx.x < ntrail) {
-        // (a) trailing update  A_ij -= L_ik L_jk'
+__device__ __forceinline__ void minv_block(const CholStep& a, int b, double* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int np = a.np, r = a.k - 1, j = b >> 2, c0 = 16 * (b & 3);
+    const long kr = (long)r * CB;
+    double* M = a.M;
+    double* Lz = smem + R0;
+    double(*A2)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_r,r-1
+    double(*Bs)[17] = reinterpret_cast<double(*)[17]>(smem + R2);      // 16 columns of M_r-1,j
+    double* Ct = smem + R1;                                            // staging [column][row], stride YLD
+    double* dinv = smem + R3;
+    {
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const double2*>(a.Dfac + kr * CB + 2 * (tid + 256 * u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+        }
+    }
+    if (tid < CB) dinv[tid] = a.dinvG[kr + tid];
+    v4d acc = {0, 0, 0, 0};
+    if (j < r) {
+        load_block(A2, a.H + kr * np + kr - CB, np);
+        {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; t[u] = M[(kr - CB + (e >> 4)) * np + (long)j * CB + c0 + (e & 15)]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; Bs[e >> 4][e & 15] = t[u]; }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k0 = 0; k0 < CB; k0 += 4) {
+            const int kx = k0 + (lane >> 4);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    {
+        const int c = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 16 * wv + (lane >> 4) + 4 * q;
+            Ct[c * YLD + t] = M[(kr + t) * np + (long)j * CB + c0 + c] - acc[q];
+        }
+    }
+    __syncthreads();
+    const int rho = tid >> 4, lam = tid & 15;
+    double v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = Ct[rho * YLD + lam + 16 * i];
+    subst16(Lz, dinv, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Ct[rho * YLD + lam + 16 * i] = v[i];
+    __syncthreads();
+    const int t = tid >> 2, c4 = (tid & 3) * 4;
+    double* dst = M + (kr + t) * np + (long)j * CB + c0 + c4;
+    *reinterpret_cast<double2*>(dst) = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]);
+    *reinterpret_cast<double2*>(dst + 2) = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    int b = blockIdx.x;
+    if (b < a.nP) { panel_block(a, b, smem); return; }
+    b -= a.nP;
+    if (b < a.nMS) { minv_block(a, b, smem); return; }
+    b -= a.nMS;
+    const int k = a.k, np = a.np;
+    if (b < a.nT) {                                       // trailing update with panel k-1, columns > k
         int ti, tj;
-        tile_decode(blockIdx.x, ti, tj);
-        const long i0 = (long)(k + 1 + ti) * CB, j0 = (long)(k + 1 + tj) * CB;
-        tile_update<true>(smem, H + i0 * np + kk, H + j0 * np + kk, H + i0 * np + j0, np);
+        tile_decode(b, ti, tj);
+        const long i0 = (long)(k + 1 + ti) * CB, j0 = (long)(k + 1 + tj) * CB, km = (long)(k - 1) * CB;
+        tile_update<true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
         return;
     }
-    // (b) M_kj = L_kk^-1 R_kj : column c = tid / 4 of the tile is one right-hand side
-    const int j = blockIdx.x - ntrail;
-    double(*Sp)[SLD] = reinterpret_cast<double(*)[SLD]>(smem);
-    double* dinv = smem + CB * SLD;
-    for (int e = tid; e < CB * CB; e += 256) Sp[e >> 6][cperm(e & 63)] = Dfac[kk * CB + e];
-    __syncthreads();
-    if (tid < CB) dinv[tid] = 1.0 / Sp[tid][cperm(tid)];
-    __syncthreads();
-    const int c = tid >> 2, q = tid & 3;
-    double* col = M + kk * np + (long)j * CB + c;
-    v16d v;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = col[(long)(4 * i + q) * np];
-    subst64(Sp, dinv, v);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) col[(long)(4 * i + q) * np] = v[i];
+    b -= a.nT;                                            // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2)
+    const int i = k + b / (k - 1), j = b % (k - 1);
+    const long mm = (long)(k - 2) * CB;
+    tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np);
 }
 
 __global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M) {
@@ -309,13 +453,15 @@ __global__ void k_diag_copy(const double* __restrict__ H, int np, double* __rest
     if (j < np) { d0[j] = H[(long)j * np + j]; M[(long)j * np + j] = 1.0; }      // R starts as the identity
 }
 
-// L (np x np, clean lower triangle) from the factored H and the diagonal-block side buffer
-__global__ void k_extract_L(const double* __restrict__ H, int np, const double* __restrict__ Dfac, double* __restrict__ Lout) {
+// L (np x np, clean lower triangle) from the factored H and the diagonal-block images
+__global__ void k_extract_L(const double* __restrict__ H, int np, const double* __restrict__ Dfac,
+                            const double* __restrict__ dinvG, double* __restrict__ Lout) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)np * np) return;
     long i = e / np, j = e - i * np;
     double v = 0.0;
-    if (j <= i) v = ((i / CB) == (j / CB)) ? Dfac[(i / CB) * CB * CB + (i % CB) * CB + (j % CB)] : H[e];
+    if (j == i) v = 1.0 / dinvG[i];
+    else if (j < i) v = ((i / CB) == (j / CB)) ? Dfac[(i / CB) * CB * CB + (j % CB) * CB + zpos(int(i % CB))] : H[e];
     Lout[e] = v;
 }
 
@@ -330,19 +476,24 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
                      double* Lcopy) {
     const int nblk = np / CB;
-    const double pivtol = 1e-13;                 // oracle/conic_ipm.py PIVTOL
-    // W1 layout: np doubles: original diagonal | 64 np doubles: L_kk blocks
-    double* d0 = W1;
-    double* Dfac = W1 + np;
+    // W1 layout: np doubles: original diagonal | 64 np doubles: images of the L_kk blocks | np: 1 / diag(L)
+    CholStep a;
+    a.H = H; a.M = M; a.np = np; a.nblk = nblk;
+    a.d0 = W1; a.Dfac = W1 + np; a.dinvG = W1 + (long)(CB + 1) * np; a.flag = flag;
+    a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
     hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
     hipMemsetAsync(flag, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, d0, M);
-    for (int k = 0; k < nblk; ++k) {
-        const int npanel = nblk - k, nrem = nblk - k - 1;
-        hipLaunchKernelGGL(k_chol_stepA, dim3(npanel + npanel * k), dim3(256), 0, st, H, M, np, nblk, k, d0, pivtol, Dfac, flag);
-        hipLaunchKernelGGL(k_chol_stepB, dim3(nrem * (nrem + 1) / 2 + k + 1), dim3(256), 0, st, H, M, np, nblk, k, Dfac);
+    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, W1, M);
+    for (int k = 0; k <= nblk; ++k) {
+        const int nrem = nblk - k - 1;
+        a.k = k;
+        a.nP = k < nblk ? 1 + 4 * nrem : 0;
+        a.nMS = k >= 1 ? 4 * k : 0;
+        a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
+        const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
+        hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU), dim3(256), 0, st, a);
     }
-    if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, Dfac, Lcopy);
+    if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
     hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32), dim3(32, 8), 0, st, M, Mt, np);
 }
 

@@ -83,7 +83,7 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 
 // Cholesky + inverse of the Cholesky factor.  H is np x np row-major (np multiple of 64), lower
 // triangle referenced; on exit M = L^-1 (lower), Mt = M'.
-// W1 is a workspace of 65*np doubles.  flag[0] counts replaced (noise-level) pivots.
+// W1 is a workspace of 66*np doubles.  flag[0] counts replaced (noise-level) pivots.
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
                      double* Lcopy = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 

@@ -1,31 +1,50 @@
-// Experiment: time the individual Cholesky kernels (events) for N = 1024.
+// Experiment: correctness + time of the Cholesky/inverse launch sequence for N = 1024 (and others).
+#define CHOL_TRACE 1
 #include "../../multiband-rf-pulse-design_amd/csrc/chol.hip"
 #include <vector>
+#include <cmath>
 using namespace mbfir;
-int main() {
-    const int np = 1024, nblk = 16;
-    std::vector<double> H(np * (size_t)np);
+int main(int argc, char** argv) {
+    const int np = argc > 1 ? atoi(argv[1]) : 1024;
+    std::vector<double> H(np * (size_t)np), L(np * (size_t)np), M(np * (size_t)np);
     for (int i = 0; i < np; ++i) for (int j = 0; j < np; ++j) H[i * (size_t)np + j] = 1.0 / (1.0 + abs(i - j)) + (i == j ? 2.0 : 0.0);
-    double *dH, *dH0, *dM, *dW; int* df;
-    hipMalloc(&dH, np * np * 8); hipMalloc(&dH0, np * np * 8); hipMalloc(&dM, np * np * 8); hipMalloc(&dW, (np * np + 65 * np) * 8); hipMalloc(&df, 16);
+    double *dH, *dH0, *dM, *dMt, *dW, *dL; int* df;
+    hipMalloc(&dH, np * np * 8); hipMalloc(&dH0, np * np * 8); hipMalloc(&dM, np * np * 8); hipMalloc(&dMt, np * np * 8); hipMalloc(&dL, np * np * 8);
+    hipMalloc(&dW, (np * np + 66 * np) * 8); hipMalloc(&df, 16);
     hipMemcpy(dH0, H.data(), np * np * 8, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    double* d0 = dW; double* Dfac = dW + np;
-    for (int rep = 0; rep < 2; ++rep) {
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dH, dH0, np * np * 8, hipMemcpyDeviceToDevice);
-        hipMemset(dM, 0, np * np * 8);
-        hipLaunchKernelGGL(k_diag_copy, dim3(4), dim3(256), 0, 0, dH, np, d0, dM);
-        for (int k = 0; k < nblk; ++k) {
-            const int npanel = nblk - k, nrem = nblk - k - 1;
-            float a, b;
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(k_chol_stepA, dim3(npanel + npanel * k), dim3(256), 0, 0, dH, dM, np, nblk, k, d0, 1e-13, Dfac, df);
-            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&a, e0, e1);
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(k_chol_stepB, dim3(nrem * (nrem + 1) / 2 + k + 1), dim3(256), 0, 0, dH, dM, np, nblk, k, Dfac);
-            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&b, e0, e1);
-            if (rep == 1) printf("k=%2d stepA(%3d blocks) %.1f us   stepB(%3d blocks) %.1f us\n", k, npanel + npanel * k, a * 1e3, nrem * (nrem + 1) / 2 + k + 1, b * 1e3);
+        hipEventRecord(e0);
+        chol_inv_launch(dH, dM, dMt, dW, np, df, 0, rep == 2 ? dL : nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("rep %d: %.1f us (%s)\n", rep, ms * 1e3, hipGetErrorString(hipGetLastError()));
+    }
+    hipMemcpy(L.data(), dL, np * np * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(M.data(), dM, np * np * 8, hipMemcpyDeviceToHost);
+    double e1m = 0, e2m = 0;
+    for (int i = 0; i < np; i += 7) for (int j = 0; j <= i; j += 3) {
+        double s = 0; for (int k = 0; k <= j; ++k) s += L[i * (size_t)np + k] * L[j * (size_t)np + k];
+        e1m = fmax(e1m, fabs(s - H[i * (size_t)np + j]));
+        double t = 0; for (int k = j; k <= i; ++k) t += M[i * (size_t)np + k] * L[k * (size_t)np + j];
+        e2m = fmax(e2m, fabs(t - (i == j ? 1.0 : 0.0)));
+    }
+    long long tr[512]; hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr));
+    for (int k : {1, 5, 10}) { printf("k=%d (10 ns ticks):", k); for (int s = 1; s < 8; ++s) printf(" %lld", tr[k * 16 + s] - tr[k * 16 + s - 1]); printf("\n"); }
+    {   // per-launch time
+        hipMemcpy(dH, dH0, np * np * 8, hipMemcpyDeviceToDevice);
+        CholStep a; a.H = dH; a.M = dM; a.np = np; a.nblk = np / 64; a.d0 = dW; a.Dfac = dW + np; a.dinvG = dW + 65L * np; a.flag = df; a.pivtol = 1e-13;
+        for (int k = 0; k <= a.nblk; ++k) {
+            const int nblk = a.nblk, nrem = nblk - k - 1; a.k = k;
+            a.nP = k < nblk ? 1 + 4 * nrem : 0; a.nMS = k >= 1 ? 4 * k : 0; a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
+            const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
+            hipEventRecord(e0); hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU), dim3(256), 0, 0, a); hipEventRecord(e1);
+            hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("k=%2d P %2d MS %2d T %3d RU %3d : %.1f us\n", k, a.nP, a.nMS, a.nT, nRU, ms * 1e3);
         }
     }
+    int flag; hipMemcpy(&flag, df, 4, hipMemcpyDeviceToHost);
+    printf("np %d: max |LL'-H| %.2e  max |ML-I| %.2e  flag %d\n", np, e1m, e2m, flag);
     return 0;
 }
