@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--grid-m", type=int, default=16384)
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch")
     ap.add_argument("--cpu-iters", type=int, default=8, help="oracle iterations for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--dense", action="store_true", help="materialised trig matrix + dense MFMA Gram (opts.dense_trig) "
+                    "instead of the default lattice (matrix-free) mode")
     args = ap.parse_args()
 
     import torch
@@ -95,9 +97,9 @@ def main():
         # ONE design, its frequency rows split over the ranks; per iteration RCCL all-reduces the
         # normal matrix, every G'v and the step / residual scalars (mbfir_set_allreduce hook)
         ctx.set_allreduce(mbfir.make_torch_allreduce())
-        opts = mbfir.make_opts(grid_m=args.grid_m, shard_rank=rank, shard_size=world)
+        opts = mbfir.make_opts(grid_m=args.grid_m, shard_rank=rank, shard_size=world, dense_trig=int(args.dense))
     else:
-        opts = mbfir.make_opts(grid_m=args.grid_m)
+        opts = mbfir.make_opts(grid_m=args.grid_m, dense_trig=int(args.dense))
 
     def step():
         h, status, info = mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)
@@ -125,14 +127,49 @@ def main():
 
     if rank == 0:
         iters = sum(i["iters"] for i in infos)
-        launches = sum(i["gram_launches"] for i in infos)
+        builds = sum(i["builds"] for i in infos)
         gram_ms = sum(i["ms_gram"] for i in infos)
-        flop_per_launch = infos[0]["gram_flop"] / max(1, infos[0]["gram_launches"] // max(1, infos[0]["iters"] + 1))
-        ach = flop_per_launch / (gram_ms / launches * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+        chol_ms = sum(i["ms_chol"] for i in infos)
+        chol_launches = sum(i["chol_launches"] for i in infos)
+        lattice = bool(infos[0]["lattice"])
         try:
             peak_mfma, peak_valu = mbfir.mfma_peak(ctx)
         except Exception:
             peak_mfma = peak_valu = float("nan")
+        # k_chol_step: one launch per 64-wide panel step of the Cholesky + triangular inverse; the
+        # algorithmic flop of a build (2/3 np^3) spread over its np/64 + 1 launches
+        chol_flop_per_launch = infos[0]["chol_flop"] * builds / max(1, chol_launches)
+        chol_avg_ms = chol_ms / max(1, chol_launches)
+        chol_ach = chol_flop_per_launch / (chol_avg_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
+        roof_chol = {"kernel": "k_chol_step (blocked Cholesky + triangular inverse, one launch per 64-wide panel; tile "
+                               "products on v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": chol_ach,
+                     "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": chol_ach / PEAK_FP64_MATRIX_TF, "traffic": None,
+                     "flop_per_launch": chol_flop_per_launch, "launches": chol_launches, "avg_launch_ms": chol_avg_ms,
+                     "note": "dependency-chain bound, not throughput bound: 1024 sequential pivots per build, ~0.29 us each "
+                             "(LDS broadcast + barrier + reciprocal per pivot); see DESIGN.md",
+                     "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
+                     "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu}
+        # normal-matrix products: dense mode = k_gram on the matrix cores; lattice mode = moment recurrences on the VALU
+        gram_flop = infos[0]["gram_flop"]
+        if lattice:
+            gram_ach = gram_flop * builds / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+            roof_gram = {"kernel": "k_trig_moments + fold + k_assemble_H_lat (normal matrix from trigonometric moments, fp64 VALU)",
+                         "bound": "valu", "achieved": gram_ach, "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s",
+                         "frac": gram_ach / PEAK_FP64_MATRIX_TF, "traffic": None, "flop_per_build": gram_flop, "builds": builds,
+                         "avg_build_ms": gram_ms / max(1, builds),
+                         "note": "replaces the dense Gram products (17.2 GFLOP per build on the matrix cores) by "
+                                 "%.2f GFLOP of recurrences; peak = fp64 vector peak (same figure as the matrix peak)" % (gram_flop / 1e9)}
+        else:
+            launches = sum(i["gram_launches"] for i in infos)
+            flop_per_launch = gram_flop / max(1, infos[0]["gram_launches"] // max(1, infos[0]["builds"]))
+            gram_ach = flop_per_launch / (gram_ms / max(1, launches) * 1e-3) / 1e12 if gram_ms > 0 else 0.0
+            roof_gram = {"kernel": "k_gram (A' D A, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": gram_ach,
+                         "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": gram_ach / PEAK_FP64_MATRIX_TF,
+                         "traffic": None, "flop_per_launch": flop_per_launch, "launches": launches,
+                         "avg_launch_ms": gram_ms / max(1, launches),
+                         "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
+                         "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu}
+        dominant, other = (roof_chol, roof_gram) if chol_ms >= gram_ms else (roof_gram, roof_chol)
         out = {
             "metric": "FIR designs/sec, n=%d taps m=%d arbitrary-phase SOCP (fir_ap_cvx form)" % (args.n, args.grid_m),
             "value": (1 if shard else world) * args.steps / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
@@ -141,22 +178,18 @@ def main():
             "config": {"workload": "S-C13 bSSFP 5-band spec, fixed-duration regime, fir_ap_cvx(n=%d, obj=0.1, Peak=1e-3), "
                                    "grid_m=%d (+10 band edges), one design per rank per step" % (args.n, args.grid_m),
                        "n_taps": args.n, "grid_m": args.grid_m, "unknowns": infos[0]["n_unknowns"], "rows": infos[0]["n_rows"],
-                       "mode": args.mode,
+                       "mode": args.mode, "trig": "lattice (matrix-free)" if lattice else "dense (materialised trig matrix, MFMA Gram)",
                        "parallelism": ("frequency rows of one design sharded x%d, RCCL all-reduce per iteration" % world) if shard
                        else "independent designs x%d" % world},
             "ipm_iters_per_design": iters / args.steps,
             "ipm_iters_per_s": (1 if shard else world) * iters / elapsed,
             "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / args.steps,
                                         "solve": sum(i["ms_solve"] for i in infos) / args.steps,
-                                        "gram_kernel": gram_ms / args.steps,
-                                        "cholesky_inverse": sum(i["ms_chol"] for i in infos) / args.steps,
+                                        "normal_matrix": gram_ms / args.steps,
+                                        "cholesky_inverse": chol_ms / args.steps,
                                         "spectral_factor": sum(i["ms_post"] for i in infos) / args.steps},
-            "roofline": {"kernel": "k_gram (A' D A, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
-                         "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MATRIX_TF,
-                         "traffic": None, "flop_per_launch": flop_per_launch, "launches": launches,
-                         "avg_launch_ms": gram_ms / max(1, launches),
-                         "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
-                         "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu},
+            "roofline": dominant,
+            "roofline_other": [other],
         }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(args.n, args.grid_m, int(round(iters / args.steps)), args.cpu_iters)

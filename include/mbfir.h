@@ -60,6 +60,10 @@ typedef struct mbfir_opts {
     int verbose;       /* 1: one line per IPM iteration on stderr                               */
     int shard_rank;    /* frequency-row sharding (multi-GPU): this process's rank ...           */
     int shard_size;    /* ... out of shard_size (0 or 1 = not sharded)                          */
+    int dense_trig;    /* 0: use the lattice structure of the trig columns / frequency grid when it
+                          is there (no trig matrix, moments instead of the dense Gram products);
+                          1: always materialise the trig matrix and use the dense MFMA Gram kernel */
+    int reserved_;
 } mbfir_opts;
 
 /* Per-solve report. */
@@ -72,11 +76,18 @@ typedef struct mbfir_info {
     int n_lp, n_q3, n_big;
     double pcost, dcost, gap, relgap, pres, dres;
     double ms_assemble, ms_solve, ms_post, ms_total;   /* host wall-clock */
-    double ms_gram;      /* device time of the k_gram launches alone (HIP events on the solver stream), summed */
-    double ms_chol;      /* device time of the Cholesky + inverse phase, summed                              */
-    double gram_flop;    /* algorithmic flop of the k_gram launches of ONE build: nw * Mf * Nt * (Nt+1)      */
-    int gram_launches;   /* k_gram launches behind ms_gram (= builds * nw; builds = iterations + 1)          */
-    int reserved_;
+    double ms_gram;      /* device time (HIP events on the solver stream), summed over the builds, of the
+                            normal-matrix products: dense mode = the k_gram launches alone; lattice mode =
+                            moment kernels + fold + H assembly                                          */
+    double ms_chol;      /* device time of the k_chol_step launches (Cholesky + inverse), summed          */
+    double gram_flop;    /* algorithmic flop of ONE build: dense nw * Mf * Nt * (Nt+1); lattice: the
+                            moment recurrences, (3 D - 1) * Mf * (4 + 4 nw)                              */
+    int gram_launches;   /* k_gram launches behind ms_gram (= builds * nw; builds = iterations + 1); 0 in
+                            lattice mode                                                                */
+    int lattice;         /* 1 if the solve ran in lattice (matrix-free) mode                             */
+    double chol_flop;    /* flop of one factorisation + triangular inverse: 2/3 np^3                      */
+    int chol_launches;   /* k_chol_step launches behind ms_chol (= builds * (np/64 + 1))                  */
+    int builds;          /* normal-matrix builds (= iterations + 1)                                       */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to

@@ -37,7 +37,8 @@ class Opts(C.Structure):
     """struct mbfir_opts (include/mbfir.h)."""
     _fields_ = [("grid_m", C.c_int), ("max_iter", C.c_int), ("feastol", C.c_double),
                 ("abstol", C.c_double), ("reltol", C.c_double), ("refine", C.c_int),
-                ("verbose", C.c_int), ("shard_rank", C.c_int), ("shard_size", C.c_int)]
+                ("verbose", C.c_int), ("shard_rank", C.c_int), ("shard_size", C.c_int),
+                ("dense_trig", C.c_int), ("reserved_", C.c_int)]
 
 
 class Info(C.Structure):
@@ -48,7 +49,8 @@ class Info(C.Structure):
                 ("pres", C.c_double), ("dres", C.c_double),
                 ("ms_assemble", C.c_double), ("ms_solve", C.c_double), ("ms_post", C.c_double),
                 ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
-                ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("reserved_", C.c_int)]
+                ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("lattice", C.c_int),
+                ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -37,6 +37,7 @@ SolveOpts to_opts(const mbfir_opts* o) {
     s.verbose = o->verbose;
     s.shard_rank = o->shard_rank;
     s.shard_size = o->shard_size;
+    s.dense_trig = o->dense_trig != 0;
     return s;
 }
 
@@ -62,7 +63,9 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->ms_assemble = (t_asm - t0) + si.ms_assemble; info->ms_solve = si.ms_solve;
     info->ms_post = t_end - t_solved; info->ms_total = t_end - t0;
     info->ms_gram = si.ms_gram; info->ms_chol = si.ms_chol; info->gram_flop = si.gram_flop;
-    info->gram_launches = si.h_builds * (P.quad ? 3 : 1);
+    info->gram_launches = si.lattice ? 0 : si.h_builds * (P.quad ? 3 : 1);
+    info->lattice = si.lattice;
+    info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
 }
 
 // Common driver: `asm_rc` is the assembly result, `post` maps the solution vector to taps.

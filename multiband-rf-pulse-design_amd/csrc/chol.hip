@@ -474,7 +474,7 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
 }
 
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy) {
+                     double* Lcopy, hipEvent_t e0, hipEvent_t e1) {
     const int nblk = np / CB;
     // W1 layout: np doubles: original diagonal | 64 np doubles: images of the L_kk blocks | np: 1 / diag(L)
     CholStep a;
@@ -484,6 +484,7 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
     hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
     hipMemsetAsync(flag, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, W1, M);
+    if (e0) hipEventRecord(e0, st);
     for (int k = 0; k <= nblk; ++k) {
         const int nrem = nblk - k - 1;
         a.k = k;
@@ -493,6 +494,7 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
         const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
         hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU), dim3(256), 0, st, a);
     }
+    if (e1) hipEventRecord(e1, st);
     if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
     hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32), dim3(32, 8), 0, st, M, Mt, np);
 }

@@ -84,8 +84,9 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 // Cholesky + inverse of the Cholesky factor.  H is np x np row-major (np multiple of 64), lower
 // triangle referenced; on exit M = L^-1 (lower), Mt = M'.
 // W1 is a workspace of 66*np doubles.  flag[0] counts replaced (noise-level) pivots.
+// e0 / e1 (optional) are recorded right before / after the np/64 + 1 k_chol_step launches.
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
+                     double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
 // y[v] = Lo * b[v] for a row-major lower (upper=0) or upper (upper=1) triangular np x np matrix.
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,

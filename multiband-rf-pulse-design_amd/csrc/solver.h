@@ -14,6 +14,7 @@ struct SolveOpts {
     int refine = 2;
     int verbose = 0;
     int shard_rank = 0, shard_size = 1;     // frequency-row sharding (one process per GPU)
+    bool dense_trig = false; // keep the materialised trig matrix and the dense MFMA Gram even when the lattice structure is there
     bool timing = true;     // HIP-event timing of the k_gram launches and the Cholesky phase (events read at the end)
 };
 
@@ -22,6 +23,9 @@ struct SolveInfo {
     double pcost = 0, dcost = 0, gap = 0, relgap = 0, pres = 0, dres = 0;
     double ms_assemble = 0, ms_solve = 0, ms_gram = 0, ms_chol = 0, gram_flop = 0;
     int h_builds = 0;       // number of (Gram, Cholesky) builds = iterations + 1 (initial point)
+    int chol_launches = 0;  // k_chol_step launches timed in ms_chol
+    double chol_flop = 0;   // factorisation + triangular inverse, per build
+    int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
 };
 
 class Solver {

@@ -53,6 +53,17 @@ struct DProg {
     const int *f_ptr, *f_rows;        // frequency -> rows
     const int *c_ptr, *c_rows;        // column   -> identity rows
     const int *yrows; int nyrows;     // rows with a non-zero ey
+    // Lattice ("matrix-free") mode: every trig column is scale * cos|sin(w (tmin + m)) with m on an
+    // integer lattice 0..D1-1 and the frequency grid splits into chunks of equally spaced points, so
+    // A1 is never formed: products with A1 / A1' and the Gram matrices A1' D A1 come from rotation
+    // recurrences (see "lattice kernels" below).  useg = number of partial sums k_rows_G adds up.
+    int trig, D1, LDL, seg, useg, nchunk, LDM;
+    double tmin;
+    const int *lat;                   // Nt: lattice index of column j
+    const int *lat_col, *lat_qcol;    // 2*D1 [kind][m]: column there (or -1); source column of P'v there
+    const double *lat_scale, *lat_qscale;
+    const int *ch_start, *ch_count;   // nchunk
+    const double *ch_w0, *ch_dw;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -117,8 +128,13 @@ __global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* _
     for (int v = 0; v < NV; ++v) {
         double val = 0;
         if (f >= 0) {
-            val = al * UU[(long)v * P.Mpad + f];
-            if (P.quad) val += be * UU[(long)(NV + v) * P.Mpad + f];
+            const int NVV = P.quad ? 2 * NV : NV;
+            double u1 = 0, u2 = 0;
+            for (int sg = 0; sg < P.useg; ++sg) {
+                u1 += UU[((long)sg * NVV + v) * P.Mpad + f];
+                if (P.quad) u2 += UU[((long)sg * NVV + NV + v) * P.Mpad + f];
+            }
+            val = al * u1 + be * u2;
         } else if (cl >= 0) {
             val = al * X[(long)v * P.LDV + cl];
         }
@@ -209,8 +225,16 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
     __shared__ double sh[16][65];
     const int c = threadIdx.x, sg = threadIdx.y, j = blockIdx.x * 64 + c, v = blockIdx.y;
     double t = 0;
-    if (j < ld)
-        for (int s = sg; s < nsplit; s += 16) t += partial[((long)s * nvv + v) * ld + j];
+    if (j < ld) {
+        const double* p = partial + (long)v * ld + j;
+        const long ss = (long)nvv * ld;
+        int s = sg;
+        for (; s + 48 < nsplit; s += 64) {
+            const double a0 = p[s * ss], a1 = p[(s + 16) * ss], a2 = p[(s + 32) * ss], a3 = p[(s + 48) * ss];
+            t += (a0 + a1) + (a2 + a3);
+        }
+        for (; s < nsplit; s += 16) t += p[s * ss];
+    }
     sh[sg][c] = t;
     __syncthreads();
     if (sg == 0 && j < ld) {
@@ -221,17 +245,19 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
     }
 }
 
-// Block x < nblk_cols: 64 columns x 16 split groups -> out[v][j]; the last block forms the y block.
+// Block x < nblk_cols: 32 columns x 32 split groups -> out[v][j] (4 loads in flight per thread);
+// the last block forms the y block.
+constexpr int GTC = 32, GTG = 32;
 template <int NV>
 __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
                                                     const double* __restrict__ val, double* __restrict__ out) {
-    __shared__ double sh[2 * NV][16][65];
+    __shared__ double sh[2 * NV][GTG][GTC + 1];
     __shared__ double red[17];
     const int c = threadIdx.x, sg = threadIdx.y;
     const int NVV = P.quad ? 2 * NV : NV;
     if ((int)blockIdx.x == (int)gridDim.x - 1) {
         // y block of G'v:  out[v][Nt+e] = sum_r ey[r][e] val[v][r]
-        const int tid = sg * 64 + c;
+        const int tid = sg * GTC + c;
         for (int v = 0; v < NV; ++v)
             for (int e = 0; e < P.Ne; ++e) {
                 double a = 0;
@@ -251,19 +277,40 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
             }
         return;
     }
-    const int j = blockIdx.x * 64 + c;
+    const int j = blockIdx.x * GTC + c;
     const bool ok = j < P.Nt;
     const int pj = (ok && P.quad) ? P.pcol[j] : 0;
+    // dense: partial[s][vv][column]; lattice: partial[chunk][vv][kind][m], scaled here
+    long o1 = j, o2 = pj, st1 = P.ld;
+    double f1 = 1.0, f2 = 1.0;
+    if (P.trig && ok) {
+        o1 = (long)P.col_kind[j] * P.LDM + P.lat[j]; o2 = (long)P.col_kind[pj] * P.LDM + P.lat[pj];
+        st1 = 2L * P.LDM;
+        f1 = P.col_scale[j]; f2 = P.col_scale[pj];
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         double t1 = 0, t2 = 0;
-        if (ok)
-            for (int s = sg; s < nsplit; s += 16) {
-                t1 += partial[((long)s * NVV + v) * P.ld + j];
-                if (P.quad) t2 += partial[((long)s * NVV + NV + v) * P.ld + pj];
+        if (ok) {
+            const double* p1 = partial + (long)v * st1 + o1;
+            const double* p2 = partial + (long)(NV + v) * st1 + o2;
+            const long ss = (long)NVV * st1;
+            int s = sg;
+            for (; s + 3 * GTG < nsplit; s += 4 * GTG) {
+                const double a0 = p1[s * ss], a1 = p1[(s + GTG) * ss], a2 = p1[(s + 2 * GTG) * ss], a3 = p1[(s + 3 * GTG) * ss];
+                t1 += (a0 + a1) + (a2 + a3);
+                if (P.quad) {
+                    const double b0 = p2[s * ss], b1 = p2[(s + GTG) * ss], b2 = p2[(s + 2 * GTG) * ss], b3 = p2[(s + 3 * GTG) * ss];
+                    t2 += (b0 + b1) + (b2 + b3);
+                }
             }
-        sh[v][sg][c] = t1;
-        sh[NV + v][sg][c] = t2;
+            for (; s < nsplit; s += GTG) {
+                t1 += p1[s * ss];
+                if (P.quad) t2 += p2[s * ss];
+            }
+        }
+        sh[v][sg][c] = f1 * t1;
+        sh[NV + v][sg][c] = f2 * t2;
     }
     __syncthreads();
     if (sg == 0 && ok) {
@@ -271,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
         for (int v = 0; v < NV; ++v) {
             double t1 = 0, t2 = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { t1 += sh[v][q][c]; t2 += sh[NV + v][q][c]; }
+            for (int q = 0; q < GTG; ++q) { t1 += sh[v][q][c]; t2 += sh[NV + v][q][c]; }
             double g = t1 + (P.quad ? P.psign[j] * t2 : 0.0);
             for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
                 const int r = P.c_rows[q];
@@ -279,6 +326,125 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
             }
             out[(long)v * P.LDV + j] = g;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lattice kernels (DProg::trig): the trig matrix is never stored.
+//  * cos/sin(w t) along a unit-step progression of t (fixed frequency) or along an equally spaced
+//    run of frequencies (fixed t) follow from one sincos seed by the rotation recurrence
+//    (c, s) <- (c cd - s sd, s cd + c sd); runs are at most 128 steps, so the recurrence error stays
+//    at a few 1e-14, the level at which cos(w * tau) is defined in double anyway.
+//  * Gram matrices: sum_i d_i trig(w_i ta) trig(w_i tb) = 1/2 [mom(ta - tb) +- mom(ta + tb)] with
+//    the moments g(t) = sum_i d_i cos(w_i t), s(t) = sum_i d_i sin(w_i t) on two unit-step
+//    progressions (differences, sums): O(Mf N) instead of the O(Mf N^2) of a dense A1' D A1.
+constexpr int CHK = 128;      // frequencies per chunk
+
+// XL[(vv*2 + kind)][m] = coefficient of cos|sin(w (tmin + m)) in A1 * [v ; P'v]
+template <int NV>
+__global__ void k_make_lattice(DProg P, const double* __restrict__ v, double* __restrict__ XL) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // (kind, m)
+    if (e >= 2 * P.D1) return;
+    const int kind = e / P.D1, m = e - kind * P.D1;
+    const int j = P.lat_col[e], qj = P.quad ? P.lat_qcol[e] : -1;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        XL[((long)q * 2 + kind) * P.LDL + m] = j >= 0 ? P.lat_scale[e] * v[(long)q * P.LDV + j] : 0.0;
+        if (P.quad) XL[((long)(NV + q) * 2 + kind) * P.LDL + m] = qj >= 0 ? P.lat_qscale[e] * v[(long)q * P.LDV + qj] : 0.0;
+    }
+}
+
+// K1 (lattice): UU[sg][vv][i] = sum_{m in segment sg} XL[vv][cos][m] cos(w_i t_m) + XL[vv][sin][m] sin(w_i t_m);
+// one thread per (frequency, segment), the coefficients are wave-uniform (scalar loads).
+template <int NVV>
+__global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __restrict__ XL, double* __restrict__ UU) {
+    const int i = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
+    if (i >= P.Mf) return;
+    const int m0 = sg * P.seg, m1 = min(m0 + P.seg, P.D1);
+    const double w = P.w[i];
+    double s, c, sw, cw;
+    sincos(w * (P.tmin + m0), &s, &c);
+    sincos(w, &sw, &cw);
+    double acc[NVV];
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) acc[v] = 0;
+    for (int m = m0; m < m1; ++m) {
+#pragma unroll
+        for (int v = 0; v < NVV; ++v) acc[v] += XL[(long)(2 * v) * P.LDL + m] * c + XL[(long)(2 * v + 1) * P.LDL + m] * s;
+        const double cn = c * cw - s * sw;
+        s = s * cw + c * sw;
+        c = cn;
+    }
+#pragma unroll
+    for (int v = 0; v < NVV; ++v) UU[((long)sg * NVV + v) * P.Mpad + i] = acc[v];
+}
+
+// K3 / K2 (lattice): partial[chunk][v][0|1][m] = sum_{i in chunk} p_v[i] cos|sin(w_i t_m), t_m on up to
+// two unit-step progressions (t0a + m, m < na; then t0b + (m - na)).  One thread per point m, the
+// chunk's operands sit in LDS: with AGG they are the per-frequency aggregates of a row vector
+// (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency), otherwise they are
+// read from the per-frequency array src[v][Mpad].
+template <int NV, bool AGG>
+__global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, double t0a, int na,
+                                                      double t0b, int nb, double* __restrict__ partial) {
+    __shared__ double pp[NV][CHK];
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const int start = P.ch_start[ch], cnt = P.ch_count[ch];
+    if (tid < CHK) {
+        const int i = start + tid;
+        if (AGG) {
+            const int nv = P.quad ? NV / 2 : NV;
+            double p1[NV], p2[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
+            if (tid < cnt)
+                for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
+                    const int r = P.f_rows[q];
+                    const double al = P.alpha[r], be = P.beta[r];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        if (v < nv) {
+                            const double x = src[(long)v * P.Rp + r];
+                            p1[v] += al * x;
+                            p2[v] += be * x;
+                        }
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (v < nv) {
+                    pp[v][tid] = p1[v];
+                    if (P.quad) pp[nv + v][tid] = p2[v];
+                }
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) pp[v][tid] = tid < cnt ? src[(long)v * P.Mpad + i] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + tid;
+    if (m >= na + nb) return;
+    const double t = m < na ? t0a + m : t0b + (m - na);
+    double s, c, sd, cd;
+    sincos(P.ch_w0[ch] * t, &s, &c);
+    sincos(P.ch_dw[ch] * t, &sd, &cd);
+    double ag[NV], as[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ag[v] = as[v] = 0;
+    for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const double p = pp[v][q];
+            ag[v] += p * c;
+            as[v] += p * s;
+        }
+        const double cn = c * cd - s * sd;
+        s = s * cd + c * sd;
+        c = cn;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        partial[(((long)ch * NV + v) * 2) * P.LDM + m] = ag[v];
+        partial[(((long)ch * NV + v) * 2 + 1) * P.LDM + m] = as[v];
     }
 }
 
@@ -955,6 +1121,51 @@ __global__ void k_assemble_H(DProg P, const double* __restrict__ T, const double
     }
     H[(long)j * P.np + k] = v;
 }
+// Lattice mode: the same H from the moments.  Mom[w][0|1][.] = g_w | s_w on the difference progression
+// (t = 0 .. D1-1, index m) followed by the sum progression (t = 2 tmin + m', index D1 + m');
+// MomB[e][0|1][m] are the border moments on the column progression t = tmin + m.
+__device__ __forceinline__ double lat_T(const DProg& P, const double* __restrict__ Mw, int j, int k) {
+    const int mj = P.lat[j], mk = P.lat[k], kj = P.col_kind[j], kk = P.col_kind[k];
+    const int d = mj - mk, ad = d < 0 ? -d : d, si = P.D1 + mj + mk;
+    const double* G = Mw;
+    const double* S = Mw + P.LDM;
+    double v;
+    if (kj == 0 && kk == 0) v = G[ad] + G[si];
+    else if (kj == 1 && kk == 1) v = G[ad] - G[si];
+    else {
+        const double sdv = d < 0 ? -S[ad] : S[ad];       // s(tau_j - tau_k)
+        v = kj == 0 ? S[si] - sdv : S[si] + sdv;
+    }
+    return 0.5 * v * P.col_scale[j] * P.col_scale[k];
+}
+__global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const double* __restrict__ MomB,
+                                 double* __restrict__ H, double pad_diag) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (k >= P.np || j >= P.np) return;
+    double v = 0;
+    const long mw = 2L * P.LDM;
+    if (j < P.Nt && k < P.Nt) {
+        v = lat_T(P, Mom, j, k);
+        if (P.quad) {
+            int pj = P.pcol[j], pk = P.pcol[k];
+            double sj = P.psign[j], sk = P.psign[k];
+            v += sj * sk * lat_T(P, Mom + 2 * mw, pj, pk) + sk * lat_T(P, Mom + mw, j, pk) + sj * lat_T(P, Mom + mw, pj, k);
+        }
+    } else if (j < P.N && k < P.N) {
+        int jj = j < k ? j : k, kk = j < k ? k : j;       // jj < Nt <= kk  or both >= Nt
+        if (jj < P.Nt) {
+            int e = kk - P.Nt;
+            v = P.col_scale[jj] * MomB[((long)e * 2 + P.col_kind[jj]) * P.LDM + P.lat[jj]];
+            if (P.quad) {
+                int pq = P.pcol[jj];
+                v += P.psign[jj] * P.col_scale[pq] * MomB[((long)(P.Ne + e) * 2 + P.col_kind[pq]) * P.LDM + P.lat[pq]];
+            }
+        }
+    } else if (j == k) {
+        v = pad_diag;
+    }
+    H[(long)j * P.np + k] = v;
+}
 // fold the atmulti partials of the border products: TT[v][j] = sum_s partial[s][v][j]
 __global__ void k_fold_tt(DProg P, const double* __restrict__ partial, int nsplit, int nvv, double* __restrict__ TT) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
@@ -1114,6 +1325,67 @@ __global__ void k_finish_x(DProg P, const double* __restrict__ x, const double* 
 // ================================================================================================
 // host driver
 // ================================================================================================
+// Host analysis for the lattice mode (DProg::trig): column delays on one unit-step lattice, at most
+// one column per (kind, lattice point), and a frequency grid made of equally spaced runs.
+struct LatticeInfo {
+    bool ok = false;
+    double tmin = 0;
+    int D1 = 0;
+    std::vector<int> lat, lat_col, lat_qcol, ch_start, ch_count;
+    std::vector<double> lat_scale, lat_qscale, ch_w0, ch_dw;
+};
+static LatticeInfo analyse_lattice(const TrigProgram& Q) {
+    LatticeInfo L;
+    const int Nt = Q.Nt, Mf = Q.Mf;
+    if (Nt <= 0 || Mf <= 0) return L;
+    double tmin = Q.col_tau[0];
+    for (double t : Q.col_tau) tmin = std::min(tmin, t);
+    L.lat.resize(Nt);
+    int D1 = 0;
+    for (int j = 0; j < Nt; ++j) {
+        const double m = Q.col_tau[j] - tmin;
+        const long mi = std::lround(m);
+        if (std::fabs(m - double(mi)) > 1e-9 || mi > 8L * Nt + 64) return L;
+        L.lat[j] = int(mi);
+        D1 = std::max(D1, int(mi) + 1);
+    }
+    L.lat_col.assign(2 * D1, -1); L.lat_qcol.assign(2 * D1, -1);
+    L.lat_scale.assign(2 * D1, 0.0); L.lat_qscale.assign(2 * D1, 0.0);
+    for (int j = 0; j < Nt; ++j) {
+        const int e = Q.col_kind[j] * D1 + L.lat[j];
+        if (L.lat_col[e] >= 0) return L;
+        L.lat_col[e] = j; L.lat_scale[e] = Q.col_scale[j];
+    }
+    if (Q.quad)
+        for (int j0 = 0; j0 < Nt; ++j0) {
+            if (Q.psign[j0] == 0.0) continue;
+            const int jp = Q.pcol[j0];
+            if (jp < 0 || jp >= Nt) return L;
+            const int e = Q.col_kind[jp] * D1 + L.lat[jp];
+            if (L.lat_qcol[e] >= 0) return L;
+            L.lat_qcol[e] = j0; L.lat_qscale[e] = Q.col_scale[jp] * Q.psign[j0];
+        }
+    double wmax = 1.0;
+    for (double w : Q.w) wmax = std::max(wmax, std::fabs(w));
+    const double tol = 8 * 2.2204460492503131e-16 * wmax;
+    for (int i = 0; i < Mf;) {
+        int k = i + 1;
+        if (k < Mf) {
+            const double dw = Q.w[k] - Q.w[i];
+            while (k < Mf && k - i < CHK && std::fabs(Q.w[k] - (Q.w[i] + (k - i) * dw)) <= tol) ++k;
+        }
+        int cnt = k - i;
+        double dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0;
+        for (int q = 1; q < cnt; ++q)
+            if (std::fabs(Q.w[i + q] - (Q.w[i] + q * dwf)) > 2 * tol) { cnt = q; dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0; break; }
+        L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(Q.w[i]); L.ch_dw.push_back(dwf);
+        i += cnt;
+    }
+    if ((long)L.ch_start.size() > Mf / 8 + 64) return L;       // grid too irregular: the dense path is the better one
+    L.tmin = tmin; L.D1 = D1; L.ok = true;
+    return L;
+}
+
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0;
@@ -1156,6 +1428,7 @@ struct Solver::Impl {
     int *tile_ij, *flag;
     double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
     double *XX, *UU, *PP, *partial, *TT, *TT2, *Dw, *BB, *qv;
+    double *XL, *Mom, *MomB;       // lattice mode: coefficient vectors, H moments, border moments
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
@@ -1181,6 +1454,15 @@ struct Solver::Impl {
     template <int NV>
     void apply_G(const double* v, double* out) {
         const int NVV = P.quad ? 2 * NV : NV;
+        if (P.trig) {
+            hipLaunchKernelGGL(k_make_lattice<NV>, dim3(cdiv(2 * P.D1, 256)), dim3(256), 0, st, P, v, XL);
+            dim3 g(cdiv(P.Mf, 256), P.useg);
+            if (NVV == 1) hipLaunchKernelGGL(k_trig_eval<1>, g, dim3(256), 0, st, P, XL, UU);
+            else if (NVV == 2) hipLaunchKernelGGL(k_trig_eval<2>, g, dim3(256), 0, st, P, XL, UU);
+            else hipLaunchKernelGGL(k_trig_eval<4>, g, dim3(256), 0, st, P, XL, UU);
+            hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
+            return;
+        }
         const double* xx = v;
         if (P.quad) {
             hipLaunchKernelGGL(k_make_xx<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, v, XX);
@@ -1193,6 +1475,19 @@ struct Solver::Impl {
         hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
     }
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
+    // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
+    void moments_array(int nv, const double* pp, double t0a, int na, double t0b, int nb, double* out) {
+        dim3 g(cdiv(na + nb, 256), P.nchunk), b(256);
+        switch (nv) {
+            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            default: throw HipError("moments: unsupported vector count");
+        }
+        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.LDM, 64), 2 * nv), dim3(64, 16), 0, st, partial, P.nchunk, 2 * nv, P.LDM, P.LDM, out);
+    }
     void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
         switch (nvv) {
@@ -1206,10 +1501,16 @@ struct Solver::Impl {
     }
     template <int NV>
     void apply_GT(const double* val, double* out) {
-        dim3 g(P.ld / 128, nsplit_at), b(64, 4);
-        if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
-        else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
-        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, 64) + 1), dim3(64, 16), 0, st, P, partial, nsplit_at, val, out);
+        if (P.trig) {
+            dim3 g(cdiv(P.D1, 256), P.nchunk), b(256);
+            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), g, b, 0, st, P, val, P.tmin, P.D1, 0.0, 0, partial);
+            else hipLaunchKernelGGL((k_trig_moments<NV, true>), g, b, 0, st, P, val, P.tmin, P.D1, 0.0, 0, partial);
+        } else {
+            dim3 g(P.ld / 128, nsplit_at), b(64, 4);
+            if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
+            else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
+        }
+        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, GTC) + 1), dim3(GTC, GTG), 0, st, P, partial, P.trig ? P.nchunk : nsplit_at, val, out);
         allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
@@ -1267,6 +1568,13 @@ struct Solver::Impl {
     void build_H() {
         hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dl, w3, Dw, BB);
         hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
+        if (P.trig) {
+            if (g0) hipEventRecord(g0, st);
+            moments_array(P.quad ? 3 : 1, Dw, 0.0, P.D1, 2.0 * P.tmin, 2 * P.D1 - 1, Mom);
+            if (P.Ne > 0) moments_array(P.quad ? 2 * P.Ne : P.Ne, BB, P.tmin, P.D1, 0.0, 0, MomB);
+            hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, MomB, H, shard_rank == 0 ? 1.0 : 0.0);
+            if (g1) hipEventRecord(g1, st);
+        } else {
         gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
@@ -1274,6 +1582,7 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
         }
         hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
+        }
         hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
         if (P.Ne > 0 && P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H);
         if (P.big) {
@@ -1283,9 +1592,7 @@ struct Solver::Impl {
         }
         allreduce(H, (long)P.np * P.np, 0);               // sum the shards' normal matrices
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
-        if (c0) hipEventRecord(c0, st);
-        chol_inv_launch(H, M, Mt, W1, P.np, flag, st);
-        if (c1) hipEventRecord(c1, st);
+        chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1);
     }
     // events are recorded as (gram begin, gram end, chol begin, chol end) per build_H
     void collect_times(double& gram_ms, double& chol_ms, int& builds) {
@@ -1373,7 +1680,15 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     // ---- sizes -----------------------------------------------------------------------------
     const int nw = Q.quad ? 3 : 1;
     S.gp = gram_plan(Mf, Nt, nw);
+    LatticeInfo Lt;
+    if (!o.dense_trig) Lt = analyse_lattice(Q);
     DProg& P = S.P;
+    P.trig = Lt.ok ? 1 : 0;
+    P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
+    P.seg = std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8)));
+    P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
+    P.nchunk = int(Lt.ch_start.size());
+    P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
     P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
@@ -1398,10 +1713,14 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     P.f_ptr = S.upload(f_ptr); P.f_rows = S.upload(f_rows); P.c_ptr = S.upload(c_ptr); P.c_rows = S.upload(c_rows);
     P.yrows = S.upload(yrows);
     S.tile_ij = S.upload(tiles);
+    P.lat = S.upload(Lt.lat); P.lat_col = S.upload(Lt.lat_col); P.lat_qcol = S.upload(Lt.lat_qcol);
+    P.lat_scale = S.upload(Lt.lat_scale); P.lat_qscale = S.upload(Lt.lat_qscale);
+    P.ch_start = S.upload(Lt.ch_start); P.ch_count = S.upload(Lt.ch_count); P.ch_w0 = S.upload(Lt.ch_w0); P.ch_dw = S.upload(Lt.ch_dw);
     // ---- work buffers ----------------------------------------------------------------------
     zero_from = ar.base + ar.off;
-    S.A1 = ar.get<double>(Mpad * ld);
-    S.T = ar.get<double>(nw * ld * ld);
+    S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
+    S.T = ar.get<double>(P.trig ? 0 : nw * ld * ld);
+    S.XL = ar.get<double>(8 * (size_t)P.LDL); S.Mom = ar.get<double>(6 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
@@ -1416,13 +1735,13 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
-    S.UU = ar.get<double>(4 * Mpad); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(3 * Mpad); S.BB = ar.get<double>(6 * Mpad);
-    S.partial = ar.get<double>((size_t)S.nsplit_at * 6 * ld);
+    S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(3 * Mpad); S.BB = ar.get<double>(6 * Mpad);
+    S.partial = ar.get<double>(P.trig ? (size_t)P.nchunk * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
     zero_bytes = size_t(ar.base + ar.off - zero_from);
-    S.slab = ar.get<double>(S.gp.slab_doubles);
+    S.slab = ar.get<double>(P.trig ? 0 : S.gp.slab_doubles);
     };
     ar.measuring = true; ar.reset();
     { char* keep = ar.base; ar.base = nullptr; layout(); ar.base = keep; }
@@ -1432,7 +1751,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     layout();
     MBFIR_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     // ---- build A1, norms -------------------------------------------------------------------
-    hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
+    if (!P.trig) hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
     {
         std::vector<double> sc0(S_COUNT, 0.0);
         sc0[S_NRMH] = nrm_h; sc0[S_NRMC] = nrm_c; sc0[S_DEG] = degree; sc0[S_TAU] = 1.0; sc0[S_KAPPA] = 1.0;
@@ -1596,7 +1915,11 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     info.ms_solve = now_ms() - t_assembled;
     S.collect_times(info.ms_gram, info.ms_chol, info.h_builds);
     info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
-    info.gram_flop = double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
+    info.lattice = P.trig;
+    info.chol_launches = info.h_builds * (P.np / 64 + 1);
+    info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
+    info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
+                            : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
     return status;
 }
 

@@ -15,11 +15,15 @@ warnings.filterwarnings("ignore", category=RuntimeWarning)
 TAP_TOL = 1e-6
 
 
+@pytest.mark.parametrize("dense", [0, 1], ids=["lattice", "dense"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_taps_match_golden(name, golden):
+def test_taps_match_golden(name, dense, golden):
+    """Both device paths: the default lattice (matrix-free) mode and the dense one (materialised trig
+    matrix, MFMA Gram) forced through opts.dense_trig."""
     fn, args = CASES[name]
-    h, status, info = getattr(mbfir, fn)(*args, info=True)
+    h, status, info = getattr(mbfir, fn)(*args, info=True, opts=mbfir.make_opts(dense_trig=dense))
     g = golden[name]
+    assert info["lattice"] == 1 - dense
     assert status == g["status"]
     if status == "Solved":
         hg = np.array(g["h"]["re"]) + 1j * np.array(g["h"]["im"])
@@ -105,12 +109,13 @@ def test_full_size_c2_properties():
     assert abs(np.sum(np.abs(h) ** 2) - z[0]) <= 2e-2 * z[0]
 
 
-def test_full_size_c3_properties():
+@pytest.mark.parametrize("dense", [0, 1], ids=["lattice", "dense"])
+def test_full_size_c3_properties(dense):
     """BASELINE headline config: n=512 taps, m=16384 grid, arbitrary-phase SOCP (S-C13, fixed duration)."""
     n = 512
     f, a, d = c13(n, "duration")
-    h, status, info = mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=mbfir.make_opts(grid_m=16384), info=True)
-    assert status == "Solved" and h.shape == (n,)
+    h, status, info = mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=mbfir.make_opts(grid_m=16384, dense_trig=dense), info=True)
+    assert status == "Solved" and h.shape == (n,) and info["lattice"] == 1 - dense
     assert info["n_unknowns"] == 1024 and info["n_freq"] == 16394
     z = mbfir.get_context().last_solution(info["n_unknowns"])
     _check_ap_solution(n, f, a, d, 0.1, 1e-3, 16384, info, z)
