@@ -2,16 +2,19 @@
 """Headline benchmark: FIR designs/sec (and IPM iterations/sec) of the arbitrary-phase SOCP designer
 at n=512 taps, m=16384 grid points (BASELINE.json metric), on N GPUs of one node.
 
-A "step" is one complete design through the C ABI (mbfir_ap_solve: host assembly, trig matrix
-generation, every IPM iteration on the GPU, spectral factorisation) of the S-C13 bSSFP spec
-(bSSFP_pulse_sb_mb.m:9-52) in the fixed-duration regime, obj=0.1, Peak=1e-3.  Inputs are a few
-dozen doubles, so "inputs resident in HBM" is trivially true; the timed region includes the
-PCIe hand-over of the spec and of the taps.
+A "step" is one batch of `--streams` (default 4) independent designs through the C ABI
+(mbfir_solve_batch -> mbfir_ap_solve: host assembly, every IPM iteration on the GPU, spectral
+factorisation), all of the S-C13 bSSFP spec (bSSFP_pulse_sb_mb.m:9-52) in the fixed-duration regime,
+obj=0.1, Peak=1e-3 -- the shape of the reference's outer loops (bisection probes, parameter sweeps).
+The designs of a batch run on separate HIP streams, so the latency-bound phases of one (Cholesky
+panels, reductions, the per-iteration host check) overlap the others; the single-design latency is
+reported beside the throughput.  Inputs are a few dozen doubles, so "inputs resident in HBM" is
+trivially true; the timed region includes the PCIe hand-over of the specs and of the taps.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the default mode gives every
-rank its own design (independent designs -- bisection probes / parameter sweeps shard with no
-data-path collective, SURVEY 8e "replicas only"), so scaling is weak and
-value = N * K / max-over-ranks time.
+rank its own batches (independent designs shard with no data-path collective, SURVEY 8e "replicas
+only"), so scaling is weak and value = N * streams * K / max-over-ranks time.  --mode shard splits
+the frequency rows of ONE design over the ranks (RCCL all-reduce per iteration, strong scaling).
 
 One JSON line on stdout (rank 0).
 """
@@ -70,6 +73,8 @@ def main():
     ap.add_argument("--grid-m", type=int, default=16384)
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch")
     ap.add_argument("--cpu-iters", type=int, default=8, help="oracle iterations for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--streams", type=int, default=4, help="independent designs in flight per GPU (contexts / HIP streams); "
+                    "a step is one batch of that many designs")
     ap.add_argument("--dense", action="store_true", help="materialised trig matrix + dense MFMA Gram (opts.dense_trig) "
                     "instead of the default lattice (matrix-free) mode")
     args = ap.parse_args()
@@ -90,9 +95,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     import mbfir
-    ctx = mbfir.Context(local_rank)
     f, a, d = workload(args.n)
     shard = args.mode == "shard" and world > 1
+    nstream = 1 if shard else max(1, args.streams)
+    ctxs = [mbfir.Context(local_rank) for _ in range(nstream)]
+    ctx = ctxs[0]
     if shard:
         # ONE design, its frequency rows split over the ranks; per iteration RCCL all-reduces the
         # normal matrix, every G'v and the step / residual scalars (mbfir_set_allreduce hook)
@@ -101,11 +108,17 @@ def main():
     else:
         opts = mbfir.make_opts(grid_m=args.grid_m, dense_trig=int(args.dense))
 
+    jobs = [("fir_ap_cvx", (args.n, f, a, d, 0.1, 1e-3))] * nstream
+
     def step():
-        h, status, info = mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)
-        if status != "Solved":
-            raise RuntimeError("benchmark design did not solve: %r" % (info,))
-        return info
+        if shard:
+            res = [mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)]
+        else:
+            res = mbfir.solve_batch(jobs, opts=opts, ctxs=ctxs, info=True)      # mbfir_solve_batch: nstream designs in flight
+        for h, status, info in res:
+            if status != "Solved":
+                raise RuntimeError("benchmark design did not solve: %r" % (info,))
+        return [info for _, _, info in res]
 
     def fence():
         torch.cuda.synchronize()
@@ -117,9 +130,15 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    infos = [step() for _ in range(args.steps)]
+    infos = [i for _ in range(args.steps) for i in step()]
     fence()
     elapsed = time.perf_counter() - t0
+    ndesign = args.steps * nstream            # designs this rank completed in the timed region
+    # single-design latency (one stream, nothing else on the GPU), outside the timed region
+    t1 = time.perf_counter()
+    mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx)
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t1) * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,30 +191,34 @@ def main():
         dominant, other = (roof_chol, roof_gram) if chol_ms >= gram_ms else (roof_gram, roof_chol)
         out = {
             "metric": "FIR designs/sec, n=%d taps m=%d arbitrary-phase SOCP (fir_ap_cvx form)" % (args.n, args.grid_m),
-            "value": (1 if shard else world) * args.steps / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
+            "value": (1 if shard else world) * ndesign / elapsed, "unit": "designs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "S-C13 bSSFP 5-band spec, fixed-duration regime, fir_ap_cvx(n=%d, obj=0.1, Peak=1e-3), "
-                                   "grid_m=%d (+10 band edges), one design per rank per step" % (args.n, args.grid_m),
+                                   "grid_m=%d (+10 band edges); a step is one batch of %d independent designs in flight per rank "
+                                   "(mbfir_solve_batch, one HIP stream each)" % (args.n, args.grid_m, nstream),
+                       "designs_per_step_per_rank": nstream, "single_design_latency_ms": latency_ms,
                        "n_taps": args.n, "grid_m": args.grid_m, "unknowns": infos[0]["n_unknowns"], "rows": infos[0]["n_rows"],
                        "mode": args.mode, "trig": "lattice (matrix-free)" if lattice else "dense (materialised trig matrix, MFMA Gram)",
                        "parallelism": ("frequency rows of one design sharded x%d, RCCL all-reduce per iteration" % world) if shard
                        else "independent designs x%d" % world},
-            "ipm_iters_per_design": iters / args.steps,
+            "ipm_iters_per_design": iters / ndesign,
             "ipm_iters_per_s": (1 if shard else world) * iters / elapsed,
-            "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / args.steps,
-                                        "solve": sum(i["ms_solve"] for i in infos) / args.steps,
-                                        "normal_matrix": gram_ms / args.steps,
-                                        "cholesky_inverse": chol_ms / args.steps,
-                                        "spectral_factor": sum(i["ms_post"] for i in infos) / args.steps},
+            "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / ndesign,
+                                        "solve": sum(i["ms_solve"] for i in infos) / ndesign,
+                                        "normal_matrix": gram_ms / ndesign,
+                                        "cholesky_inverse": chol_ms / ndesign,
+                                        "spectral_factor": sum(i["ms_post"] for i in infos) / ndesign,
+                                        "note": "per-stream device/host times while %d designs share the GPU" % nstream},
             "roofline": dominant,
             "roofline_other": [other],
         }
         if world == 1 and args.cpu_iters > 0:
-            out["cpu_baseline"] = cpu_baseline(args.n, args.grid_m, int(round(iters / args.steps)), args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(args.n, args.grid_m, int(round(iters / ndesign)), args.cpu_iters)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

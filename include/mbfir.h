@@ -120,6 +120,26 @@ int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f,
                           const double* dc_re, const double* dc_im, const mbfir_opts* opts,
                           double* h_re, double* h_im, mbfir_info* info);
 
+/* Batch of independent designs -- the shape of the reference's outer loops (min-order / min-
+ * duration bisections probe several n, fir_ap_cvx.m callers such as bSSFP_pulse_sb_mb.m:56-99
+ * and dzbeta_min_order; parameter sweeps over obj / Peak).  The jobs are spread over `nctx`
+ * contexts (all on one device, or one per device), one host thread per context; each context
+ * has its own HIP stream, so the latency-bound phases of different designs overlap on the GPU.
+ * `which`: 0 fir_ap_cvx (params = obj, Peak), 1 fir_qp_cvx (params = k, obj[0], obj[1], nobj),
+ * 2 fir_linprog, 3 fir_qprog_phs (a: 2*nband and d: nband complex values, re/im interleaved).
+ * Every job gets its own rc / info, as from the single-design entry points; returns 0 or the
+ * most negative rc of the batch. */
+typedef struct mbfir_job {
+    int which, n, nband, rc;
+    const double *f, *a, *d;
+    double params[4];
+    double *h_re, *h_im;          /* n doubles each, caller-allocated */
+    mbfir_info info;
+} mbfir_job;
+
+int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njobs,
+                      const mbfir_opts* opts);
+
 /* Conic solution z = [x ; y] / tau of the last solve on this context (n_unknowns doubles of
  * mbfir_info; returns the count copied, or <0).  For fir_ap_cvx x is the autocorrelation
  * [r(0), Re r(1..n-1), Im r(1..n-1)] (fir_ap_cvx.m:185-186), for the others [Re h ; Im h] or the

@@ -56,6 +56,14 @@ class Info(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class Job(C.Structure):
+    """struct mbfir_job (include/mbfir.h)."""
+    _fields_ = [("which", C.c_int), ("n", C.c_int), ("nband", C.c_int), ("rc", C.c_int),
+                ("f", C.POINTER(C.c_double)), ("a", C.POINTER(C.c_double)), ("d", C.POINTER(C.c_double)),
+                ("params", C.c_double * 4), ("h_re", C.POINTER(C.c_double)), ("h_im", C.POINTER(C.c_double)),
+                ("info", Info)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
 
 _dp = C.POINTER(C.c_double)
@@ -79,6 +87,7 @@ SYMBOLS = {
                                       C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
     "mbfir_qprog_phs_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp,
                                         C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
+    "mbfir_solve_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Job), C.c_int, C.POINTER(Opts)]),
     "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mbfir_program_free": (None, [C.c_void_p]),
@@ -302,6 +311,77 @@ def fir_qprog_phs(n, f, ac, dc, x0=None, dbg=0, *, opts=None, ctx=None, info=Fal
     rc = load_library().mbfir_qprog_phs_solve(ctx._h, int(n), len(dc), _ptr(f), _ptr(are), _ptr(aim), _ptr(dre),
                                               _ptr(dim), C.byref(o), _ptr(hre), _ptr(him), C.byref(inf))
     return _finish(ctx, rc, hre, him, inf, info)
+
+
+_WHICH = {"fir_ap_cvx": 0, "fir_qp_cvx": 1, "fir_linprog": 2, "fir_qprog_phs": 3}
+_pools = {}
+
+
+def get_pool(streams=4, device=None):
+    """`streams` contexts (one HIP stream each) on one device, created once and reused."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    key = (device, streams)
+    if key not in _pools:
+        _pools[key] = [Context(device) for _ in range(streams)]
+    return _pools[key]
+
+
+def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False):
+    """Independent designs, `streams` in flight at a time on one GPU (mbfir_solve_batch): the shape of
+    the reference's outer loops -- the probes of a min-order / min-duration bisection, parameter sweeps.
+    jobs: sequence of (designer, args) with designer in {'fir_ap_cvx', 'fir_qp_cvx', 'fir_linprog',
+    'fir_qprog_phs'} and args the positional arguments of that function (n, f, a, d, ...).
+    Returns a list of (h, status) -- or (h, status, info) -- in job order, as the single calls return."""
+    ctxs = ctxs or get_pool(streams)
+    o = opts if opts is not None else make_opts()
+    arr = (Job * len(jobs))()
+    keep = []
+    for q, (name, args) in enumerate(jobs):
+        which = _WHICH[name]
+        n, f = int(args[0]), _vec(args[1])
+        params = [0.0] * 4
+        if which == 3:
+            ac = np.asarray(args[2], dtype=np.complex128).ravel()
+            dc = np.asarray(args[3], dtype=np.complex128).ravel()
+            if len(f) % 2 or len(ac) != len(f) or len(dc) != len(f) // 2:
+                raise ValueError("f, ac, dc have inconsistent lengths")
+            a, d = _vec(np.stack([ac.real, ac.imag], 1)), _vec(np.stack([dc.real, dc.imag], 1))
+            nband = len(dc)
+        else:
+            a, d = _vec(args[2]), _vec(args[3])
+            _check_spec(f, a, d)
+            nband = len(d)
+            if which == 0:
+                params[0] = float(args[4]) if len(args) > 4 else 0.0
+                params[1] = float(args[5]) if len(args) > 5 else 1e-3
+            elif which == 1:
+                params[0] = float(args[4]) if len(args) > 4 else 100.0
+                objv = _vec(args[5] if len(args) > 5 else 0.0)
+                if len(objv) not in (1, 2):
+                    raise ValueError("invalid input of obj")
+                params[1:1 + len(objv)] = list(objv)
+                params[3] = float(len(objv))
+        hre, him = np.zeros(n), np.zeros(n)
+        keep.append((f, a, d, hre, him))
+        J = arr[q]
+        J.which, J.n, J.nband = which, n, nband
+        J.f, J.a, J.d, J.h_re, J.h_im = _ptr(f), _ptr(a), _ptr(d), _ptr(hre), _ptr(him)
+        for t in range(4):
+            J.params[t] = params[t]
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    load_library().mbfir_solve_batch(handles, len(ctxs), arr, len(jobs), C.byref(o))
+    out = []
+    for q in range(len(jobs)):
+        hre, him = keep[q][3], keep[q][4]
+        inf = Info.from_buffer_copy(arr[q].info)
+        # errors are reported per job, like the single calls do (which context ran it is not recorded)
+        if arr[q].rc < 0:
+            if arr[q].rc == E_ARG:
+                raise ValueError("job %d: invalid argument" % q)
+            raise MbfirError("job %d failed (%d)" % (q, arr[q].rc))
+        out.append(_finish(ctxs[0], arr[q].rc, hre, him, inf, info))
+    return out
 
 
 def _check_spec(f, a, d):

@@ -33,14 +33,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     # compare the ctypes mirrors with what a C compiler makes of include/mbfir.h
-    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mbfir.h"\nint main(){printf("%zu %zu %zu %zu", sizeof(mbfir_opts), sizeof(mbfir_info), offsetof(mbfir_opts, refine), offsetof(mbfir_info, gram_flop));return 0;}'
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mbfir.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(mbfir_opts), sizeof(mbfir_info), offsetof(mbfir_opts, refine), offsetof(mbfir_info, gram_flop), sizeof(mbfir_job), offsetof(mbfir_job, info));return 0;}'
     exe = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mbfir_sizeof_%d" % os.getpid())
     r = subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True).stdout.split()
     os.remove(exe)
     assert [int(v) for v in out] == [ctypes.sizeof(mbfir.Opts), ctypes.sizeof(mbfir.Info), mbfir.Opts.refine.offset,
-                                     mbfir.Info.gram_flop.offset]
+                                     mbfir.Info.gram_flop.offset, ctypes.sizeof(mbfir.Job), mbfir.Job.info.offset]
     o = mbfir.make_opts(grid_m=123, verbose=1)
     assert (o.grid_m, o.refine, o.verbose, o.max_iter) == (123, -1, 1, 0)
 

@@ -80,6 +80,23 @@ def test_context_reuse_like_a_bisection():
     ctx.close()
 
 
+def test_batch_of_designs_matches_single_calls(golden):
+    """mbfir_solve_batch: all four designers, feasible and infeasible jobs, 4 streams in flight; every
+    job must return what the single-design entry point returns (golden taps within the tolerance)."""
+    names = sorted(CASES) * 2
+    res = mbfir.solve_batch([CASES[nm] for nm in names], streams=4, info=True)
+    assert len(res) == len(names)
+    for nm, (h, status, info) in zip(names, res):
+        g = golden[nm]
+        assert status == g["status"], nm
+        if status == "Solved":
+            hg = np.array(g["h"]["re"]) + 1j * np.array(g["h"]["im"])
+            assert relinf(h, hg) <= TAP_TOL, nm
+            assert abs(info["pcost"] - g["pcost"]) <= 1e-7 * max(1.0, abs(g["pcost"]))
+        else:
+            assert len(h) == 0
+
+
 def _check_ap_solution(n, f, a, d, obj, peak, grid_m, info, z):
     """Size-independent properties of a fir_ap_cvx solve: the returned autocorrelation is primal
     feasible for the reference's constraints and the certificate (gap, residuals) is small."""
