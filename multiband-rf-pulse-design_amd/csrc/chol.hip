@@ -91,29 +91,15 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
 // =================================================================================================
 typedef double v16d __attribute__((ext_vector_type(16)));   // register-resident 16-vector (an array would go to scratch)
 
-// Column permutation of the potf2 broadcast buffer: column t is stored at position
-// perm(t) = (t & 3) * 16 + (t >> 2), so the 16 columns {q, q+4, ...} that one lane needs are
-// contiguous (wide LDS reads, no per-element address math).
-__device__ __forceinline__ int cperm(int t) { return (t & 3) * 16 + (t >> 2); }
-
 // NOTE on code shape (all measured on MI355X with tools/exp/*.hip):
 //  * one wave issues an independent v_fma_f64 every ~2.9 ns, a (uniform select + fma) pair costs
 //    18 ns (v_cndmask pairs), a ds_read_b128 costs the CU 13.5 ns whatever the address pattern
 //    (the 128 B/clk return path), a dependent mul -> DPP -> fma chain 22 ns, an LDS store ->
-//    barrier -> load round trip ~110 ns;
+//    barrier -> load round trip ~65 ns; a single wave per SIMD issues in order, so whatever is
+//    not hidden behind a latency adds up;
 //  * so: no per-element selects (finished rows / columns are masked by ZEROS in the broadcast
-//    images instead), operands in registers with static indices, as few LDS bytes per pivot as
-//    possible, and cross-lane traffic on DPP where the layout allows it.
-__device__ __forceinline__ double sel16(const v16d& v, int idx) {
-    double r = v[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) r = (i == idx) ? v[i] : r;
-    return r;
-}
-__device__ __forceinline__ void put16(v16d& v, int idx, double x) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (i == idx) ? x : v[i];
-}
+//    images instead), operands in registers with static indices, as few LDS bytes and as few
+//    instructions per pivot as possible, and cross-lane traffic on DPP where the layout allows it.
 
 // ---- forward substitution, 16 lanes per right-hand side ----------------------------------------
 // A DPP row (16 lanes) owns one right-hand side: lane lam holds a[t] for t = lam + 16 i in v[i].
@@ -159,76 +145,106 @@ __device__ __forceinline__ void subst16(const double* __restrict__ Lz, const dou
     v[0] = v0 * dm0; v[1] = v1 * dm1; v[2] = v2 * dm2; v[3] = v3 * dm3;
 }
 
-// Unblocked right-looking Cholesky of a 64x64 block held in registers: thread (tx = tid & 63,
-// ty = tid >> 6) owns row tx, columns ty + 4 i in rv[i].  Column j is broadcast through a
-// triple-buffered, column-permuted LDS vector (one barrier per pivot) with the rows up to the pivot
-// written as zeros, which masks every finished row and column without a select; the pivot itself
-// travels in pd[].  The per-pivot dependent chain is only
-//     read (p, S_tx,j, S_c,j for the column published next) -> 1/p -> scale -> one fma -> publish,
-// the 16-column rank-1 update of pivot j ("bulk") is issued one pivot late, behind the chain's LDS
-// reads of pivot j+1, so its 8 wide LDS reads and 16 fmas overlap the next chain instead of
-// delaying the next publish; the element of the next column group that must be current at the
-// group boundary is carried separately (nxt).  Square-root free (S_ic -= S_ij S_cj / p_j, 1/p from
-// v_rcp_f64 + one Newton step); the pivots go to piv[] and the caller applies
-// L_ij = S_ij / sqrt(p_j) in one parallel pass.  Only the lower triangle of the result is meaningful.
-// colbuf: 3 x 64 column slots + 4 pivot slots (200 doubles).
-__device__ __forceinline__ void potf2_regs(v16d& rv, double* colbuf, const double* dsh, double* piv,
-                                           double pivtol, int* flag, bool count) {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int ptx = cperm(tx);
+// Unblocked right-looking Cholesky of a 64x64 block held in registers, 2-D cyclic layout: thread
+// (rL = tid >> 4, cL = tid & 15) owns rows rL + 16 a and columns cL + 16 b in s[4 a + b] -- exactly
+// what the MFMA product of panel_block leaves in its accumulators, so the block never goes through
+// LDS.  Column j is broadcast through a triple-buffered LDS image (index ipos(t) = (t & 15) * 4 +
+// (t >> 4), so the 4 entries a thread writes or reads are contiguous), one barrier per pivot, the
+// entries up to the pivot written as zeros, which masks every finished row and column without a
+// select; the pivot itself travels in pd[].  Per pivot a thread reads 2 x 32 bytes (its 4 row
+// values, its 4 column values) and does (4 - Q)^2 fmas, Q = j / 16 (dead slots are skipped
+// statically: one code body per phase).  The dependent chain is
+//     read -> 1/p -> scale -> 4 fmas on the slot of the next column -> publish,
+// the other slots of the rank-1 update are issued one pivot late, in the shadow of the next
+// pivot's LDS reads.  Square-root free (S_rc -= S_rj S_cj / p_j, 1/p from v_rcp_f64 + one Newton
+// step); the pivots go to piv[] and the caller applies L_rc = S_rc / sqrt(p_c).  Only the lower
+// triangle of the result is meaningful.  colbuf: 3 x 64 image slots + 4 pivot slots.
+struct Potf2State {
+    double ar[4], cv[4];      // scaled row values / column values of the previous pivot (late update)
+    int slot, nbad;
+};
+
+// one pivot: j = 16 Q + jl; BN = slot of the next column (Q, or Q + 1 for jl = 15); QP / BNP describe
+// the previous pivot (QP < 0: none)
+template <int Q, int BN, int QP, int BNP>
+__device__ __forceinline__ void potf2_step(v16d& s, Potf2State& st, int j, double* colbuf, const double* dsh,
+                                           double* piv, double pivtol) {
+    const int rL = threadIdx.x >> 4, cL = threadIdx.x & 15;
+    const int slot = st.slot, nslot = slot == 2 ? 0 : slot + 1;
+    const double* img = colbuf + slot * CB;
+    double* imn = colbuf + nslot * CB;
     double* pd = colbuf + 3 * CB;
-    if (threadIdx.x < 3 * CB) colbuf[threadIdx.x] = 0.0;
-    __syncthreads();
-    double cur = rv[0], nxt = 0.0;                        // elements (tx, ty) and (tx, 4 + ty)
-    if (ty == 0) { colbuf[ptx] = tx > 0 ? cur : 0.0; if (tx == 0) pd[0] = cur; }
-    __syncthreads();
-    double a_prev = 0.0;
-    int off_prev = ty * 16, slot = 0, nbad = 0;
-#pragma unroll 1
-    for (int jg = 0; jg < 16; ++jg) {
-        const int jg1 = (jg + 1) & 15;
+    const double p0 = pd[slot];
+    const double dj = dsh[j];
+    const double2 r01 = *reinterpret_cast<const double2*>(img + rL * 4), r23 = *reinterpret_cast<const double2*>(img + rL * 4 + 2);
+    const double2 c01 = *reinterpret_cast<const double2*>(img + cL * 4), c23 = *reinterpret_cast<const double2*>(img + cL * 4 + 2);
+    if constexpr (QP >= 0) {                               // late part of the previous pivot's rank-1 update
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * jg + jj;
-            const double* cb = colbuf + slot * CB;
-            const int nslot = slot == 2 ? 0 : slot + 1;
-            double* cbn = colbuf + nslot * CB;
-            // chain operands first, then the late bulk operands of pivot j-1
-            double p = pd[slot];
-            const double dj = dsh[j];
-            const double asrc = cb[ptx];
-            const double mjg = cb[ty * 16 + jg];          // S_cj, c = ty + 4 jg (0 unless c > j)
-            const double mj1 = cb[ty * 16 + jg1];         // S_cj, c = ty + 4 (jg + 1)
-#ifndef POTF2_EXP_NOBULK
-            const v16d mp = *reinterpret_cast<const v16d*>(colbuf + off_prev);
-#else
-            v16d mp; for (int i = 0; i < 16; ++i) mp[i] = mj1;
-#endif
-            const bool bad = !(p > pivtol * dj);
-            p = bad ? fmax(dj, 1e-300) : p;
-            nbad += bad;
-            double rcp = __builtin_amdgcn_rcp(p);         // ~26 bits
-            rcp = rcp * fma(-p, rcp, 2.0);                // 1/p to rounding
-            const double a = asrc * rcp;                  // 0 for the rows up to the pivot
-            cur -= a * mjg;
-            if (jj >= 2) nxt -= a * mj1;
-            if (jj < 3) {
-                if (ty == jj + 1) { cbn[ptx] = tx > j + 1 ? cur : 0.0; if (tx == j + 1) pd[nslot] = cur; }
-            } else {
-                if (ty == 0) { cbn[ptx] = tx > j + 1 ? nxt : 0.0; if (tx == j + 1) pd[nslot] = nxt; }
-            }
-            if (ty == jj && tx == j) { cur = p; piv[j] = p; }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int a = QP; a < 4; ++a)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) rv[i] -= a_prev * mp[i];    // rank-1 update of pivot j-1
-            if (jj == 1) { nxt = sel16(rv, jg1); nxt -= a * mj1; }   // slot jg+1 is now current through pivot 4 jg
-            a_prev = a; off_prev = slot * CB + ty * 16; slot = nslot;
-            __syncthreads();
-        }
-        put16(rv, jg, cur);
-        cur = nxt;
+            for (int b = QP; b < 4; ++b)
+                if (b != BNP) s[4 * a + b] -= st.ar[a] * st.cv[b];
     }
-    if (count && threadIdx.x == 0 && nbad) atomicAdd(flag, nbad);
+    const double pfix = fmax(dj, 1e-300);
+    const bool bad = !(p0 > pivtol * dj);
+    const double p = bad ? pfix : p0;
+    st.nbad += bad;
+    double rcp = __builtin_amdgcn_rcp(p);                 // ~26 bits
+    rcp = rcp * fma(-p, rcp, 2.0);                        // 1/p to rounding
+    const double rv[4] = {r01.x, r01.y, r23.x, r23.y};
+    const double cv[4] = {c01.x, c01.y, c23.x, c23.y};
+    double ar[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ar[a] = a >= Q ? rv[a] * rcp : 0.0;    // 0 for the rows up to the pivot
+    if constexpr (BN < 4) {
+#pragma unroll
+        for (int a = Q; a < 4; ++a) s[4 * a + BN] -= ar[a] * cv[BN];   // the slot the next column lives in
+        const int jn = j + 1, rn = jn & 15;
+        if (cL == rn) {                                   // publish column j + 1 (rows up to the pivot as zeros)
+            double v[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = a < BN ? 0.0 : s[4 * a + BN];
+            if (rL <= rn) v[BN] = 0.0;
+            *reinterpret_cast<double2*>(imn + rL * 4) = make_double2(v[0], v[1]);
+            *reinterpret_cast<double2*>(imn + rL * 4 + 2) = make_double2(v[2], v[3]);
+            if (rL == rn) pd[nslot] = s[4 * BN + BN];
+        }
+    }
+    if (rL == (j & 15) && cL == (j & 15)) { s[4 * Q + Q] = p; piv[j] = p; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { st.ar[a] = ar[a]; st.cv[a] = cv[a]; }
+    st.slot = nslot;
+    __syncthreads();
+}
+
+template <int Q>
+__device__ __forceinline__ void potf2_phase(v16d& s, Potf2State& st, double* colbuf, const double* dsh, double* piv,
+                                            double pivtol) {
+    potf2_step<Q, Q, Q - 1, Q>(s, st, 16 * Q, colbuf, dsh, piv, pivtol);          // previous pivot: last of phase Q-1
+#pragma unroll 1
+    for (int jl = 1; jl < 15; ++jl) potf2_step<Q, Q, Q, Q>(s, st, 16 * Q + jl, colbuf, dsh, piv, pivtol);
+    potf2_step<Q, Q + 1, Q, Q>(s, st, 16 * Q + 15, colbuf, dsh, piv, pivtol);     // next column lives in slot Q+1
+}
+
+__device__ __forceinline__ void potf2_2d(v16d& s, double* colbuf, const double* dsh, double* piv, double pivtol,
+                                         int* flag, bool count) {
+    const int rL = threadIdx.x >> 4, cL = threadIdx.x & 15;
+    double* pd = colbuf + 3 * CB;
+    if (cL == 0) {                                        // column 0
+        *reinterpret_cast<double2*>(colbuf + rL * 4) = make_double2(rL > 0 ? s[0] : 0.0, s[4]);
+        *reinterpret_cast<double2*>(colbuf + rL * 4 + 2) = make_double2(s[8], s[12]);
+        if (rL == 0) pd[0] = s[0];
+    }
+    __syncthreads();
+    Potf2State st;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) st.ar[a] = st.cv[a] = 0.0;
+    st.slot = 0; st.nbad = 0;
+    potf2_phase<0>(s, st, colbuf, dsh, piv, pivtol);
+    potf2_phase<1>(s, st, colbuf, dsh, piv, pivtol);
+    potf2_phase<2>(s, st, colbuf, dsh, piv, pivtol);
+    potf2_phase<3>(s, st, colbuf, dsh, piv, pivtol);
+    if (count && threadIdx.x == 0 && st.nbad) atomicAdd(flag, st.nbad);
 }
 
 __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
@@ -282,10 +298,13 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     double(*AR)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R2);    // 16 rows of L_i,k-1
     double* dsh = smem + R3;                              // original diagonal of this block (64)
     double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
-    double* colbuf = dinv + CB;                           // 3 x 64 + 4 (16-byte aligned)
+    double* colbuf = dinv + CB;                           // 3 x 64 image slots + 4 pivot slots (16-byte aligned)
     const bool rows = b > 0;
     const long r0 = rows ? (long)(k + 1 + (b - 1) / 4) * CB + 16 * ((b - 1) & 3) : 0;
-    v4d accS[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    // acc[b][a]: rows 16 a + rL, columns 16 b + cL of L_k,k-1 L_k,k-1' -- the 2-D cyclic layout of potf2_2d:
+    // wave w takes the row residues 4 w .. 4 w + 3 of every 16-row block (a permuted A operand costs nothing)
+    const int rL = tid >> 4, cL = tid & 15;
+    v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     v4d accC = {0, 0, 0, 0};
     TRACE(0)
     if (k > 0) {
@@ -299,7 +318,17 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         }
         __syncthreads();
         TRACE(1)
-        mma64<true>(X, X, 0, CB, accS);
+        {
+            const int m = lane & 15, arow = 16 * (m >> 2) + 4 * wv + (m & 3);
+#pragma unroll 4
+            for (int k0 = 0; k0 < CB; k0 += 4) {
+                const int kx = k0 + (lane >> 4);
+                const double av = X[arow][kx];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb)
+                    acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[16 * bb + m][kx], acc[bb], 0, 0, 0);
+            }
+        }
         if (rows) {
 #pragma unroll 4
             for (int k0 = 0; k0 < CB; k0 += 4) {
@@ -307,23 +336,21 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
                 accC = __builtin_amdgcn_mfma_f64_16x16x4f64(AR[lane & 15][kx], X[16 * wv + (lane & 15)][kx], accC, 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     TRACE(2)
-    acc_foreach(accS, [&](int r, int c, double v) { Y[r * YLD + c] = H[(kk + r) * np + kk + c] - v; });
-    if (tid < CB) dsh[tid] = a.d0[kk + tid];
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
-    v16d rv;
+    v16d sv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = ty + 4 * i;
-        rv[i] = c <= tx ? Y[tx * YLD + c] : 0.0;
-    }
-    __syncthreads();
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const int r = 16 * aa + rL, c = 16 * bb + cL;
+            sv[4 * aa + bb] = c <= r ? H[(kk + r) * np + kk + c] - acc[bb][aa] : 0.0;
+        }
+    if (tid < CB) dsh[tid] = a.d0[kk + tid];
+    if (tid < 3 * CB + 4) colbuf[tid] = 0.0;
+    __syncthreads();                                      // also: everybody is done with X (the image goes there)
     TRACE(3)
-    potf2_regs(rv, colbuf, dsh, dinv, a.pivtol, a.flag, b == 0);
-    __syncthreads();
+    potf2_2d(sv, colbuf, dsh, dinv, a.pivtol, a.flag, b == 0);
     TRACE(4)
     if (tid < CB) {                                       // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
         const double p = dinv[tid];
@@ -335,10 +362,12 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     __syncthreads();
     double* Lz = smem + R0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {                        // L_tc = S_tc / sqrt(p_c), strictly lower part
-        const int c = ty + 4 * i;
-        Lz[c * ZLD + zpos(tx)] = tx > c ? rv[i] * dinv[c] : 0.0;
-    }
+    for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {                  // L_rc = S_rc / sqrt(p_c), strictly lower part
+            const int r = 16 * aa + rL, c = 16 * bb + cL;
+            Lz[c * ZLD + zpos(r)] = r > c ? sv[4 * aa + bb] * dinv[c] : 0.0;
+        }
     if (rows) {                                           // updated rows of A_ik (MFMA layout -> one row per DPP row)
         const int cc = 16 * wv + (lane & 15);
 #pragma unroll
