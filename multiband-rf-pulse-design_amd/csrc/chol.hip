@@ -145,106 +145,100 @@ __device__ __forceinline__ void subst16(const double* __restrict__ Lz, const dou
     v[0] = v0 * dm0; v[1] = v1 * dm1; v[2] = v2 * dm2; v[3] = v3 * dm3;
 }
 
-// Unblocked right-looking Cholesky of a 64x64 block held in registers, 2-D cyclic layout: thread
-// (rL = tid >> 4, cL = tid & 15) owns rows rL + 16 a and columns cL + 16 b in s[4 a + b] -- exactly
-// what the MFMA product of panel_block leaves in its accumulators, so the block never goes through
-// LDS.  Column j is broadcast through a triple-buffered LDS image (index ipos(t) = (t & 15) * 4 +
-// (t >> 4), so the 4 entries a thread writes or reads are contiguous), one barrier per pivot, the
-// entries up to the pivot written as zeros, which masks every finished row and column without a
-// select; the pivot itself travels in pd[].  Per pivot a thread reads 2 x 32 bytes (its 4 row
-// values, its 4 column values) and does (4 - Q)^2 fmas, Q = j / 16 (dead slots are skipped
-// statically: one code body per phase).  The dependent chain is
-//     read -> 1/p -> scale -> 4 fmas on the slot of the next column -> publish,
-// the other slots of the rank-1 update are issued one pivot late, in the shadow of the next
-// pivot's LDS reads.  Square-root free (S_rc -= S_rj S_cj / p_j, 1/p from v_rcp_f64 + one Newton
-// step); the pivots go to piv[] and the caller applies L_rc = S_rc / sqrt(p_c).  Only the lower
-// triangle of the result is meaningful.  colbuf: 3 x 64 image slots + 4 pivot slots.
-struct Potf2State {
-    double ar[4], cv[4];      // scaled row values / column values of the previous pivot (late update)
-    int slot, nbad;
-};
+// ---- factorisation of the 64x64 diagonal block: four 16-column slabs -------------------------------
+// The trailing matrix lives in MFMA accumulators (the ten lower 16x16 tiles, dealt to the 4 waves by
+// the table below); per slab
+//   (1) the owners of its tiles put the slab (64 x 16) into the LDS array LB,
+//   (2) ONE wave eliminates it right-looking with lane = row and the 16 columns in registers: the
+//       pivot-row values come from v_readlane into SGPRs (no LDS, no barrier inside a slab; 99 ns
+//       per pivot measured, against 275 ns for an LDS broadcast + barrier per pivot),
+//   (3) the other tiles get their rank-16 update on the matrix cores (operands: the finished slab,
+//       unscaled from LB and scaled by -1/pivot from LS).
+// Square-root free (S_rc -= S_rj S_cj / p_j, 1/p from v_rcp_f64 + one Newton step); LB ends up
+// holding S_rc for the whole lower triangle and piv[] the pivots; the caller applies
+// L_rc = S_rc / sqrt(p_c).  Pivot rule as described at the top of this file.
+constexpr int LBLD = 65, LSLD = 17;
 
-// one pivot: j = 16 Q + jl; BN = slot of the next column (Q, or Q + 1 for jl = 15); QP / BNP describe
-// the previous pivot (QP < 0: none)
-template <int Q, int BN, int QP, int BNP>
-__device__ __forceinline__ void potf2_step(v16d& s, Potf2State& st, int j, double* colbuf, const double* dsh,
-                                           double* piv, double pivtol) {
-    const int rL = threadIdx.x >> 4, cL = threadIdx.x & 15;
-    const int slot = st.slot, nslot = slot == 2 ? 0 : slot + 1;
-    const double* img = colbuf + slot * CB;
-    double* imn = colbuf + nslot * CB;
-    double* pd = colbuf + 3 * CB;
-    const double p0 = pd[slot];
-    const double dj = dsh[j];
-    const double2 r01 = *reinterpret_cast<const double2*>(img + rL * 4), r23 = *reinterpret_cast<const double2*>(img + rL * 4 + 2);
-    const double2 c01 = *reinterpret_cast<const double2*>(img + cL * 4), c23 = *reinterpret_cast<const double2*>(img + cL * 4 + 2);
-    if constexpr (QP >= 0) {                               // late part of the previous pivot's rank-1 update
+// tiles of wave w: (ti, tj) pairs, 4 bits each (ti | tj << 2), count in bits 12..
+//   w0: (0,0) (2,1) (3,2)   w1: (1,0) (2,2) (3,3)   w2: (1,1) (3,0)   w3: (2,0) (3,1)
+__device__ __forceinline__ unsigned wave_tiles(int wv) {
+    return wv == 0 ? (3u << 12 | 0x0u | 0x6u << 4 | 0xBu << 8)
+         : wv == 1 ? (3u << 12 | 0x1u | 0xAu << 4 | 0xFu << 8)
+         : wv == 2 ? (2u << 12 | 0x5u | 0x3u << 4)
+                   : (2u << 12 | 0x2u | 0x7u << 4);
+}
+
+__device__ __forceinline__ double rdlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// the 16 pivots of one slab; t[c] = S[row = lane][16 b + c], base = 16 b; rp = 1 / pivot, pv = pivot
+template <int J>
+__device__ __forceinline__ void slab_steps(double (&t)[16], double (&rp)[16], double (&pv)[16], const double* dsh,
+                                           int base, double pivtol, int& nbad) {
+    if constexpr (J < 16) {
+        double p = rdlane(t[J], base + J);
+        const double dj = dsh[base + J];
+        const bool bad = !(p > pivtol * dj);
+        p = bad ? fmax(dj, 1e-300) : p;
+        nbad += bad;
+        double rcp = __builtin_amdgcn_rcp(p);             // ~26 bits
+        rcp = rcp * fma(-p, rcp, 2.0);                    // 1/p to rounding
+        const double l = t[J] * rcp;
 #pragma unroll
-        for (int a = QP; a < 4; ++a)
-#pragma unroll
-            for (int b = QP; b < 4; ++b)
-                if (b != BNP) s[4 * a + b] -= st.ar[a] * st.cv[b];
+        for (int c = J + 1; c < 16; ++c) t[c] -= l * rdlane(t[J], base + c);
+        rp[J] = rcp; pv[J] = p;
+        slab_steps<J + 1>(t, rp, pv, dsh, base, pivtol, nbad);
     }
-    const double pfix = fmax(dj, 1e-300);
-    const bool bad = !(p0 > pivtol * dj);
-    const double p = bad ? pfix : p0;
-    st.nbad += bad;
-    double rcp = __builtin_amdgcn_rcp(p);                 // ~26 bits
-    rcp = rcp * fma(-p, rcp, 2.0);                        // 1/p to rounding
-    const double rv[4] = {r01.x, r01.y, r23.x, r23.y};
-    const double cv[4] = {c01.x, c01.y, c23.x, c23.y};
-    double ar[4];
+}
+
+// acc[q]: the wave's tiles of S (MFMA D layout).  LB: 64 x LBLD, LS: 64 x LSLD, piv: 64.
+__device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, double* LB, double* LS, const double* dsh,
+                                            double* piv, double pivtol, int* flag, bool count) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, g = lane >> 4, nt = int(tiles >> 12);
+    int nbad = 0;
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ar[a] = a >= Q ? rv[a] * rcp : 0.0;    // 0 for the rows up to the pivot
-    if constexpr (BN < 4) {
+        for (int q = 0; q < 3; ++q) {                     // (1) slab b -> LB
+            const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
+            if (q < nt && tj == b) {
 #pragma unroll
-        for (int a = Q; a < 4; ++a) s[4 * a + BN] -= ar[a] * cv[BN];   // the slot the next column lives in
-        const int jn = j + 1, rn = jn & 15;
-        if (cL == rn) {                                   // publish column j + 1 (rows up to the pivot as zeros)
-            double v[4];
+                for (int r = 0; r < 4; ++r) LB[(16 * ti + g + 4 * r) * LBLD + 16 * b + m] = acc[q][r];
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {                                    // (2) eliminate: lane = row
+            double t[16], rp[16], pv[16];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) v[a] = a < BN ? 0.0 : s[4 * a + BN];
-            if (rL <= rn) v[BN] = 0.0;
-            *reinterpret_cast<double2*>(imn + rL * 4) = make_double2(v[0], v[1]);
-            *reinterpret_cast<double2*>(imn + rL * 4 + 2) = make_double2(v[2], v[3]);
-            if (rL == rn) pd[nslot] = s[4 * BN + BN];
+            for (int c = 0; c < 16; ++c) t[c] = LB[lane * LBLD + 16 * b + c];
+            slab_steps<0>(t, rp, pv, dsh, 16 * b, pivtol, nbad);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                LB[lane * LBLD + 16 * b + c] = t[c];
+                LS[lane * LSLD + c] = -t[c] * rp[c];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) piv[16 * b + c] = pv[c];
+            }
+        }
+        __syncthreads();
+        if (b == 3) break;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                     // (3) rank-16 update of the tiles right of the slab
+            const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
+            if (q < nt && tj > b) {
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(LS[(16 * ti + m) * LSLD + k0 + g],
+                                                                  LB[(16 * tj + m) * LBLD + 16 * b + k0 + g], acc[q], 0, 0, 0);
+            }
         }
     }
-    if (rL == (j & 15) && cL == (j & 15)) { s[4 * Q + Q] = p; piv[j] = p; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { st.ar[a] = ar[a]; st.cv[a] = cv[a]; }
-    st.slot = nslot;
-    __syncthreads();
-}
-
-template <int Q>
-__device__ __forceinline__ void potf2_phase(v16d& s, Potf2State& st, double* colbuf, const double* dsh, double* piv,
-                                            double pivtol) {
-    potf2_step<Q, Q, Q - 1, Q>(s, st, 16 * Q, colbuf, dsh, piv, pivtol);          // previous pivot: last of phase Q-1
-#pragma unroll 1
-    for (int jl = 1; jl < 15; ++jl) potf2_step<Q, Q, Q, Q>(s, st, 16 * Q + jl, colbuf, dsh, piv, pivtol);
-    potf2_step<Q, Q + 1, Q, Q>(s, st, 16 * Q + 15, colbuf, dsh, piv, pivtol);     // next column lives in slot Q+1
-}
-
-__device__ __forceinline__ void potf2_2d(v16d& s, double* colbuf, const double* dsh, double* piv, double pivtol,
-                                         int* flag, bool count) {
-    const int rL = threadIdx.x >> 4, cL = threadIdx.x & 15;
-    double* pd = colbuf + 3 * CB;
-    if (cL == 0) {                                        // column 0
-        *reinterpret_cast<double2*>(colbuf + rL * 4) = make_double2(rL > 0 ? s[0] : 0.0, s[4]);
-        *reinterpret_cast<double2*>(colbuf + rL * 4 + 2) = make_double2(s[8], s[12]);
-        if (rL == 0) pd[0] = s[0];
-    }
-    __syncthreads();
-    Potf2State st;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) st.ar[a] = st.cv[a] = 0.0;
-    st.slot = 0; st.nbad = 0;
-    potf2_phase<0>(s, st, colbuf, dsh, piv, pivtol);
-    potf2_phase<1>(s, st, colbuf, dsh, piv, pivtol);
-    potf2_phase<2>(s, st, colbuf, dsh, piv, pivtol);
-    potf2_phase<3>(s, st, colbuf, dsh, piv, pivtol);
-    if (count && threadIdx.x == 0 && st.nbad) atomicAdd(flag, st.nbad);
+    if (count && threadIdx.x == 0 && nbad) atomicAdd(flag, nbad);
 }
 
 __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
@@ -298,13 +292,12 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     double(*AR)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R2);    // 16 rows of L_i,k-1
     double* dsh = smem + R3;                              // original diagonal of this block (64)
     double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
-    double* colbuf = dinv + CB;                           // 3 x 64 image slots + 4 pivot slots (16-byte aligned)
     const bool rows = b > 0;
     const long r0 = rows ? (long)(k + 1 + (b - 1) / 4) * CB + 16 * ((b - 1) & 3) : 0;
-    // acc[b][a]: rows 16 a + rL, columns 16 b + cL of L_k,k-1 L_k,k-1' -- the 2-D cyclic layout of potf2_2d:
-    // wave w takes the row residues 4 w .. 4 w + 3 of every 16-row block (a permuted A operand costs nothing)
-    const int rL = tid >> 4, cL = tid & 15;
-    v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    // the wave's tiles of S = A_kk - L_k,k-1 L_k,k-1' (lower triangle, 16x16 tiles, MFMA D layout)
+    const unsigned tiles = wave_tiles(wv);
+    const int nt = int(tiles >> 12), m16 = lane & 15, g4 = lane >> 4;
+    v4d acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     v4d accC = {0, 0, 0, 0};
     TRACE(0)
     if (k > 0) {
@@ -318,39 +311,40 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         }
         __syncthreads();
         TRACE(1)
-        {
-            const int m = lane & 15, arow = 16 * (m >> 2) + 4 * wv + (m & 3);
-#pragma unroll 4
-            for (int k0 = 0; k0 < CB; k0 += 4) {
-                const int kx = k0 + (lane >> 4);
-                const double av = X[arow][kx];
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb)
-                    acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[16 * bb + m][kx], acc[bb], 0, 0, 0);
+        for (int q = 0; q < 3; ++q) {
+            const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
+            if (q < nt) {
+#pragma unroll 4
+                for (int k0 = 0; k0 < CB; k0 += 4) {
+                    const int kx = k0 + g4;
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[16 * ti + m16][kx], X[16 * tj + m16][kx], acc[q], 0, 0, 0);
+                }
             }
         }
         if (rows) {
 #pragma unroll 4
             for (int k0 = 0; k0 < CB; k0 += 4) {
-                const int kx = k0 + (lane >> 4);
-                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(AR[lane & 15][kx], X[16 * wv + (lane & 15)][kx], accC, 0, 0, 0);
+                const int kx = k0 + g4;
+                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(AR[m16][kx], X[16 * wv + m16][kx], accC, 0, 0, 0);
             }
         }
     }
     TRACE(2)
-    v16d sv;
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa)
+    for (int q = 0; q < 3; ++q) {
+        const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
+        if (q < nt) {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const int r = 16 * aa + rL, c = 16 * bb + cL;
-            sv[4 * aa + bb] = c <= r ? H[(kk + r) * np + kk + c] - acc[bb][aa] : 0.0;
+            for (int r = 0; r < 4; ++r) acc[q][r] = H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] - acc[q][r];
         }
+    }
     if (tid < CB) dsh[tid] = a.d0[kk + tid];
-    if (tid < 3 * CB + 4) colbuf[tid] = 0.0;
-    __syncthreads();                                      // also: everybody is done with X (the image goes there)
+    double* LB = smem + R1;                               // 64 x LBLD: slabs, then S_rc of the whole lower triangle
+    double* LS = smem + R2;                               // 64 x LSLD: the current slab scaled by -1 / pivot
+    __syncthreads();                                      // also: everybody is done with X and AR
     TRACE(3)
-    potf2_2d(sv, colbuf, dsh, dinv, a.pivtol, a.flag, b == 0);
+    potf2_slabs(acc, tiles, LB, LS, dsh, dinv, a.pivtol, a.flag, b == 0);
     TRACE(4)
     if (tid < CB) {                                       // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
         const double p = dinv[tid];
@@ -362,12 +356,11 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     __syncthreads();
     double* Lz = smem + R0;
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {                  // L_rc = S_rc / sqrt(p_c), strictly lower part
-            const int r = 16 * aa + rL, c = 16 * bb + cL;
-            Lz[c * ZLD + zpos(r)] = r > c ? sv[4 * aa + bb] * dinv[c] : 0.0;
-        }
+    for (int u = 0; u < 16; ++u) {                        // L_rc = S_rc / sqrt(p_c), strictly lower part
+        const int e = tid + 256 * u, r = e & 63, c = e >> 6;
+        Lz[c * ZLD + zpos(r)] = r > c ? LB[r * LBLD + c] * dinv[c] : 0.0;
+    }
+    __syncthreads();                                      // LB is free again (Y aliases it)
     if (rows) {                                           // updated rows of A_ik (MFMA layout -> one row per DPP row)
         const int cc = 16 * wv + (lane & 15);
 #pragma unroll
