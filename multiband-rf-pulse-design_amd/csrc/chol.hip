@@ -524,7 +524,8 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
 // y[v][i] = sum_j T[i][j] b[v][j] over the stored triangle; one wave per row, 16-byte loads.
 template <int NV>
 __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, int np, int upper,
-                                                 const double* __restrict__ b, double* __restrict__ y, int ldv) {
+                                                 const double* __restrict__ b, const double* __restrict__ b2,
+                                                 double* __restrict__ y, int ldv) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     if (i >= np) return;
@@ -539,6 +540,10 @@ __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, i
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             double2 bb = *reinterpret_cast<const double2*>(b + (long)v * ldv + j);
+            if (b2) {
+                const double2 cc = *reinterpret_cast<const double2*>(b2 + (long)v * ldv + j);
+                bb.x += cc.x; bb.y += cc.y;
+            }
             acc[v] += t.x * bb.x + t.y * bb.y;
         }
     }
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, i
 }
 
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
-                    hipStream_t st) {
+                    hipStream_t st, const double* b2) {
     dim3 grid(cdiv(np, 4));
-    if (nv == 1) hipLaunchKernelGGL(k_trigemv<1>, grid, dim3(256), 0, st, T, np, upper, b, y, ldv);
-    else if (nv == 2) hipLaunchKernelGGL(k_trigemv<2>, grid, dim3(256), 0, st, T, np, upper, b, y, ldv);
+    if (nv == 1) hipLaunchKernelGGL(k_trigemv<1>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv);
+    else if (nv == 2) hipLaunchKernelGGL(k_trigemv<2>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv);
     else throw HipError("trigemv_launch: nv must be 1 or 2");
 }
 

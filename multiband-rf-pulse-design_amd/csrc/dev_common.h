@@ -88,9 +88,10 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
                      double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
-// y[v] = Lo * b[v] for a row-major lower (upper=0) or upper (upper=1) triangular np x np matrix.
+// y[v] = Lo * (b[v] + b2[v]) for a row-major lower (upper=0) or upper (upper=1) triangular np x np
+// matrix; b2 may be null.
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
-                    hipStream_t st);
+                    hipStream_t st, const double* b2 = nullptr);
 
 // Spectral factorisation (fir_ap_cvx.m:185-186,264-304): x (2n-1) -> n taps (re, im interleaved
 // in hout[2n]).  work must hold 6*lp doubles, lp = 8*2^ceil(log2(2n-1)).

@@ -116,6 +116,27 @@ __global__ __launch_bounds__(256) void k_amulti(const double* __restrict__ A1, i
     }
 }
 
+// one row of G v from the per-frequency products
+template <int NV>
+__device__ __forceinline__ double row_value(const DProg& P, const double* __restrict__ UU, const double* __restrict__ X,
+                                            int r, int v) {
+    const int f = P.freq[r], cl = P.col[r];
+    const double al = P.alpha[r], be = P.beta[r];
+    double val = 0;
+    if (f >= 0) {
+        const int NVV = P.quad ? 2 * NV : NV;
+        double u1 = 0, u2 = 0;
+        for (int sg = 0; sg < P.useg; ++sg) {
+            u1 += UU[((long)sg * NVV + v) * P.Mpad + f];
+            if (P.quad) u2 += UU[((long)sg * NVV + NV + v) * P.Mpad + f];
+        }
+        val = al * u1 + be * u2;
+    } else if (cl >= 0) {
+        val = al * X[(long)v * P.LDV + cl];
+    }
+    for (int e = 0; e < P.Ne; ++e) val += P.ey[3 * r + e] * X[(long)v * P.LDV + P.Nt + e];
+    return val;
+}
 // rows of G v from the per-frequency products
 template <int NV>
 __global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* __restrict__ X,
@@ -340,43 +361,51 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
 //    progressions (differences, sums): O(Mf N) instead of the O(Mf N^2) of a dense A1' D A1.
 constexpr int CHK = 128;      // frequencies per chunk
 
-// XL[(vv*2 + kind)][m] = coefficient of cos|sin(w (tmin + m)) in A1 * [v ; P'v]
+// K1 (lattice): UU[sg][vv][i] = sum_{m in segment sg} XL[vv][cos][m] cos(w_i t_m) + XL[vv][sin][m] sin(w_i t_m),
+// XL = the lattice coefficients of A1 * [v ; P'v] (column scale * entry of v, or of P'v), formed here in
+// LDS for the block's segment; one thread per (frequency, segment), the coefficient reads are wave-uniform.
+constexpr int SEGMAX = 128;
 template <int NV>
-__global__ void k_make_lattice(DProg P, const double* __restrict__ v, double* __restrict__ XL) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // (kind, m)
-    if (e >= 2 * P.D1) return;
-    const int kind = e / P.D1, m = e - kind * P.D1;
-    const int j = P.lat_col[e], qj = P.quad ? P.lat_qcol[e] : -1;
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        XL[((long)q * 2 + kind) * P.LDL + m] = j >= 0 ? P.lat_scale[e] * v[(long)q * P.LDV + j] : 0.0;
-        if (P.quad) XL[((long)(NV + q) * 2 + kind) * P.LDL + m] = qj >= 0 ? P.lat_qscale[e] * v[(long)q * P.LDV + qj] : 0.0;
-    }
-}
-
-// K1 (lattice): UU[sg][vv][i] = sum_{m in segment sg} XL[vv][cos][m] cos(w_i t_m) + XL[vv][sin][m] sin(w_i t_m);
-// one thread per (frequency, segment), the coefficients are wave-uniform (scalar loads).
-template <int NVV>
-__global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __restrict__ XL, double* __restrict__ UU) {
+__global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __restrict__ vin, double* __restrict__ UU) {
+    constexpr int NVVMAX = 2 * NV;
+    __shared__ double2 cf[NVVMAX][SEGMAX];                // (cos, sin) coefficient pairs
     const int i = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
-    if (i >= P.Mf) return;
     const int m0 = sg * P.seg, m1 = min(m0 + P.seg, P.D1);
+    const int NVV = P.quad ? 2 * NV : NV;
+    for (int e = threadIdx.x; e < 2 * (m1 - m0); e += 256) {
+        const int kind = e & 1, m = m0 + (e >> 1), le = kind * P.D1 + m;
+        const int j = P.lat_col[le], qj = P.quad ? P.lat_qcol[le] : -1;
+        const double sc = P.lat_scale[le], qs = P.quad ? P.lat_qscale[le] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const double c1 = j >= 0 ? sc * vin[(long)q * P.LDV + j] : 0.0;
+            if (kind) cf[q][e >> 1].y = c1; else cf[q][e >> 1].x = c1;
+            if (P.quad) {
+                const double c2 = qj >= 0 ? qs * vin[(long)q * P.LDV + qj] : 0.0;
+                if (kind) cf[NV + q][e >> 1].y = c2; else cf[NV + q][e >> 1].x = c2;
+            }
+        }
+    }
+    __syncthreads();
+    if (i >= P.Mf) return;
     const double w = P.w[i];
     double s, c, sw, cw;
     sincos(w * (P.tmin + m0), &s, &c);
     sincos(w, &sw, &cw);
-    double acc[NVV];
+    double acc[NVVMAX];
 #pragma unroll
-    for (int v = 0; v < NVV; ++v) acc[v] = 0;
-    for (int m = m0; m < m1; ++m) {
+    for (int v = 0; v < NVVMAX; ++v) acc[v] = 0;
+    for (int m = 0; m < m1 - m0; ++m) {
 #pragma unroll
-        for (int v = 0; v < NVV; ++v) acc[v] += XL[(long)(2 * v) * P.LDL + m] * c + XL[(long)(2 * v + 1) * P.LDL + m] * s;
+        for (int v = 0; v < NVVMAX; ++v)
+            if (v < NVV) { const double2 x = cf[v][m]; acc[v] += x.x * c + x.y * s; }
         const double cn = c * cw - s * sw;
         s = s * cw + c * sw;
         c = cn;
     }
 #pragma unroll
-    for (int v = 0; v < NVV; ++v) UU[((long)sg * NVV + v) * P.Mpad + i] = acc[v];
+    for (int v = 0; v < NVVMAX; ++v)
+        if (v < NVV) UU[((long)sg * NVV + v) * P.Mpad + i] = acc[v];
 }
 
 // K3 / K2 (lattice): partial[chunk][v][0|1][m] = sum_{i in chunk} p_v[i] cos|sin(w_i t_m), t_m on up to
@@ -609,6 +638,34 @@ __global__ void k_winv2(DProg P, const double* __restrict__ dl, const double* __
                 if (mode == 0) out[o + a] = rr[a] - (sub ? sub[o + a] : 0.0);
                 else out[o + a] += rr[a];
             }
+        }
+    }
+}
+// rows of G v AND out = W^-2 (G v) - sub in one pass (programs without a big cone): one thread per
+// LP row / Q3 cone
+template <int NV>
+__global__ void k_rows_winv2(DProg P, const double* __restrict__ UU, const double* __restrict__ X,
+                             const double* __restrict__ dl, const double* __restrict__ w3,
+                             const double* __restrict__ sub, double* __restrict__ gout, double* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.l) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const long o = (long)v * P.Rp + t;
+            const double gv = row_value<NV>(P, UU, X, t, v);
+            gout[o] = gv;
+            out[o] = dl[t] * gv - (sub ? sub[o] : 0.0);
+        }
+    } else if (t < P.l + P.nq3) {
+        const int c = t - P.l;
+        const Soc3 W = load_w3(w3, c);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const long o = (long)v * P.Rp + P.l + 3 * c;
+            double vv[3], rr[3];
+            for (int a = 0; a < 3; ++a) { vv[a] = row_value<NV>(P, UU, X, P.l + 3 * c + a, v); gout[o + a] = vv[a]; }
+            soc3_inv2_apply(W, vv, rr);
+            for (int a = 0; a < 3; ++a) out[o + a] = rr[a] - (sub ? sub[o + a] : 0.0);
         }
     }
 }
@@ -1455,11 +1512,7 @@ struct Solver::Impl {
     void apply_G(const double* v, double* out) {
         const int NVV = P.quad ? 2 * NV : NV;
         if (P.trig) {
-            hipLaunchKernelGGL(k_make_lattice<NV>, dim3(cdiv(2 * P.D1, 256)), dim3(256), 0, st, P, v, XL);
-            dim3 g(cdiv(P.Mf, 256), P.useg);
-            if (NVV == 1) hipLaunchKernelGGL(k_trig_eval<1>, g, dim3(256), 0, st, P, XL, UU);
-            else if (NVV == 2) hipLaunchKernelGGL(k_trig_eval<2>, g, dim3(256), 0, st, P, XL, UU);
-            else hipLaunchKernelGGL(k_trig_eval<4>, g, dim3(256), 0, st, P, XL, UU);
+            hipLaunchKernelGGL(k_trig_eval<NV>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, v, UU);
             hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
             return;
         }
@@ -1473,6 +1526,18 @@ struct Solver::Impl {
         else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
         else hipLaunchKernelGGL(k_amulti<4>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
         hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
+    }
+    // gout = G v and wout = W^-2 gout - sub; one kernel less than apply_G + winv2 on the lattice path
+    // without a big cone
+    template <int NV>
+    void apply_G_winv2(const double* v, double* gout, const double* sub, double* wout) {
+        if (P.trig && !P.big) {
+            hipLaunchKernelGGL(k_trig_eval<NV>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, v, UU);
+            hipLaunchKernelGGL(k_rows_winv2<NV>, dim3(cdiv(P.l + P.nq3, 256)), dim3(256), 0, st, P, UU, v, dl, w3, sub, gout, wout);
+            return;
+        }
+        apply_G<NV>(v, gout);
+        winv2<NV>(gout, sub, wout, 0);
     }
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
@@ -1533,10 +1598,9 @@ struct Solver::Impl {
         const dim3 gN(nbN), gR(cdiv(P.R, 256)), b256(256);
         winv2<NV>(bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
-        hipLaunchKernelGGL(k_add_n<NV>, gN, b256, 0, st, P, bx, tmpN, 1.0, rhsN);
-        hsolve<NV>(rhsN, dx);
-        apply_G<NV>(dx, gdx);
-        winv2<NV>(gdx, wbz, dz, 0);
+        trigemv_launch(M, P.np, 0, bx, yN, NV, P.LDV, st, tmpN);                            // M (bx + G' W^-2 bz)
+        trigemv_launch(Mt, P.np, 1, yN, dx, NV, P.LDV, st);
+        apply_G_winv2<NV>(dx, gdx, wbz, dz);
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
         hipLaunchKernelGGL(k_resid_norm<NV>, dim3(1), dim3(1024), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
@@ -1544,8 +1608,7 @@ struct Solver::Impl {
         hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
             hipLaunchKernelGGL(k_cg_start<NV>, dim3(1), dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
-            apply_G<NV>(pN, tmpR);                                                          // G p
-            winv2<NV>(tmpR, nullptr, wpR, 0);                                               // W^-2 G p
+            apply_G_winv2<NV>(pN, tmpR, nullptr, wpR);                                      // G p, W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
             hipLaunchKernelGGL(k_cg_step<NV>, dim3(1), dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
             hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
@@ -1570,9 +1633,18 @@ struct Solver::Impl {
         hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
         if (P.trig) {
             if (g0) hipEventRecord(g0, st);
-            moments_array(P.quad ? 3 : 1, Dw, 0.0, P.D1, 2.0 * P.tmin, 2 * P.D1 - 1, Mom);
-            if (P.Ne > 0) moments_array(P.quad ? 2 * P.Ne : P.Ne, BB, P.tmin, P.D1, 0.0, 0, MomB);
-            hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, MomB, H, shard_rank == 0 ? 1.0 : 0.0);
+            const int nwv = P.quad ? 3 : 1, nvb = P.quad ? 2 * P.Ne : P.Ne;
+            const double* momb = MomB;
+            if (P.Ne > 0 && P.tmin == 0.0 && nwv + nvb <= 4) {
+                // delays start at 0: the border moments sit on the difference progression, one launch does both
+                // (BB follows the weight vectors in memory)
+                moments_array(nwv + nvb, Dw, 0.0, P.D1, 0.0, 2 * P.D1 - 1, Mom);
+                momb = Mom + 2L * nwv * P.LDM;
+            } else {
+                moments_array(nwv, Dw, 0.0, P.D1, 2.0 * P.tmin, 2 * P.D1 - 1, Mom);
+                if (P.Ne > 0) moments_array(nvb, BB, P.tmin, P.D1, 0.0, 0, MomB);
+            }
+            hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
         } else {
         gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
@@ -1685,7 +1757,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     DProg& P = S.P;
     P.trig = Lt.ok ? 1 : 0;
     P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
-    P.seg = std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8)));
+    P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
     P.nchunk = int(Lt.ch_start.size());
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
@@ -1720,7 +1792,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
     S.T = ar.get<double>(P.trig ? 0 : nw * ld * ld);
-    S.XL = ar.get<double>(8 * (size_t)P.LDL); S.Mom = ar.get<double>(6 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
+    S.XL = ar.get<double>(8 * (size_t)P.LDL); S.Mom = ar.get<double>(18 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
@@ -1735,7 +1807,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
-    S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(3 * Mpad); S.BB = ar.get<double>(6 * Mpad);
+    S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(P.trig ? (size_t)P.nchunk * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
