@@ -313,6 +313,8 @@ def fir_qprog_phs(n, f, ac, dc, x0=None, dbg=0, *, opts=None, ctx=None, info=Fal
     return _finish(ctx, rc, hre, him, inf, info)
 
 
+from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)
+
 _WHICH = {"fir_ap_cvx": 0, "fir_qp_cvx": 1, "fir_linprog": 2, "fir_qprog_phs": 3}
 _pools = {}
 
