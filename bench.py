@@ -32,6 +32,12 @@ F100 = [-0.241994, -0.233994, -0.152431, -0.144431, -0.083851, -0.075851, -0.052
 A_C13 = [0.0] * 8 + [0.500125, 0.500125]
 D_C13 = [0.00250001] * 4 + [0.00866503]
 PEAK_FP64_MATRIX_TF = 78.6     # AMD's public MI355X fp64 matrix figure; the local hardware guide lists none
+# HBM-side bytes of one k_chol_step launch at np = 1024 from the PMC passes of this round
+# (profiles/r01d_pmc_fetch_write_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate
+# runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streaming reads on gfx950):
+# 2 x 3475.8 KB + 2620.7 KB.  Algorithmic: the tiles a panel step touches (~96 KB read per updated tile,
+# 32 KB written), 8.7 MB read + 2.6 MB written on average -- no re-read excess.
+CHOL_STEP_TRAFFIC_BYTES_NP1024 = (2 * 3475.8 + 2620.7) * 1024
 
 
 def workload(n):
@@ -171,7 +177,9 @@ def main():
         chol_ach = chol_flop_per_launch / (chol_avg_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
         roof_chol = {"kernel": "k_chol_step (blocked Cholesky + triangular inverse, one launch per 64-wide panel; tile "
                                "products on v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": chol_ach,
-                     "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": chol_ach / PEAK_FP64_MATRIX_TF, "traffic": None,
+                     "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": chol_ach / PEAK_FP64_MATRIX_TF,
+                     "traffic": CHOL_STEP_TRAFFIC_BYTES_NP1024 if infos[0]["n_unknowns"] == 1024 else None,
+                     "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01d_pmc_fetch_write_per_kernel.csv)",
                      "flop_per_launch": chol_flop_per_launch, "launches": chol_launches, "avg_launch_ms": chol_avg_ms,
                      "note": "dependency-chain bound, not throughput bound: 1024 sequential pivots per build, ~0.29 us each "
                              "(LDS broadcast + barrier + reciprocal per pivot); see DESIGN.md",
