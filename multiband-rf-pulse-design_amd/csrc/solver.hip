@@ -64,6 +64,10 @@ struct DProg {
     const double *lat_scale, *lat_qscale;
     const int *ch_start, *ch_count;   // nchunk
     const double *ch_w0, *ch_dw;
+    // rotation seeds, tabulated once per design (a sincos costs as much as ~40 recurrence steps):
+    const double4* seed_tau;          // [nchunk][D1]   (cos, sin)(w0 t), (cos, sin)(dw t), t = tmin + m
+    const double4* seed_h;            // [nchunk][3 D1 - 1]  same for the difference | sum progressions of the H moments
+    const double4* seed_eval;         // [useg][Mpad]   (cos, sin)(w_i (tmin + sg seg)), (cos, sin)(w_i)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -388,10 +392,9 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
     }
     __syncthreads();
     if (i >= P.Mf) return;
-    const double w = P.w[i];
-    double s, c, sw, cw;
-    sincos(w * (P.tmin + m0), &s, &c);
-    sincos(w, &sw, &cw);
+    const double4 sd4 = P.seed_eval[(long)sg * P.Mpad + i];
+    double c = sd4.x, s = sd4.y;
+    const double cw = sd4.z, sw = sd4.w;
     double acc[NVVMAX];
 #pragma unroll
     for (int v = 0; v < NVVMAX; ++v) acc[v] = 0;
@@ -408,14 +411,34 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
         if (v < NVV) UU[((long)sg * NVV + v) * P.Mpad + i] = acc[v];
 }
 
+// seed tables for the recurrences below (once per design)
+__global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb, double4* __restrict__ seeds) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (m >= na + nb) return;
+    const double t = m < na ? t0a + m : t0b + (m - na);
+    double s, c, sd, cd;
+    sincos(P.ch_w0[ch] * t, &s, &c);
+    sincos(P.ch_dw[ch] * t, &sd, &cd);
+    seeds[(long)ch * (na + nb) + m] = make_double4(c, s, cd, sd);
+}
+__global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
+    if (i >= P.Mf) return;
+    const double w = P.w[i];
+    double s, c, sw, cw;
+    sincos(w * (P.tmin + sg * P.seg), &s, &c);
+    sincos(w, &sw, &cw);
+    seeds[(long)sg * P.Mpad + i] = make_double4(c, s, cw, sw);
+}
+
 // K3 / K2 (lattice): partial[chunk][v][0|1][m] = sum_{i in chunk} p_v[i] cos|sin(w_i t_m), t_m on up to
-// two unit-step progressions (t0a + m, m < na; then t0b + (m - na)).  One thread per point m, the
+// two unit-step progressions (na points, then nb points; the seeds table knows them).  One thread per point m, the
 // chunk's operands sit in LDS: with AGG they are the per-frequency aggregates of a row vector
 // (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency), otherwise they are
 // read from the per-frequency array src[v][Mpad].
 template <int NV, bool AGG>
-__global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, double t0a, int na,
-                                                      double t0b, int nb, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, const double4* __restrict__ seeds,
+                                                      int na, int nb, double* __restrict__ partial) {
     __shared__ double pp[NV][CHK];
     const int tid = threadIdx.x, ch = blockIdx.y;
     const int start = P.ch_start[ch], cnt = P.ch_count[ch];
@@ -452,10 +475,9 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __r
     __syncthreads();
     const int m = blockIdx.x * 256 + tid;
     if (m >= na + nb) return;
-    const double t = m < na ? t0a + m : t0b + (m - na);
-    double s, c, sd, cd;
-    sincos(P.ch_w0[ch] * t, &s, &c);
-    sincos(P.ch_dw[ch] * t, &sd, &cd);
+    const double4 sd4 = seeds[(long)ch * (na + nb) + m];
+    double c = sd4.x, s = sd4.y;
+    const double cd = sd4.z, sd = sd4.w;
     double ag[NV], as[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) ag[v] = as[v] = 0;
@@ -1541,14 +1563,14 @@ struct Solver::Impl {
     }
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
-    void moments_array(int nv, const double* pp, double t0a, int na, double t0b, int nb, double* out) {
+    void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
         dim3 g(cdiv(na + nb, 256), P.nchunk), b(256);
         switch (nv) {
-            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
-            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
-            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
-            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
-            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), g, b, 0, st, P, pp, t0a, na, t0b, nb, partial); break;
+            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
             default: throw HipError("moments: unsupported vector count");
         }
         hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.LDM, 64), 2 * nv), dim3(64, 16), 0, st, partial, P.nchunk, 2 * nv, P.LDM, P.LDM, out);
@@ -1568,8 +1590,8 @@ struct Solver::Impl {
     void apply_GT(const double* val, double* out) {
         if (P.trig) {
             dim3 g(cdiv(P.D1, 256), P.nchunk), b(256);
-            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), g, b, 0, st, P, val, P.tmin, P.D1, 0.0, 0, partial);
-            else hipLaunchKernelGGL((k_trig_moments<NV, true>), g, b, 0, st, P, val, P.tmin, P.D1, 0.0, 0, partial);
+            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
+            else hipLaunchKernelGGL((k_trig_moments<NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
         } else {
             dim3 g(P.ld / 128, nsplit_at), b(64, 4);
             if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
@@ -1638,11 +1660,11 @@ struct Solver::Impl {
             if (P.Ne > 0 && P.tmin == 0.0 && nwv + nvb <= 4) {
                 // delays start at 0: the border moments sit on the difference progression, one launch does both
                 // (BB follows the weight vectors in memory)
-                moments_array(nwv + nvb, Dw, 0.0, P.D1, 0.0, 2 * P.D1 - 1, Mom);
+                moments_array(nwv + nvb, Dw, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
                 momb = Mom + 2L * nwv * P.LDM;
             } else {
-                moments_array(nwv, Dw, 0.0, P.D1, 2.0 * P.tmin, 2 * P.D1 - 1, Mom);
-                if (P.Ne > 0) moments_array(nvb, BB, P.tmin, P.D1, 0.0, 0, MomB);
+                moments_array(nwv, Dw, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
+                if (P.Ne > 0) moments_array(nvb, BB, P.seed_tau, P.D1, 0, MomB);
             }
             hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
@@ -1792,6 +1814,12 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
     S.T = ar.get<double>(P.trig ? 0 : nw * ld * ld);
+    {
+        const size_t nch = std::max(P.nchunk, 1), d1 = std::max(P.D1, 1);
+        P.seed_tau = ar.get<double4>(P.trig ? nch * d1 : 1);
+        P.seed_h = ar.get<double4>(P.trig ? nch * (3 * d1 - 1) : 1);
+        P.seed_eval = ar.get<double4>(P.trig ? (size_t)P.useg * Mpad : 1);
+    }
     S.XL = ar.get<double>(8 * (size_t)P.LDL); S.Mom = ar.get<double>(18 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
@@ -1824,6 +1852,13 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     MBFIR_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
     // ---- build A1, norms -------------------------------------------------------------------
     if (!P.trig) hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
+    else {
+        hipLaunchKernelGGL(k_build_seeds_m, dim3(cdiv(P.D1, 256), P.nchunk), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
+                           const_cast<double4*>(P.seed_tau));
+        hipLaunchKernelGGL(k_build_seeds_m, dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
+                           2 * P.D1 - 1, const_cast<double4*>(P.seed_h));
+        hipLaunchKernelGGL(k_build_seeds_e, dim3(cdiv(Mf, 256), P.useg), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
+    }
     {
         std::vector<double> sc0(S_COUNT, 0.0);
         sc0[S_NRMH] = nrm_h; sc0[S_NRMC] = nrm_c; sc0[S_DEG] = degree; sc0[S_TAU] = 1.0; sc0[S_KAPPA] = 1.0;
