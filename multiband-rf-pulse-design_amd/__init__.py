@@ -314,6 +314,7 @@ def fir_qprog_phs(n, f, ac, dc, x0=None, dbg=0, *, opts=None, ctx=None, info=Fal
 
 
 from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)
+from .search import fir_ap   # noqa: E402  (fir_ap.m: order / transition-width searches around fir_ap_cvx)
 
 _WHICH = {"fir_ap_cvx": 0, "fir_qp_cvx": 1, "fir_linprog": 2, "fir_qprog_phs": 3}
 _pools = {}
