@@ -610,15 +610,19 @@ __device__ __forceinline__ double big_step(int big, const double* lam, const dou
 
 // ------------------------------------------------------------------------------------------------
 // K6 scaling for LP rows and Q3 cones (thread per cone); lam = W z
+// NT scaling of the LP rows and Q3 cones; with bz2 != null also wbz2 = W^-2 bz2 for the two right-hand
+// sides of the batch solve that follows (saves the separate k_winv2 pass)
 __global__ void k_scaling(DProg P, const double* __restrict__ s, const double* __restrict__ z,
                           double* __restrict__ dl, double* __restrict__ wl, double* __restrict__ w3,
-                          double* __restrict__ lam) {
+                          double* __restrict__ lam, const double* __restrict__ bz2, double* __restrict__ wbz2) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.l) {
         double sv = s[t], zv = z[t];
-        dl[t] = zv / sv;
+        const double dd = zv / sv;
+        dl[t] = dd;
         wl[t] = sqrt(sv / zv);
         lam[t] = sqrt(sv * zv);
+        if (bz2) { wbz2[t] = dd * bz2[t]; wbz2[P.Rp + t] = dd * bz2[P.Rp + t]; }
     } else if (t < P.l + P.nq3) {
         int c = t - P.l, r = P.l + 3 * c;
         double ss[3] = {s[r], s[r + 1], s[r + 2]}, zz[3] = {z[r], z[r + 1], z[r + 2]}, ll[3];
@@ -626,6 +630,13 @@ __global__ void k_scaling(DProg P, const double* __restrict__ s, const double* _
         soc3_apply(W, zz, ll, false);
         w3[4 * c] = W.eta; w3[4 * c + 1] = W.w0; w3[4 * c + 2] = W.w1; w3[4 * c + 3] = W.w2;
         lam[r] = ll[0]; lam[r + 1] = ll[1]; lam[r + 2] = ll[2];
+        if (bz2)
+            for (int v = 0; v < 2; ++v) {
+                const long o = (long)v * P.Rp + r;
+                double vv[3] = {bz2[o], bz2[o + 1], bz2[o + 2]}, rr[3];
+                soc3_inv2_apply(W, vv, rr);
+                wbz2[o] = rr[0]; wbz2[o + 1] = rr[1]; wbz2[o + 2] = rr[2];
+            }
     }
 }
 __device__ __forceinline__ Soc3 load_w3(const double* w3, int c) {
@@ -706,14 +717,16 @@ __global__ __launch_bounds__(1024) void k_big_winv2(DProg P, const double* __res
 // ------------------------------------------------------------------------------------------------
 // residuals
 // rows: rz = Gx + s - h tau ; bz batch: [0] = h (constant system), [1] = s - rz (affine)
+// UU != null: the rows of G x are formed here from the per-frequency products (no k_rows_G pass)
 __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __restrict__ Gx, const double* __restrict__ s,
                                                     const double* __restrict__ z, const double* __restrict__ Sc,
                                                     double* __restrict__ rz, double* __restrict__ bz2,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, const double* __restrict__ UU,
+                                                    const double* __restrict__ X) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     double v[4] = {0, 0, 0, 0};
     if (r < P.R) {
-        double tau = Sc[S_TAU], gx = Gx[r], sv = s[r], zv = z[r], hv = P.h[r];
+        double tau = Sc[S_TAU], gx = UU ? row_value<1>(P, UU, X, r, 0) : Gx[r], sv = s[r], zv = z[r], hv = P.h[r];
         double res = gx + sv - hv * tau;
         rz[r] = res;
         bz2[r] = hv;
@@ -880,6 +893,50 @@ __global__ void k_cg_update_r(DProg P, const double* __restrict__ Sc, const doub
         dz[o] += al * Wp[o];
     }
 }
+// CG step and R-space update in one launch (unsharded solves): every block forms alpha = rz / p'Hp itself
+// (N is small), updates its slice of gdx / dz, and block 0 also does dx += alpha p, r -= alpha Hp and the
+// residual norm.
+template <int NV>
+__global__ __launch_bounds__(256) void k_cg_step_update(DProg P, double* __restrict__ Sc, const double* __restrict__ p,
+                                                        const double* __restrict__ Hp, double* __restrict__ dx,
+                                                        double* __restrict__ r, int slot, const double* __restrict__ Gp,
+                                                        const double* __restrict__ Wp, double* __restrict__ gdx,
+                                                        double* __restrict__ dz) {
+    __shared__ double sh[17];
+    double al[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) a += p[(long)v * P.LDV + j] * Hp[(long)v * P.LDV + j];
+        const double pHp = block_sum(a, sh);
+        al[v] = pHp > 0 ? Sc[S_CG_RZ + v] / pHp : 0.0;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.R) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const long o = (long)q * P.Rp + t;
+            gdx[o] += al[q] * Gp[o];
+            dz[o] += al[q] * Wp[o];
+        }
+    }
+    if (blockIdx.x != 0) return;
+    double m = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double rr2 = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) {
+            const long o = (long)v * P.LDV + j;
+            dx[o] += al[v] * p[o];
+            const double rr = r[o] - al[v] * Hp[o];
+            r[o] = rr;
+            rr2 += rr * rr;
+        }
+        m = fmax(m, sqrt(block_sum(rr2, sh)));
+        if (threadIdx.x == 0) Sc[S_CG_ALPHA + v] = al[v];
+    }
+    if (threadIdx.x == 0) Sc[slot] = m;
+}
 // dots needed for dtau: c'x1, c'x2 (N space) ; h'z1, h'z2, ||W z1||^2 (R space)
 __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                                                 const double* __restrict__ z1, const double* __restrict__ z2,
@@ -963,10 +1020,36 @@ __global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restr
                                                   const double* __restrict__ lam, const double* __restrict__ z1,
                                                   const double* __restrict__ z2, const double* __restrict__ g1,
                                                   const double* __restrict__ g2, const double* __restrict__ rz,
-                                                  const double* __restrict__ Sc, double* __restrict__ outA,
-                                                  double* __restrict__ outB, double* __restrict__ part, int mode) {
+                                                  double* __restrict__ Sc, double* __restrict__ outA,
+                                                  double* __restrict__ outB, double* __restrict__ part, int mode,
+                                                  const double* __restrict__ dpart, int ndp, const double* __restrict__ x2) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+    double dtau;
+    if (dpart) {
+        // fused k_scal_dtau (unsharded solves): every block folds the k_dots_r partials and the N-space dot
+        // c'x2 itself, block 0 publishes dtau / dkappa
+        __shared__ double sh[17];
+        const double hz2 = fold_partials(dpart, ndp, 3, 1, false, sh);
+        const double wz1 = fold_partials(dpart, ndp, 3, 2, false, sh);
+        double a2 = 0;
+        for (int j = threadIdx.x; j < P.N; j += blockDim.x) a2 += P.c[j] * x2[j];
+        const double cx2 = block_sum(a2, sh);
+        const double tau = Sc[S_TAU], kap = Sc[S_KAPPA], den = kap / tau + wz1;
+        double dkc, bt;
+        if (mode == 0) { dkc = -kap * tau; bt = -Sc[S_RT]; }
+        else {
+            const double sigma = Sc[S_SIGMA];
+            dkc = sigma * Sc[S_MU] - kap * tau - Sc[S_DKAP_A] * Sc[S_DTAU_A];
+            bt = -(1 - sigma) * Sc[S_RT];
+        }
+        dtau = (dkc / tau - bt + cx2 + hz2) / den;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            Sc[mode == 0 ? S_DTAU_A : S_DTAU] = dtau;
+            Sc[mode == 0 ? S_DKAP_A : S_DKAP] = (dkc - kap * dtau) / tau;
+        }
+    } else {
+        dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+    }
     const double oms = mode == 0 ? 1.0 : 1.0 - Sc[S_SIGMA];
     double v[2] = {-1e300, -1e300};
     if (t < P.l) {
@@ -1065,18 +1148,41 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
 
 // combined right-hand side: ds_c = sigma mu e - lam o lam - dssa o wdza ; lds = lam \ ds_c ;
 // bz = -(1-sigma) rz - W lds ;  (bx = -(1-sigma) rx is formed by k_scal_step)
-__global__ void k_comb_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
+// spart != null (unsharded solves): the affine step length and sigma (k_scal_step, mode 0) are formed here
+// by every block from the k_dir_post partials, block 0 publishes them and bx = -(1-sigma) rx.
+// wbz != null: also wbz = W^-2 bz (saves the k_winv2 pass of the solve that follows).
+__global__ __launch_bounds__(256) void k_comb_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                            const double* __restrict__ lam, const double* __restrict__ dssa,
                            const double* __restrict__ wdza, const double* __restrict__ rz,
-                           const double* __restrict__ Sc, double* __restrict__ lds, double* __restrict__ bz) {
+                           double* __restrict__ Sc, double* __restrict__ lds, double* __restrict__ bz,
+                           const double* __restrict__ spart, int nsp, const double* __restrict__ rx,
+                           double* __restrict__ bxc, const double* __restrict__ dl, double* __restrict__ wbz) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double sigma = Sc[S_SIGMA], smu = sigma * Sc[S_MU];
+    double sigma;
+    if (spart) {
+        __shared__ double sh[17];
+        const double ts = fold_partials(spart, nsp, 2, 0, true, sh);
+        const double tz = fold_partials(spart, nsp, 2, 1, true, sh);
+        const double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
+        const double tt = fmax(0.0, fmax(fmax(ts, tz), fmax(-Sc[S_DTAU_A] / tau, -Sc[S_DKAP_A] / kap)));
+        const double a = tt == 0.0 ? 1.0 : fmin(1.0, 1.0 / tt);
+        sigma = (1 - a) * (1 - a) * (1 - a);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) { Sc[S_TMAX] = tt; Sc[S_ALPHA_A] = a; Sc[S_SIGMA] = sigma; }
+            for (int j = threadIdx.x; j < P.N; j += blockDim.x) bxc[j] = -(1.0 - sigma) * rx[j];
+        }
+    } else {
+        sigma = Sc[S_SIGMA];
+    }
+    const double smu = sigma * Sc[S_MU];
     if (t < P.l) {
         double l = lam[t];
         double dsc = smu - l * l - dssa[t] * wdza[t];
         double q = dsc / l;
         lds[t] = q;
-        bz[t] = -(1 - sigma) * rz[t] - wl[t] * q;
+        const double b = -(1 - sigma) * rz[t] - wl[t] * q;
+        bz[t] = b;
+        if (wbz) wbz[t] = dl[t] * b;
     } else if (t < P.l + P.nq3) {
         int c = t - P.l, r = P.l + 3 * c;
         Soc3 W = load_w3(w3, c);
@@ -1087,7 +1193,12 @@ __global__ void k_comb_rhs(DProg P, const double* __restrict__ wl, const double*
         dsc[0] = smu - p1[0] - p2[0]; dsc[1] = -p1[1] - p2[1]; dsc[2] = -p1[2] - p2[2];
         soc3_div(ll, dsc, q);
         soc3_apply(W, q, wq, false);
-        for (int a = 0; a < 3; ++a) { lds[r + a] = q[a]; bz[r + a] = -(1 - sigma) * rz[r + a] - wq[a]; }
+        double bb[3], wb[3];
+        for (int a = 0; a < 3; ++a) { lds[r + a] = q[a]; bb[a] = -(1 - sigma) * rz[r + a] - wq[a]; bz[r + a] = bb[a]; }
+        if (wbz) {
+            soc3_inv2_apply(W, bb, wb);
+            for (int a = 0; a < 3; ++a) wbz[r + a] = wb[a];
+        }
     }
 }
 __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
@@ -1511,7 +1622,7 @@ struct Solver::Impl {
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
-    double *partR, *partN, *xout, *hout, *sfwork;
+    double *partR, *partR2, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
 
     void ensure_arena(size_t bytes) {
@@ -1616,9 +1727,11 @@ struct Solver::Impl {
     // dual equation G'dz = bx ends at the CG residual.  Residual norms n_0 (after the Cholesky solve)
     // .. n_nsweep go to Sc[slot ..] for the sweep controller.  Mirrors oracle/conic_ipm.py kkt_solve.
     template <int NV>
-    void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot) {
+    void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot,
+                   bool wbz_ready = false) {
         const dim3 gN(nbN), gR(cdiv(P.R, 256)), b256(256);
-        winv2<NV>(bz, nullptr, wbz, 0);
+        if (!wbz_ready) winv2<NV>(bz, nullptr, wbz, 0);
+        else if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
         trigemv_launch(M, P.np, 0, bx, yN, NV, P.LDV, st, tmpN);                            // M (bx + G' W^-2 bz)
         trigemv_launch(Mt, P.np, 1, yN, dx, NV, P.LDV, st);
@@ -1632,8 +1745,12 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_cg_start<NV>, dim3(1), dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
             apply_G_winv2<NV>(pN, tmpR, nullptr, wpR);                                      // G p, W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
-            hipLaunchKernelGGL(k_cg_step<NV>, dim3(1), dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
-            hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
+            if (shard_size == 1) {
+                hipLaunchKernelGGL(k_cg_step_update<NV>, gR, b256, 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1, tmpR, wpR, gdx, dz);
+            } else {
+                hipLaunchKernelGGL(k_cg_step<NV>, dim3(1), dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
+                hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
+            }
             if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
         }
     }
@@ -1837,7 +1954,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
     S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(P.trig ? (size_t)P.nchunk * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
-    S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
+    S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
     zero_bytes = size_t(ar.base + ar.off - zero_from);
@@ -1900,9 +2017,15 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     bool have_best = false;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
-        S.apply_G<1>(S.x, S.Gx);
-        S.apply_GT<1>(S.z, S.GTz);
-        hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR);
+        if (P.trig) {                                     // G x rows are formed inside k_resid_rows
+            hipLaunchKernelGGL(k_trig_eval<1>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, S.x, S.UU);
+            S.apply_GT<1>(S.z, S.GTz);
+            hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
+        } else {
+            S.apply_G<1>(S.x, S.Gx);
+            S.apply_GT<1>(S.z, S.GTz);
+            hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
+        }
         if (sharded) {
             hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
             S.allreduce(S.RB, 4, 0);
@@ -1952,16 +2075,16 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
         }
         if (it == o.max_iter) break;
         // scaling + H
-        hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam);
+        hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
         if (P.big) {
             const long ob = P.l + 3L * P.nq3;
             hipLaunchKernelGGL(k_big_scaling, dim3(1), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc);
         }
         S.build_H();
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
-        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA);
+        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA, true);       // W^-2 bz2 came with k_scaling
         double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
-        auto dots = [&](const double* xx2, const double* zz2, int mode) {
+        auto dots = [&](const double* xx2, const double* zz2, int mode) -> int {
             hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
             int nb = std::max(S.nbC, 1);
             if (P.big) {
@@ -1971,35 +2094,41 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
             if (sharded) {
                 hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 0);
                 S.allreduce(S.RB, 3, 0);
+                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 1);
             }
-            hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, sharded ? 1 : 2);
+            return nb;                                     // unsharded: k_dir_post folds these partials itself
         };
-        auto dir_post = [&](const double* zz2, const double* gg2, double* outA, double* outB, int mode) {
+        // step maxima go to partR2 (k_dir_post reads the k_dots_r partials in partR while it writes them);
+        // returns the number of partial rows; step_mode0_fused: the affine step length is left to k_comb_rhs
+        auto dir_post = [&](const double* xx2, const double* zz2, const double* gg2, double* outA, double* outB, int mode, int ndots) -> int {
             int nb = std::max(S.nbC, 1);
             hipLaunchKernelGGL(k_dir_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
-                               S.partR, mode);
+                               S.partR2, mode, sharded ? nullptr : S.partR, ndots, xx2);
             if (P.big) {
                 hipLaunchKernelGGL(k_big_dir_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
-                                   S.scratch, S.partR + 2L * nb, mode);
+                                   S.scratch, S.partR2 + 2L * nb, mode);
                 nb += 1;
             }
             if (sharded) {
-                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc, S.RB, 0);
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 0);
                 S.allreduce(S.RB, 2, 1);
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
+            } else if (mode == 1) {
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
             }
-            hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR, nb, mode, S.rx, S.bxc, S.RB, sharded ? 1 : 2);
+            return nb;
         };
-        dots(x2a, z2a, 0);
-        dir_post(z2a, g2a, S.dssa, S.wdza, 0);
-        // combined direction
+        const int nd0 = dots(x2a, z2a, 0);
+        const int ns0 = dir_post(x2a, z2a, g2a, S.dssa, S.wdza, 0, nd0);
+        // combined direction (unsharded: sigma and bx are formed inside k_comb_rhs, and W^-2 bz comes with it)
         hipLaunchKernelGGL(k_comb_rhs, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.dssa, S.wdza, S.rz, S.Sc,
-                           S.lds, S.bzc);
+                           S.lds, S.bzc, sharded ? nullptr : S.partR2, ns0, S.rx, S.bxc, S.dl, S.wbz);
         if (P.big)
             hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
-        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB);
-        dots(S.dxc, S.dzc, 1);
-        dir_post(S.dzc, S.gdxc, S.ds, S.dz, 1);
+        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB, true);
+        const int nd1 = dots(S.dxc, S.dzc, 1);
+        dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
         hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
     }
     const double* xsrc = S.xout;
