@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=8, help="oracle iterations for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="independent designs in flight per GPU (contexts / HIP streams); "
                     "a step is one batch of that many designs")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks: ranks then share devices)")
     ap.add_argument("--dense", action="store_true", help="materialised trig matrix + dense MFMA Gram (opts.dense_trig) "
                     "instead of the default lattice (matrix-free) mode")
     args = ap.parse_args()
@@ -93,8 +95,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend)
     if args.gpus != world:
         if rank == 0:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d; launch with torch.distributed.run\n" % (args.gpus, world))
@@ -142,7 +149,7 @@ def main():
     ndesign = args.steps * nstream            # designs this rank completed in the timed region
     # single-design latency (one stream, nothing else on the GPU), outside the timed region
     t1 = time.perf_counter()
-    mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx)
+    _, _, solo = mbfir.fir_ap_cvx(args.n, f, a, d, 0.1, 1e-3, opts=opts, ctx=ctx, info=True)
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) * 1e3
     # the north-star kernel A'DA on the matrix cores is the dense path's (opts.dense_trig); the default
@@ -155,16 +162,20 @@ def main():
         if st_d != "Solved":
             dense_info = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         iters = sum(i["iters"] for i in infos)
-        builds = sum(i["builds"] for i in infos)
-        gram_ms = sum(i["ms_gram"] for i in infos)
-        chol_ms = sum(i["ms_chol"] for i in infos)
-        chol_launches = sum(i["chol_launches"] for i in infos)
+        # kernel rooflines come from the single-stream pass (`solo`: one design alone on the GPU, same build):
+        # HIP events around a stream's launches also see the other streams' kernels when several designs are
+        # in flight, while rocprofv3 reports pure kernel durations -- alone on the GPU the two agree
+        # (profiles/*_streams1_kernel_stats.csv).  The per-design breakdown below stays that of the timed region.
+        builds = solo["builds"]
+        gram_ms = solo["ms_gram"]
+        chol_ms = solo["ms_chol"]
+        chol_launches = solo["chol_launches"]
         lattice = bool(infos[0]["lattice"])
         try:
             peak_mfma, peak_valu = mbfir.mfma_peak(ctx)
@@ -181,8 +192,9 @@ def main():
                      "traffic": CHOL_STEP_TRAFFIC_BYTES_NP1024 if infos[0]["n_unknowns"] == 1024 else None,
                      "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01d_pmc_fetch_write_per_kernel.csv)",
                      "flop_per_launch": chol_flop_per_launch, "launches": chol_launches, "avg_launch_ms": chol_avg_ms,
-                     "note": "dependency-chain bound, not throughput bound: 1024 sequential pivots per build, ~0.29 us each "
-                             "(LDS broadcast + barrier + reciprocal per pivot); see DESIGN.md",
+                     "note": "dependency-chain bound, not throughput bound: 1024 sequential pivots per build (single-wave "
+                             "register elimination of 16-column slabs, ~0.1 us per pivot) plus 17 launch boundaries; measured on "
+                             "the single-stream pass; see DESIGN.md",
                      "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
                      "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu}
         # normal-matrix products: dense mode = k_gram on the matrix cores; lattice mode = moment recurrences on the VALU
@@ -196,7 +208,7 @@ def main():
                          "note": "replaces the dense Gram products (17.2 GFLOP per build on the matrix cores) by "
                                  "%.2f GFLOP of recurrences; peak = fp64 vector peak (same figure as the matrix peak)" % (gram_flop / 1e9)}
         else:
-            launches = sum(i["gram_launches"] for i in infos)
+            launches = solo["gram_launches"]
             flop_per_launch = gram_flop / max(1, infos[0]["gram_launches"] // max(1, infos[0]["builds"]))
             gram_ach = flop_per_launch / (gram_ms / max(1, launches) * 1e-3) / 1e12 if gram_ms > 0 else 0.0
             roof_gram = {"kernel": "k_gram (A' D A, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": gram_ach,
@@ -233,10 +245,12 @@ def main():
             "ipm_iters_per_s": (1 if shard else world) * iters / elapsed,
             "ms_breakdown_per_design": {"assemble": sum(i["ms_assemble"] for i in infos) / ndesign,
                                         "solve": sum(i["ms_solve"] for i in infos) / ndesign,
-                                        "normal_matrix": gram_ms / ndesign,
-                                        "cholesky_inverse": chol_ms / ndesign,
+                                        "normal_matrix": sum(i["ms_gram"] for i in infos) / ndesign,
+                                        "cholesky_inverse": sum(i["ms_chol"] for i in infos) / ndesign,
                                         "spectral_factor": sum(i["ms_post"] for i in infos) / ndesign,
                                         "note": "per-stream device/host times while %d designs share the GPU" % nstream},
+            "ms_breakdown_single_stream": {"assemble": solo["ms_assemble"], "solve": solo["ms_solve"], "normal_matrix": solo["ms_gram"],
+                                           "cholesky_inverse": solo["ms_chol"], "spectral_factor": solo["ms_post"]},
             "roofline": dominant,
             "roofline_other": others,
         }
