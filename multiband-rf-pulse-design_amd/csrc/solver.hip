@@ -8,13 +8,17 @@
 // with dz kept explicit and corrected incrementally (`refine` sweeps) so the dual equation
 // G'dz = bx holds to rounding.
 //
-// Per iteration on the GPU:
-//   K1  G v   : A1 * [v, P'v]  (k_amulti, HBM-bound, one wave per frequency row) + row gather
-//   K3  G' v  : per-frequency aggregation (CSR) + A1' * [p1, p2] (k_atmulti, HBM-bound)
-//   K6  NT scaling, per-frequency 2x2 weight blocks (k_freq_blocks)
-//   K2  T_k = A1' D_k A1 on the fp64 matrix cores (gram.hip), H assembled from T11,T12,T22 through
-//       the quadrature permutation P plus the sparse identity-row / border / big-cone terms
-//   K4  Cholesky + triangular inverse (chol.hip); every solve = two triangular GEMVs
+// Per iteration on the GPU (K numbers as in SURVEY 8a / DESIGN 4):
+//   K1  G v   : lattice mode: trigonometric polynomial per frequency by a rotation recurrence
+//               (k_trig_eval) + row gather; dense mode: A1 * [v, P'v] (k_amulti, HBM-bound)
+//   K3  G' v  : per-frequency aggregation + trigonometric moments per column (k_trig_moments,
+//               k_gt_finish); dense mode: A1' * [p1, p2] (k_atmulti)
+//   K6  NT scaling, per-frequency 2x2 weight blocks (k_scaling, k_freq_blocks)
+//   K2  normal matrix: lattice mode from the moments of the weight vectors (Toeplitz + Hankel,
+//       k_assemble_H_lat); dense mode T_k = A1' D_k A1 on the fp64 matrix cores (gram.hip); plus the
+//       sparse identity-row / border / big-cone terms
+//   K4  Cholesky + triangular inverse (chol.hip); every solve = two triangular GEMVs, refined by
+//       preconditioned CG on the exact operator
 //   K5  step length: closed form per cone, block max-reductions, scalars stay on the device
 // One host synchronisation per iteration (termination test on 24 doubles).
 #include "dev_common.h"
@@ -788,18 +792,6 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
 
 // ------------------------------------------------------------------------------------------------
 // N-space helpers
-// rhs[v][j] = bx[v][j] + t[v][j]
-template <int NV>
-__global__ void k_add_n(DProg P, const double* __restrict__ a, const double* __restrict__ b, double sb,
-                        double* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.N) return;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        long o = (long)v * P.LDV + j;
-        out[o] = a[o] + sb * b[o];
-    }
-}
 // ---- single-workgroup N-space kernels (N <= a few thousand: one launch does reduce + update) ----
 // r[v] = bx[v] - t[v] ; Sc[slot] = max_v ||r_v||_2
 template <int NV>
@@ -863,21 +855,6 @@ __global__ __launch_bounds__(1024) void k_cg_step(DProg P, double* __restrict__ 
     }
     if (threadIdx.x == 0) Sc[slot] = m;
 }
-template <int NV>
-__global__ void k_axpy_r(DProg P, const double* __restrict__ a, double* __restrict__ out) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.R) return;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) out[(long)v * P.Rp + r] += a[(long)v * P.Rp + r];
-}
-template <int NV>
-__global__ void k_axpy_n(DProg P, const double* __restrict__ a, double* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.N) return;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) out[(long)v * P.LDV + j] += a[(long)v * P.LDV + j];
-}
-
 // ---- preconditioned conjugate gradients on (G' W^-2 G) dx = rhs: R-space update -------------------
 // gdx += alpha Gp ; dz += alpha Wp
 template <int NV>
@@ -1356,14 +1333,6 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
     }
     H[(long)j * P.np + k] = v;
 }
-// fold the atmulti partials of the border products: TT[v][j] = sum_s partial[s][v][j]
-__global__ void k_fold_tt(DProg P, const double* __restrict__ partial, int nsplit, int nvv, double* __restrict__ TT) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
-    if (j >= P.ld) return;
-    double t = 0;
-    for (int s = 0; s < nsplit; ++s) t += partial[((long)s * nvv + v) * P.ld + j];
-    TT[(long)v * P.LDV + j] = t;
-}
 // identity rows: thread j owns row j of H (and the mirrored border entries)
 __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                              double* __restrict__ H) {
@@ -1618,7 +1587,7 @@ struct Solver::Impl {
     int *tile_ij, *flag;
     double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
     double *XX, *UU, *PP, *partial, *TT, *TT2, *Dw, *BB, *qv;
-    double *XL, *Mom, *MomB;       // lattice mode: coefficient vectors, H moments, border moments
+    double *Mom, *MomB;            // lattice mode: H moments, border moments
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
@@ -1937,7 +1906,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
         P.seed_h = ar.get<double4>(P.trig ? nch * (3 * d1 - 1) : 1);
         P.seed_eval = ar.get<double4>(P.trig ? (size_t)P.useg * Mpad : 1);
     }
-    S.XL = ar.get<double>(8 * (size_t)P.LDL); S.Mom = ar.get<double>(18 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
+    S.Mom = ar.get<double>(18 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
@@ -1986,7 +1955,6 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.evused = 0;
     S.timing = o.timing;
 
-    const int nbRc = S.nbC + (P.big ? 1 : 0);      // cone-indexed reductions (+1 row for the big cone)
     const bool sharded = S.shard_size > 1;
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
