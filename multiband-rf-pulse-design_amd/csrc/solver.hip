@@ -43,7 +43,7 @@ enum {
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int MAX_SWEEPS = 8;
-constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1e-5;
+constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
 
 // ------------------------------------------------------------------------------------------------
 // device-side problem description

@@ -230,7 +230,7 @@ def _max_step(c, lam, d):
 MAX_SWEEPS = 8
 REFTOL = 1e-11
 INACC_FEAS = 1e-6
-INACC_GAP = 1e-5
+INACC_GAP = 1.22e-4           # CVX's reduced tolerance eps^(1/4): what 'Inaccurate/Solved' means in the reference
 STATUS_OPTIMAL_INACCURATE = 5
 
 
