@@ -43,6 +43,7 @@ enum {
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int MAX_SWEEPS = 8;
+constexpr int WALL_ITERS = 3;
 constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
 
 // ------------------------------------------------------------------------------------------------
@@ -1983,6 +1984,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     double best_merit = 1e300;
     SolveInfo best_info;
     bool have_best = false;
+    int wall = 0;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
@@ -2042,6 +2044,10 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
             }
         }
         if (it == o.max_iter) break;
+        // numerical wall (mirrors oracle/conic_ipm.py): the last factorisation replaced pivots and the
+        // residuals are out of the reduced-accuracy range, three iterations in a row
+        wall = (S.hostFlag[0] > 0 && (hs[S_PRES] > INACC_FEAS || hs[S_DRES] > INACC_FEAS)) ? wall + 1 : 0;
+        if (wall >= WALL_ITERS) { status = ST_NUMERICAL; break; }
         // scaling + H
         hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
         if (P.big) {

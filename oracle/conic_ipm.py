@@ -229,6 +229,7 @@ def _max_step(c, lam, d):
 
 MAX_SWEEPS = 8
 REFTOL = 1e-11
+WALL_ITERS = 3
 INACC_FEAS = 1e-6
 INACC_GAP = 1.22e-4           # CVX's reduced tolerance eps^(1/4): what 'Inaccurate/Solved' means in the reference
 STATUS_OPTIMAL_INACCURATE = 5
@@ -384,6 +385,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
     it = 0
     info = {}
     best = (np.inf, None, None)
+    wall = 0                  # consecutive iterations past the numerical wall (see below)
+    fixes_seen = 0
     for it in range(max_iter + 1):
         rx = G.T @ z + c * tau
         rz = G @ x + s - h * tau
@@ -432,6 +435,15 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             if merit < best[0]:
                 best = (merit, x / tau, dict(info))
         if it == max_iter:
+            break
+        # numerical wall: the last factorisation had to replace pivots AND the residuals are out of the
+        # reduced-accuracy range -- three such iterations in a row and the normal matrix has lost the weak
+        # directions for good; stop instead of iterating on noise to max_iter
+        last_fixes = chol_fixes[0] - fixes_seen
+        fixes_seen = chol_fixes[0]
+        wall = wall + 1 if (last_fixes > 0 and (pres > INACC_FEAS or dres > INACC_FEAS)) else 0
+        if wall >= WALL_ITERS:
+            status = STATUS_NUMERICAL
             break
         try:
             Wm = _Scaling(cone, s, z)
