@@ -194,8 +194,23 @@ __device__ __forceinline__ void slab_steps(double (&t)[16], double (&rp)[16], do
 }
 
 // acc[q]: the wave's tiles of S (MFMA D layout).  LB: 64 x LBLD, LS: 64 x LSLD, piv: 64.
+// Lz / dinv: on exit the zero-padded column image of L (see subst16) and 1 / diag(L); the image of a
+// finished slab is written by the three idle waves while wave 0 eliminates the next one.
+__device__ __forceinline__ void slab_image(const double* LB, const double* piv, double* Lz, double* dinv, int b, int e0,
+                                           int estride) {
+    for (int e = e0; e < 16 * CB; e += estride) {
+        const int r = e & 63, c = 16 * b + (e >> 6);
+        const double p = piv[c];
+        double y = __builtin_amdgcn_rsq(p);               // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
+        y = y * (1.5 - 0.5 * p * y * y);
+        y = y * (1.5 - 0.5 * p * y * y);
+        Lz[c * ZLD + zpos(r)] = r > c ? LB[r * LBLD + c] * y : 0.0;
+        if (r == 0) dinv[c] = y;
+    }
+}
+
 __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, double* LB, double* LS, const double* dsh,
-                                            double* piv, double pivtol, int* flag, bool count) {
+                                            double* piv, double* Lz, double* dinv, double pivtol, int* flag, bool count) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = lane & 15, g = lane >> 4, nt = int(tiles >> 12);
     int nbad = 0;
@@ -224,6 +239,8 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
 #pragma unroll
                 for (int c = 0; c < 16; ++c) piv[16 * b + c] = pv[c];
             }
+        } else if (b >= 1) {
+            slab_image(LB, piv, Lz, dinv, b - 1, threadIdx.x - 64, 192);
         }
         __syncthreads();
         if (b == 3) break;
@@ -238,6 +255,7 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
             }
         }
     }
+    slab_image(LB, piv, Lz, dinv, 3, threadIdx.x, 256);
     if (count && threadIdx.x == 0 && nbad) atomicAdd(flag, nbad);
 }
 
@@ -299,6 +317,18 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     const int nt = int(tiles >> 12), m16 = lane & 15, g4 = lane >> 4;
     v4d acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     v4d accC = {0, 0, 0, 0};
+    // the tiles of A_kk / A_ik the products are subtracted from: loads issued first, used after the products
+    double hv[3][4], hc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[q][r] = q < nt ? H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] : 0.0;
+    }
+    if (rows) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hc[r] = H[(r0 + g4 + 4 * r) * np + kk + 16 * wv + m16];
+    }
     TRACE(0)
     if (k > 0) {
         const long km = kk - CB;
@@ -333,10 +363,9 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     TRACE(2)
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
         if (q < nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] - acc[q][r];
+            for (int r = 0; r < 4; ++r) acc[q][r] = hv[q][r] - acc[q][r];
         }
     }
     if (tid < CB) dsh[tid] = a.d0[kk + tid];
@@ -344,29 +373,16 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     double* LS = smem + R2;                               // 64 x LSLD: the current slab scaled by -1 / pivot
     __syncthreads();                                      // also: everybody is done with X and AR
     TRACE(3)
-    potf2_slabs(acc, tiles, LB, LS, dsh, dinv, a.pivtol, a.flag, b == 0);
-    TRACE(4)
-    if (tid < CB) {                                       // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps
-        const double p = dinv[tid];
-        double y = __builtin_amdgcn_rsq(p);
-        y = y * (1.5 - 0.5 * p * y * y);
-        y = y * (1.5 - 0.5 * p * y * y);
-        dinv[tid] = y;
-    }
-    __syncthreads();
     double* Lz = smem + R0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {                        // L_rc = S_rc / sqrt(p_c), strictly lower part
-        const int e = tid + 256 * u, r = e & 63, c = e >> 6;
-        Lz[c * ZLD + zpos(r)] = r > c ? LB[r * LBLD + c] * dinv[c] : 0.0;
-    }
-    __syncthreads();                                      // LB is free again (Y aliases it)
+    potf2_slabs(acc, tiles, LB, LS, dsh, dsh + 2 * CB, Lz, dinv, a.pivtol, a.flag, b == 0);
+    TRACE(4)
+    __syncthreads();                                      // image complete; LB is free again (Y aliases it)
     if (rows) {                                           // updated rows of A_ik (MFMA layout -> one row per DPP row)
         const int cc = 16 * wv + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = (lane >> 4) + 4 * r;
-            Y[rr * YLD + cc] = H[(r0 + rr) * np + kk + cc] - accC[r];
+            Y[rr * YLD + cc] = hc[r] - accC[r];
         }
     }
     __syncthreads();
