@@ -436,27 +436,33 @@ __global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
     seeds[(long)sg * P.Mpad + i] = make_double4(c, s, cw, sw);
 }
 
-// K3 / K2 (lattice): partial[chunk][v][0|1][m] = sum_{i in chunk} p_v[i] cos|sin(w_i t_m), t_m on up to
-// two unit-step progressions (na points, then nb points; the seeds table knows them).  One thread per point m, the
-// chunk's operands sit in LDS: with AGG they are the per-frequency aggregates of a row vector
-// (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency), otherwise they are
-// read from the per-frequency array src[v][Mpad].
+// K3 / K2 (lattice): partial[group][v][0|1][m] = sum over the CGRP chunks of the group, sum_{i in chunk}
+// p_v[i] cos|sin(w_i t_m), t_m on up to two unit-step progressions (na points, then nb points; the seeds table
+// knows them).  Block = 64 points x CGRP chunks: one thread per (point, chunk) runs the recurrence over the
+// chunk's frequencies, the CGRP chunk sums of a point are added in LDS (fixed order), so the fold kernels
+// see nchunk / CGRP partials.  The chunks' operands sit in LDS: with AGG they are the per-frequency
+// aggregates of a row vector (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency),
+// otherwise they are read from the per-frequency array src[v][Mpad].
+constexpr int CGRP = 4;
 template <int NV, bool AGG>
 __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, const double4* __restrict__ seeds,
                                                       int na, int nb, double* __restrict__ partial) {
-    __shared__ double pp[NV][CHK];
-    const int tid = threadIdx.x, ch = blockIdx.y;
-    const int start = P.ch_start[ch], cnt = P.ch_count[ch];
-    if (tid < CHK) {
-        const int i = start + tid;
+    __shared__ double pp[NV][CGRP][CHK];
+    __shared__ double red[CGRP - 1][2 * NV][64];
+    const int tid = threadIdx.x, pt = tid & 63, cl = tid >> 6;
+    const int ch0 = blockIdx.y * CGRP;
+    for (int e = tid; e < CGRP * CHK; e += 256) {         // stage the operands of the group's chunks
+        const int cc = e / CHK, q = e - cc * CHK, ch = ch0 + cc;
+        const bool live = ch < P.nchunk && q < P.ch_count[ch < P.nchunk ? ch : 0];
+        const int i = live ? P.ch_start[ch] + q : 0;
         if (AGG) {
             const int nv = P.quad ? NV / 2 : NV;
             double p1[NV], p2[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
-            if (tid < cnt)
-                for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
-                    const int r = P.f_rows[q];
+            if (live)
+                for (int qq = P.f_ptr[i]; qq < P.f_ptr[i + 1]; ++qq) {
+                    const int r = P.f_rows[qq];
                     const double al = P.alpha[r], be = P.beta[r];
 #pragma unroll
                     for (int v = 0; v < NV; ++v)
@@ -469,38 +475,51 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __r
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if (v < nv) {
-                    pp[v][tid] = p1[v];
-                    if (P.quad) pp[nv + v][tid] = p2[v];
+                    pp[v][cc][q] = p1[v];
+                    if (P.quad) pp[nv + v][cc][q] = p2[v];
                 }
         } else {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) pp[v][tid] = tid < cnt ? src[(long)v * P.Mpad + i] : 0.0;
+            for (int v = 0; v < NV; ++v) pp[v][cc][q] = live ? src[(long)v * P.Mpad + i] : 0.0;
         }
     }
     __syncthreads();
-    const int m = blockIdx.x * 256 + tid;
-    if (m >= na + nb) return;
-    const double4 sd4 = seeds[(long)ch * (na + nb) + m];
-    double c = sd4.x, s = sd4.y;
-    const double cd = sd4.z, sd = sd4.w;
+    const int m = blockIdx.x * 64 + pt, ch = ch0 + cl;
+    const bool work = m < na + nb && ch < P.nchunk;
     double ag[NV], as[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) ag[v] = as[v] = 0;
-    for (int q = 0; q < cnt; ++q) {
+    if (work) {
+        const double4 sd4 = seeds[(long)ch * (na + nb) + m];
+        double c = sd4.x, s = sd4.y;
+        const double cd = sd4.z, sd = sd4.w;
+        const int cnt = P.ch_count[ch];
+        for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double p = pp[v][cl][q];
+                ag[v] += p * c;
+                as[v] += p * s;
+            }
+            const double cn = c * cd - s * sd;
+            s = s * cd + c * sd;
+            c = cn;
+        }
+    }
+    if (cl > 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { red[cl - 1][2 * v][pt] = ag[v]; red[cl - 1][2 * v + 1][pt] = as[v]; }
+    }
+    __syncthreads();
+    if (cl == 0 && m < na + nb) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const double p = pp[v][q];
-            ag[v] += p * c;
-            as[v] += p * s;
-        }
-        const double cn = c * cd - s * sd;
-        s = s * cd + c * sd;
-        c = cn;
-    }
+            double g = ag[v], h = as[v];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        partial[(((long)ch * NV + v) * 2) * P.LDM + m] = ag[v];
-        partial[(((long)ch * NV + v) * 2 + 1) * P.LDM + m] = as[v];
+            for (int k = 0; k < CGRP - 1; ++k) { g += red[k][2 * v][pt]; h += red[k][2 * v + 1][pt]; }
+            partial[(((long)blockIdx.y * NV + v) * 2) * P.LDM + m] = g;
+            partial[(((long)blockIdx.y * NV + v) * 2 + 1) * P.LDM + m] = h;
+        }
     }
 }
 
@@ -1645,7 +1664,7 @@ struct Solver::Impl {
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
     void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
-        dim3 g(cdiv(na + nb, 256), P.nchunk), b(256);
+        dim3 g(cdiv(na + nb, 64), cdiv(P.nchunk, CGRP)), b(256);
         switch (nv) {
             case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
             case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
@@ -1654,7 +1673,7 @@ struct Solver::Impl {
             case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
             default: throw HipError("moments: unsupported vector count");
         }
-        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.LDM, 64), 2 * nv), dim3(64, 16), 0, st, partial, P.nchunk, 2 * nv, P.LDM, P.LDM, out);
+        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.LDM, 64), 2 * nv), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, CGRP), 2 * nv, P.LDM, P.LDM, out);
     }
     void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
@@ -1670,7 +1689,7 @@ struct Solver::Impl {
     template <int NV>
     void apply_GT(const double* val, double* out) {
         if (P.trig) {
-            dim3 g(cdiv(P.D1, 256), P.nchunk), b(256);
+            dim3 g(cdiv(P.D1, 64), cdiv(P.nchunk, CGRP)), b(256);
             if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
             else hipLaunchKernelGGL((k_trig_moments<NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
         } else {
@@ -1678,7 +1697,7 @@ struct Solver::Impl {
             if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
             else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
         }
-        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, GTC) + 1), dim3(GTC, GTG), 0, st, P, partial, P.trig ? P.nchunk : nsplit_at, val, out);
+        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, GTC) + 1), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, CGRP) : nsplit_at, val, out);
         allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
