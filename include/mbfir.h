@@ -168,6 +168,17 @@ void mbfir_program_trig(const mbfir_program* p, double* w, int* col_kind, double
 void mbfir_program_rows(const mbfir_program* p, int* freq, int* col, double* alpha, double* beta,
                         double* ey, double* h);
 
+/* ---- Inverse SLR: what dzrf_mb.m:239-240 does with the designed beta polynomial ----
+ * n complex taps in, host arrays, all caller-allocated with n doubles each.
+ *  mbfir_b2a  : minimum-phase alpha of beta, `a = b2a(b)`            (rf_tools/b2a.m:15-32, mag2mp.m:21-31)
+ *  mbfir_ab2rf: RF pulse of (alpha, beta), `rf = ab2rf(a, b)`, n <= 2048   (rf_tools/ab2rf.m:14-29)
+ *  mbfir_b2rf : `rf = b2rf(b)` = ab2rf(b2a(b), b) without the round trip   (rf_tools/mex5/b2rf.c)
+ * rf is in radians per sample, as the reference returns it (dzrf_mb.m:244 rescales it to Gauss). */
+int mbfir_b2a(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* a_re, double* a_im);
+int mbfir_ab2rf(mbfir_ctx* ctx, int n, const double* a_re, const double* a_im, const double* b_re,
+                const double* b_im, double* rf_re, double* rf_im);
+int mbfir_b2rf(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* rf_re, double* rf_im);
+
 /* Device kernel test hooks (need a GPU; host arrays in, host arrays out):
  *  mbfir_test_gram: T = A' diag(dk) A for nw weight vectors; A is m x nt row-major,
  *     d is nw x m, out is nw x nt x nt (full symmetric).

@@ -88,6 +88,9 @@ SYMBOLS = {
     "mbfir_qprog_phs_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp,
                                         C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
     "mbfir_solve_batch": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Job), C.c_int, C.POINTER(Opts)]),
+    "mbfir_b2a": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
+    "mbfir_ab2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "mbfir_b2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
     "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mbfir_program_free": (None, [C.c_void_p]),
@@ -311,6 +314,49 @@ def fir_qprog_phs(n, f, ac, dc, x0=None, dbg=0, *, opts=None, ctx=None, info=Fal
     rc = load_library().mbfir_qprog_phs_solve(ctx._h, int(n), len(dc), _ptr(f), _ptr(are), _ptr(aim), _ptr(dre),
                                               _ptr(dim), C.byref(o), _ptr(hre), _ptr(him), C.byref(inf))
     return _finish(ctx, rc, hre, him, inf, info)
+
+
+# ---- inverse SLR: beta polynomial -> alpha -> RF (dzrf_mb.m:239-244) -------------------------------
+def _split(z):
+    z = np.asarray(z, dtype=np.complex128).ravel()
+    return np.ascontiguousarray(z.real), np.ascontiguousarray(z.imag)
+
+
+def b2a(bc, *, ctx=None):
+    """`aca = b2a(bc)` (b2a.m:15): the minimum-phase alpha polynomial consistent with beta."""
+    ctx = ctx or get_context()
+    bre, bim = _split(bc)
+    are, aim = np.zeros(len(bre)), np.zeros(len(bre))
+    _check(ctx, load_library().mbfir_b2a(ctx._h, len(bre), _ptr(bre), _ptr(bim), _ptr(are), _ptr(aim)))
+    return are + 1j * aim
+
+
+def ab2rf(ac, bc, *, ctx=None):
+    """`rf = ab2rf(ac, bc)` (ab2rf.m:14): inverse SLR transform, rf in radians per sample."""
+    ctx = ctx or get_context()
+    are, aim = _split(ac)
+    bre, bim = _split(bc)
+    if len(are) != len(bre):
+        raise ValueError("ab2rf: alpha and beta must have the same length")
+    rre, rim = np.zeros(len(bre)), np.zeros(len(bre))
+    _check(ctx, load_library().mbfir_ab2rf(ctx._h, len(bre), _ptr(are), _ptr(aim), _ptr(bre), _ptr(bim),
+                                           _ptr(rre), _ptr(rim)))
+    return rre + 1j * rim
+
+
+def b2rf(bc, *, ctx=None):
+    """`rf = b2rf(bc)` = ab2rf(b2a(bc), bc) with alpha kept on the device (rf_tools/mex5/b2rf.c)."""
+    ctx = ctx or get_context()
+    bre, bim = _split(bc)
+    rre, rim = np.zeros(len(bre)), np.zeros(len(bre))
+    _check(ctx, load_library().mbfir_b2rf(ctx._h, len(bre), _ptr(bre), _ptr(bim), _ptr(rre), _ptr(rim)))
+    return rre + 1j * rim
+
+
+def rfscaleg(rf, t, gamma):
+    """`rfs = rfscaleg(rf, t, gamma)` (rfscaleg.m:12-16): radians -> Gauss; t in ms, gamma in kHz/G."""
+    rf = np.asarray(rf)
+    return rf / (2 * np.pi * gamma * (t / len(rf)))
 
 
 from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)

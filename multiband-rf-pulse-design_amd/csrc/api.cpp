@@ -275,6 +275,19 @@ int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, doubl
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im) {
     MBFIR_TRY(ctx, ctx->solver->test_specfact(n, x, h_re, h_im));
 }
+int mbfir_b2a(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* a_re, double* a_im) {
+    if (!ctx || n < 1 || !b_re || !b_im || !a_re || !a_im) return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->slr(n, b_re, b_im, nullptr, nullptr, a_re, a_im, nullptr, nullptr));
+}
+int mbfir_ab2rf(mbfir_ctx* ctx, int n, const double* a_re, const double* a_im, const double* b_re, const double* b_im,
+                double* rf_re, double* rf_im) {
+    if (!ctx || n < 1 || n > 2048 || !a_re || !a_im || !b_re || !b_im || !rf_re || !rf_im) return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->slr(n, b_re, b_im, a_re, a_im, nullptr, nullptr, rf_re, rf_im));
+}
+int mbfir_b2rf(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* rf_re, double* rf_im) {
+    if (!ctx || n < 1 || n > 2048 || !b_re || !b_im || !rf_re || !rf_im) return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->slr(n, b_re, b_im, nullptr, nullptr, nullptr, nullptr, rf_re, rf_im));
+}
 int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tf_mfma, double* tf_valu) {
     MBFIR_TRY(ctx, ctx->solver->test_mfma_peak(tf_mfma, tf_valu));
 }

@@ -1,0 +1,153 @@
+// Inverse SLR step on the device: beta polynomial -> minimum-phase alpha -> RF pulse,
+// the restatement of b2a.m:15-32 (with mag2mp.m:21-31) and ab2rf.m:14-29 as dzrf_mb.m:239-240 calls them.
+//   b2a   : DFTs of length blp = 8 n (any n: direct O(blp^2) DFT, twiddles by rotation recurrence with an
+//           exact sincospi seed every 256 terms), elementwise steps in between
+//   ab2rf : the n-step inverse SLR recursion in one workgroup, the two polynomials in LDS (ping-pong)
+#include "dev_common.h"
+
+namespace mbfir {
+
+__device__ __forceinline__ double2 cmul2(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// out[k] = scale * sum_j in[j] exp(sign * 2 pi i j k / N); one thread per k, input staged through LDS
+constexpr int DFT_TILE = 256;
+__global__ __launch_bounds__(256) void k_dft_any(const double2* __restrict__ in, double2* __restrict__ out, int N, int sign,
+                                                 double scale) {
+    __shared__ double2 tile[DFT_TILE];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int kk = k < N ? k : 0;
+    double sw, cw;
+    sincospi(2.0 * double(kk) / double(N), &sw, &cw);
+    sw *= sign;
+    double2 acc = make_double2(0, 0);
+    for (int j0 = 0; j0 < N; j0 += DFT_TILE) {
+        const int j = j0 + threadIdx.x;
+        __syncthreads();
+        tile[threadIdx.x] = j < N ? in[j] : make_double2(0, 0);
+        __syncthreads();
+        const long ph = ((long)kk * j0) % N;              // exact phase of the tile's first term
+        double s, c;
+        sincospi(2.0 * double(ph) / double(N), &s, &c);
+        s *= sign;
+        const int cnt = min(DFT_TILE, N - j0);
+        for (int q = 0; q < cnt; ++q) {
+            const double2 v = tile[q];
+            acc.x += v.x * c - v.y * s;
+            acc.y += v.x * s + v.y * c;
+            const double cn = c * cw - s * sw;
+            s = s * cw + c * sw;
+            c = cn;
+        }
+    }
+    if (k < N) out[k] = make_double2(acc.x * scale, acc.y * scale);
+}
+
+// B0 = [b ; zeros] (length N)
+__global__ void k_slr_pad(const double* __restrict__ b_re, const double* __restrict__ b_im, int n, int N, double2* __restrict__ B0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) B0[i] = i < n ? make_double2(b_re[i], b_im[i]) : make_double2(0, 0);
+}
+// xl = log(sqrt(1 - |bf|^2)) with bf scaled by 1 / (1e-8 + max|bf|) when max|bf| >= 1     (b2a.m:24-29, mag2mp.m:24)
+__global__ __launch_bounds__(1024) void k_slr_logmag(const double2* __restrict__ bf, int N, double2* __restrict__ xl) {
+    __shared__ double sh[17];
+    double m = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) m = fmax(m, hypot(bf[i].x, bf[i].y));
+    m = block_max(m, sh);
+    const double sc = m >= 1.0 ? 1.0 / (1e-8 + m) : 1.0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const double re = bf[i].x * sc, im = bf[i].y * sc;
+        xl[i] = make_double2(log(sqrt(1.0 - (re * re + im * im))), 0.0);
+    }
+}
+// keep DC and N/2, double 1 .. N/2-1, zero the rest                                        (mag2mp.m:26-29)
+__global__ void k_slr_window(double2* __restrict__ x, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double2 v = x[i];
+    if (i >= 1 && i < N / 2) v = make_double2(2 * v.x, 2 * v.y);
+    else if (i > N / 2) v = make_double2(0, 0);
+    x[i] = v;
+}
+// a = exp(xlaf)                                                                            (mag2mp.m:31)
+__global__ void k_slr_exp(double2* __restrict__ x, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double2 v = x[i];
+    double s, c;
+    sincos(v.y, &s, &c);
+    const double e = exp(v.x);
+    x[i] = make_double2(e * c, e * s);
+}
+// aca(n:-1:1)                                                                              (b2a.m:31-32)
+__global__ void k_slr_out(const double2* __restrict__ aca, int n, double* __restrict__ a_il) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a_il[2 * i] = aca[n - 1 - i].x; a_il[2 * i + 1] = aca[n - 1 - i].y; }
+}
+
+// inverse SLR recursion; a_il / b_il / rf_il interleaved (re, im); n <= SLR_MAXN
+constexpr int SLR_MAXN = 2048;
+__global__ __launch_bounds__(1024) void k_ab2rf(const double* __restrict__ a_il, const double* __restrict__ b_il, int n,
+                                                double* __restrict__ rf_il) {
+    __shared__ double2 A[2][SLR_MAXN], B[2][SLR_MAXN];
+    __shared__ double2 cs[2];                             // (c, 0), s
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        A[0][i] = make_double2(a_il[2 * i], a_il[2 * i + 1]);
+        B[0][i] = make_double2(b_il[2 * i], b_il[2 * i + 1]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int i = n; i >= 1; --i) {
+        if (threadIdx.x == 0) {
+            const double2 ai = A[cur][i - 1], bi = B[cur][i - 1];
+            const double den = ai.x * ai.x + ai.y * ai.y;
+            const double2 q = make_double2((bi.x * ai.x + bi.y * ai.y) / den, (bi.y * ai.x - bi.x * ai.y) / den);   // b / a
+            const double c = sqrt(1.0 / (1.0 + (q.x * q.x + q.y * q.y)));
+            const double2 s = make_double2(c * q.x, -c * q.y);                                                      // conj(c b / a)
+            const double theta = atan2(hypot(s.x, s.y), c), psi = atan2(s.y, s.x);
+            rf_il[2 * (i - 1)] = 2 * theta * cos(psi);
+            rf_il[2 * (i - 1) + 1] = 2 * theta * sin(psi);
+            cs[0] = make_double2(c, 0);
+            cs[1] = s;
+        }
+        __syncthreads();
+        const double c = cs[0].x;
+        const double2 s = cs[1], ms = make_double2(-s.x, s.y);                                                      // -conj(s)
+        const int nxt = cur ^ 1;
+        for (int k = threadIdx.x; k < i; k += blockDim.x) {
+            const double2 ak = A[cur][k], bk = B[cur][k];
+            const double2 sb = cmul2(s, bk), msa = cmul2(ms, ak);
+            const double2 acn = make_double2(c * ak.x + sb.x, c * ak.y + sb.y);
+            const double2 bcn = make_double2(msa.x + c * bk.x, msa.y + c * bk.y);
+            if (k >= 1) A[nxt][k - 1] = acn;              // ac = acn(2:i)
+            if (k < i - 1) B[nxt][k] = bcn;               // bc = bcn(1:i-1)
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+// work: 3 * 8n double2.  a_il / rf_il: device arrays of 2n doubles (interleaved).
+void slr_b2a_launch(const double* b_re, const double* b_im, int n, double* work, double* a_il, hipStream_t st) {
+    const int N = 8 * n;
+    double2* B0 = reinterpret_cast<double2*>(work);
+    double2* B1 = B0 + N;
+    double2* B2 = B1 + N;
+    const dim3 g(cdiv(N, 256)), b(256);
+    hipLaunchKernelGGL(k_slr_pad, g, b, 0, st, b_re, b_im, n, N, B0);
+    hipLaunchKernelGGL(k_dft_any, g, b, 0, st, B0, B1, N, -1, 1.0);              // bf = fft(bcp)
+    hipLaunchKernelGGL(k_slr_logmag, dim3(1), dim3(1024), 0, st, B1, N, B2);     // xl
+    hipLaunchKernelGGL(k_dft_any, g, b, 0, st, B2, B0, N, -1, 1.0);              // xlf = fft(xl)
+    hipLaunchKernelGGL(k_slr_window, g, b, 0, st, B0, N);
+    hipLaunchKernelGGL(k_dft_any, g, b, 0, st, B0, B2, N, +1, 1.0 / N);          // xlaf = ifft(xlfp)
+    hipLaunchKernelGGL(k_slr_exp, g, b, 0, st, B2, N);                           // afa
+    hipLaunchKernelGGL(k_dft_any, g, b, 0, st, B2, B1, N, -1, 1.0 / N);          // aca = fft(afa) / blp
+    hipLaunchKernelGGL(k_slr_out, dim3(cdiv(n, 256)), b, 0, st, B1, n, a_il);
+}
+void slr_ab2rf_launch(const double* a_il, const double* b_il, int n, double* rf_il, hipStream_t st) {
+    if (n > SLR_MAXN) throw HipError("ab2rf: more than 2048 taps");
+    hipLaunchKernelGGL(k_ab2rf, dim3(1), dim3(1024), 0, st, a_il, b_il, n, rf_il);
+}
+
+}  // namespace mbfir

@@ -38,6 +38,10 @@ public:
     int solve(const TrigProgram& P, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info);
     // fir_ap_cvx tap extraction on the device from the solution left by the last solve().
     void specfact_last(int n, double* h_re, double* h_im);
+    // Inverse SLR on the device (slr.hip).  b: n complex taps.  a_in null: a = b2a(b) (b2a.m:15-32), else a = a_in.
+    // a_out (optional) receives a; rf (optional) receives ab2rf(a, b) (ab2rf.m:14-29).
+    void slr(int n, const double* b_re, const double* b_im, const double* a_in_re, const double* a_in_im,
+             double* a_re, double* a_im, double* rf_re, double* rf_im);
     // kernel test hooks
     void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
     void test_chol(int n, const double* H, double* out_l, double* out_m);

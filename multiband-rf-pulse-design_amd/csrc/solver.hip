@@ -2232,6 +2232,39 @@ void Solver::test_specfact(int n, const double* x, double* h_re, double* h_im) {
     for (int i = 0; i < n; ++i) { h_re[i] = h[2 * i]; h_im[i] = h[2 * i + 1]; }
 }
 
+void Solver::slr(int n, const double* b_re, const double* b_im, const double* a_in_re, const double* a_in_im,
+                 double* a_re, double* a_im, double* rf_re, double* rf_im) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const size_t N = (size_t)n;
+    DevBuf db(2 * N * 8), dbil(2 * N * 8), da(2 * N * 8), drf(2 * N * 8), dw(a_in_re ? 8 : 48 * N * 8);
+    std::vector<double> h(2 * N);
+    MBFIR_HIP(hipMemcpyAsync(db.p, b_re, N * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(db.as<double>() + N, b_im, N * 8, hipMemcpyHostToDevice, S.st));
+    if (a_in_re) {
+        for (size_t i = 0; i < N; ++i) { h[2 * i] = a_in_re[i]; h[2 * i + 1] = a_in_im[i]; }
+        MBFIR_HIP(hipMemcpyAsync(da.p, h.data(), 2 * N * 8, hipMemcpyHostToDevice, S.st));
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+    } else {
+        slr_b2a_launch(db.as<double>(), db.as<double>() + N, n, dw.as<double>(), da.as<double>(), S.st);
+    }
+    if (a_re) {
+        MBFIR_HIP(hipMemcpyAsync(h.data(), da.p, 2 * N * 8, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+        for (size_t i = 0; i < N; ++i) { a_re[i] = h[2 * i]; a_im[i] = h[2 * i + 1]; }
+    }
+    if (rf_re) {
+        std::vector<double> hb(2 * N);
+        for (size_t i = 0; i < N; ++i) { hb[2 * i] = b_re[i]; hb[2 * i + 1] = b_im[i]; }
+        MBFIR_HIP(hipMemcpyAsync(dbil.p, hb.data(), 2 * N * 8, hipMemcpyHostToDevice, S.st));
+        slr_ab2rf_launch(da.as<double>(), dbil.as<double>(), n, drf.as<double>(), S.st);
+        MBFIR_HIP(hipMemcpyAsync(h.data(), drf.p, 2 * N * 8, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+        for (size_t i = 0; i < N; ++i) { rf_re[i] = h[2 * i]; rf_im[i] = h[2 * i + 1]; }
+    }
+    MBFIR_HIP(hipGetLastError());
+}
+
 // fp64 peak microbenchmarks (roofline denominators; the local hardware guide lists no fp64
 // matrix peak).  One wave per SIMD, 8 independent accumulators, operands in registers.
 __global__ __launch_bounds__(256) void k_peak_mfma(double* out, int iters) {
