@@ -360,7 +360,7 @@ def rfscaleg(rf, t, gamma):
 
 
 from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)
-from .search import fir_ap   # noqa: E402  (fir_ap.m: order / transition-width searches around fir_ap_cvx)
+from .search import fir_ap, fir_qp, fir_min_order_linprog, fir_min_order_qprog_phs   # noqa: E402  (outer bisections)
 
 _WHICH = {"fir_ap_cvx": 0, "fir_qp_cvx": 1, "fir_linprog": 2, "fir_qprog_phs": 3}
 _pools = {}

@@ -91,6 +91,19 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         std::vector<double> x;
         SolveOpts so = to_opts(opts);
         int st = ctx->solver->solve(P, so, x, si);
+        // The lattice path forms the normal matrix from trigonometric moments; its rounding noise (recurrences,
+        // ~1e-14 relative) is above that of the dense Gram products, so on programs that end near cond(H) ~ 1e14
+        // it can hit the numerical wall a few iterations before the dense path does.
+        // A numerical failure there -- not an infeasibility certificate -- is retried once on the dense path.
+        if (status_to_rc(st) == MBFIR_NUMERICAL && si.lattice && !so.dense_trig && so.shard_size <= 1 &&
+            (double)P.Mf * P.N() <= 6e8) {
+            const SolveInfo first = si;
+            so.dense_trig = true;
+            st = ctx->solver->solve(P, so, x, si);
+            si.ms_assemble += first.ms_assemble; si.ms_solve += first.ms_solve; si.ms_chol += first.ms_chol;
+            si.ms_gram += first.ms_gram; si.h_builds += first.h_builds; si.chol_launches += first.chol_launches;
+            si.chol_flop += first.chol_flop; si.iters += first.iters;
+        }
         ctx->last_x = x;
         double t_solved = now_ms();
         int rc = status_to_rc(st);

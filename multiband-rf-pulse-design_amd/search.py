@@ -1,4 +1,5 @@
-"""Outer searches around the convex designers: host-side mirror of fir_ap.m.
+"""Outer searches around the convex designers: host-side mirrors of fir_ap.m, fir_qp.m,
+ss/fir_min_order_linprog.m and ss/fir_min_order_qprog_phs.m.
 
 fir_ap(n, f, a, d, Peak, min_order, min_tran, ...) reproduces the reference's two bisections
 (fir_ap.m:63-106 transition widening, :143-176 order) probe for probe when `probes == 1`.  With
@@ -104,3 +105,140 @@ def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *,
             h, status = design([(n_op, f)])[0]
             note("n_final", n_op, status)
     return h, status, n_op, f_op
+
+
+QP_DF_THRE = 0.001      # fir_qp.m:30
+QP_LAMBDA = 1e5         # fir_qp.m:31
+
+
+def fir_qp(n, f, a, d, min_order=0, min_tran=0, min_peak=0, dbg=0, *, opts=None, log=None, designer=None):
+    """Returns (h, status) like fir_qp.m: the low-pass transition-width and order bisections of that file,
+    which (as in the reference, fir_qp.m:46,69,97,111,131) run on fir_ap_cvx(n, f, a, d, 1e5) with the default
+    Peak.  f has four edges [f1 fp fs f4]; the widened spec is [-fp fp fs f4] (fir_qp.m:68).
+    designer: callable (n, f) -> (h, status) replacing the device call (tests)."""
+    import mbfir
+    if n is None or f is None or a is None or d is None:
+        raise ValueError("not enough input")                                          # fir_qp.m:33
+    if min_peak:
+        raise NotImplementedError("min_peak (fir_flip_zero.m) is outside the built path")
+    f = np.asarray(f, dtype=np.float64).ravel()
+    note = (lambda *t: log.append(t)) if log is not None else (lambda *t: None)
+    design = designer or (lambda nn, ff: mbfir.fir_ap_cvx(nn, ff, a, d, QP_LAMBDA, opts=opts))
+    h1, status1 = design(n, f)                                                        # fir_qp.m:46
+    if status1 == "Failed":
+        raise ValueError("original parameters are too tight")                         # fir_qp.m:47-49
+    h, status = h1, status1
+    df_top = None
+    if min_tran > 0:                                                                  # fir_qp.m:56-85
+        centre = (f[2] + f[1]) / 2
+        df_top, df_bot = (f[2] - f[1]) / 2, 0.0
+        while True:
+            df_mid = (df_top + df_bot) / 2
+            f_new = np.array([-(centre - df_mid), centre - df_mid, centre + df_mid, f[3]])
+            h0, s0 = design(n, f_new)
+            note("df", df_mid, s0)
+            if s0 == "Failed":
+                df_bot = df_mid
+            else:
+                h, status, df_top = h0, s0, df_mid
+            if df_top - df_bot < QP_DF_THRE:
+                break
+    if min_tran != 0:                                                                 # fir_qp.m:88-100
+        if not 0 < min_tran <= 1:
+            raise ValueError("invalid input of min_tran")
+        centre = (f[2] + f[1]) / 2
+        df_new = ((f[2] - f[1]) / 2) * (1 - min_tran) + df_top * min_tran
+        f = np.array([-(centre - df_new), centre - df_new, centre + df_new, f[3]])
+        h, status = design(n, f)
+        note("df_final", df_new, status)
+    n_top = n
+    if min_order > 0:                                                                 # fir_qp.m:104-124
+        n_bot = 2
+        while True:
+            n_mid = int(math.ceil((n_top + n_bot) / 2))
+            h0, s0 = design(n_mid, f)
+            note("n", n_mid, s0)
+            if s0 == "Failed":
+                n_bot = n_mid
+            else:
+                h, status, n_top = h0, s0, n_mid
+            if n_top - n_bot == 1:
+                break
+    if min_order not in (0, 1):                                                       # fir_qp.m:126-136
+        if not 0 < min_order < 1:
+            raise ValueError("invalid input of min_order")
+        n_new = int(math.ceil(n * (1 - min_order) + n_top * min_order))
+        h, status = design(n_new, f)
+        note("n_final", n_new, status)
+    return h, status
+
+
+def _min_order(which, n, f, a, d, even_odd, probes, opts, log, designer):
+    """ss/fir_min_order_linprog.m:56-233 / ss/fir_min_order_qprog_phs.m:40-213 (the two files differ only in
+    the designer they call): bisection over the half length, odd lengths first, then even lengths below the
+    best odd one; the shorter of the two wins, odd on a tie (:222-229)."""
+    import mbfir
+    note = (lambda *t: log.append(t)) if log is not None else (lambda *t: None)
+    if even_odd not in (1, 2):
+        even_odd = 0
+
+    def design(taps):
+        if designer is not None:
+            return [designer(t) for t in taps]
+        if len(taps) == 1:
+            return [getattr(mbfir, which)(taps[0], f, a, d, opts=opts)]
+        return mbfir.solve_batch([(which, (t, f, a, d)) for t in taps], opts=opts, streams=min(len(taps), 4))
+
+    def search(n_top, taps_of):
+        """The reference's loop (:79-140): the first probe is n_top itself."""
+        best = None
+        n_bot, n_cur = 1, n_top
+        while n_top - n_bot > 1:
+            if probes == 1 or n_cur == n_top:
+                cand = [n_cur]
+            else:                                        # several interior points of (n_bot, n_top) at once
+                cand = sorted({n_bot + int(math.ceil((n_top - n_bot) * (q + 1) / (probes + 1))) for q in range(probes)}
+                              - {n_bot, n_top}) or [n_cur]
+            res = design([taps_of(c) for c in cand])
+            hit_fail = False
+            for c, (h0, s0) in sorted(zip(cand, res), reverse=True):     # from the longest filter down
+                note("n", taps_of(c), s0)
+                if s0 == "Solved":
+                    best, n_top = h0, c
+                else:
+                    n_bot = max(n_bot, c)
+                    hit_fail = True
+                    break                                # everything shorter is taken as failed too
+            n_cur = n_bot if (not hit_fail and n_top == n_bot + 1) else int(math.ceil((n_top + n_bot) / 2))
+        return best
+
+    n_odd_max = 2 * ((n - 1) // 2) + 1
+    n_even_max = 2 * (n // 2)
+    best_odd = best_even = None
+    if even_odd != 2:
+        best_odd = search((n_odd_max + 1) // 2, lambda c: 2 * c - 1)
+    if even_odd != 1:
+        top = n_even_max // 2 if best_odd is None else min(n_even_max // 2, (len(best_odd) + 1) // 2)
+        best_even = search(top, lambda c: 2 * c)
+    if best_odd is None and best_even is None:
+        return np.zeros(0, dtype=np.complex128), "Failed"
+    if best_odd is None:
+        return best_even, "Solved"
+    if best_even is None:
+        return best_odd, "Solved"
+    return (best_odd if len(best_odd) < len(best_even) else best_even), "Solved"
+
+
+def fir_min_order_linprog(n, f, a, d, even_odd=0, dbg=0, *, probes=1, opts=None, log=None, designer=None):
+    """`[h, status] = fir_min_order_linprog(n, f, a, d, even_odd, dbg)` (ss/fir_min_order_linprog.m:56):
+    shortest linear-phase filter of at most n taps; even_odd 1 = odd lengths only, 2 = even only."""
+    if n is None or f is None or a is None or d is None:
+        raise ValueError("Usage: function [h, status] = fir_min_order(n, f, a, d, even_odd, dbg)")
+    return _min_order("fir_linprog", n, f, a, d, even_odd, probes, opts, log, designer)
+
+
+def fir_min_order_qprog_phs(n, f, a, d, even_odd=0, dbg=0, *, probes=1, opts=None, log=None, designer=None):
+    """`[h, status] = fir_min_order_qprog_phs(n, f, a, d, even_odd, dbg)` (ss/fir_min_order_qprog_phs.m:40)."""
+    if n is None or f is None or a is None or d is None:
+        raise ValueError("Usage: function [h, status] = fir_min_order(n, f, a, d, even_odd, dbg)")
+    return _min_order("fir_qprog_phs", n, f, a, d, even_odd, probes, opts, log, designer)

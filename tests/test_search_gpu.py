@@ -51,3 +51,64 @@ def test_argument_errors_and_tight_spec():
         mbfir.fir_ap(100, f, a, d, 1e-3, 0, 0, 1)
     with pytest.raises(ValueError, match="original parameters are too tight"):
         mbfir.fir_ap(40, f, a, d, 1e-3, 1, 0)           # infeasible at 40 taps (fir_ap.m:52-54)
+
+
+def _oracle_designer(name, f, a, d):
+    from oracle import designers
+    return lambda taps: getattr(designers, name)(taps, f, a, d)
+
+
+@pytest.mark.parametrize("which,spec", [
+    ("fir_min_order_linprog", ([0, 0.2, 0.3, 1], [1, 1, 0, 0], [0.01, 0.01])),
+    ("fir_min_order_linprog", ([-1, -0.4, -0.2, 0.3, 0.5, 1], [0, 0, 1, 0.8, 0, 0], [0.01, 0.02, 0.01])),
+    ("fir_min_order_qprog_phs", ([-0.6, -0.3, -0.1, 0.1, 0.3, 0.6], [0, 0, 1, 1, 0, 0], [0.02, 0.05 * np.exp(0.3j), 0.02])),
+])
+def test_min_order_searches_follow_the_oracle_probe_for_probe(which, spec):
+    """ss/fir_min_order_*.m on the device against the same search driven by the CPU oracle: same probe
+    sequence, same verdict at every probe, same final taps."""
+    f, a, d = spec
+    base = "fir_linprog" if "linprog" in which else "fir_qprog_phs"
+    lg, lo = [], []
+    hg, sg = getattr(mbfir, which)(48, f, a, d, log=lg)
+    ho, so = getattr(mbfir, which)(48, f, a, d, log=lo, designer=_oracle_designer(base, f, a, d))
+    assert lg == lo and sg == so == "Solved"
+    assert len(hg) == len(ho) and relinf(hg, ho) <= 1e-6
+    # one tap fewer of the same parity is infeasible (that is what the bisection certifies)
+    if len(hg) > 2:
+        assert getattr(mbfir, base)(len(hg) - 2, f, a, d)[1] == "Failed"
+    h4, s4 = getattr(mbfir, which)(48, f, a, d, probes=4)
+    assert s4 == "Solved" and len(h4) == len(hg) and relinf(h4, hg) <= 1e-9
+
+
+def test_min_order_search_reports_failure_when_the_longest_filter_fails():
+    h, s = mbfir.fir_min_order_linprog(12, [0, 0.2, 0.22, 1], [1, 1, 0, 0], [0.001, 0.001])
+    assert s == "Failed" and len(h) == 0
+
+
+def test_fir_qp_search_matches_the_oracle():
+    """fir_qp.m (which designs through fir_ap_cvx with lambda = 1e5): order bisection of a low-pass spec."""
+    from oracle import designers
+    f, a, d = [-0.25, 0.25, 0.45, 1.0], [0.15, 0.15, 0, 0], [0.004, 0.002]   # default Peak=1e-3 caps the energy at n/1000
+    lg, lo = [], []
+    hg, sg = mbfir.fir_qp(40, f, a, d, 1, 0, log=lg)
+    ho, so = mbfir.fir_qp(40, f, a, d, 1, 0, log=lo, designer=lambda n, ff: designers.fir_ap_cvx(n, ff, a, d, 1e5))
+    assert lg == lo and sg == so == "Solved" and len(hg) == len(ho)
+    assert relinf(hg, ho) <= 1e-6
+    # transition bisection at 20 taps (at 40 taps with lambda = 1e5 every probe near the threshold ends at the
+    # reduced-accuracy wall in both solvers and the verdicts there are a coin toss -- tools/gpu_qp_search.py)
+    lg, lo = [], []
+    hg, sg = mbfir.fir_qp(20, f, a, d, 0, 0.5, log=lg)
+    ho, so = mbfir.fir_qp(20, f, a, d, 0, 0.5, log=lo, designer=lambda n, ff: designers.fir_ap_cvx(n, ff, a, d, 1e5))
+    assert lg == lo and sg == so == "Solved" and len(hg) == 20 and lg[-1][0] == "df_final" and lg[-1][1] < 0.1
+    assert relinf(hg, ho) <= 1e-6
+
+
+def test_lattice_numerical_failure_is_retried_on_the_dense_path():
+    """fir_ap_cvx(20, ..., 1e5): the moment-based normal matrix hits the numerical wall at iteration 19, the dense
+    Gram path follows the oracle to a clean solve (25 iterations); the entry point retries by itself."""
+    from oracle import designers
+    f, a, d = [-0.25, 0.25, 0.45, 1.0], [0.15, 0.15, 0, 0], [0.004, 0.002]
+    h, s, i = mbfir.fir_ap_cvx(20, f, a, d, 1e5, info=True)
+    ho, so = designers.fir_ap_cvx(20, f, a, d, 1e5)
+    assert s == so == "Solved" and i["lattice"] == 0 and i["relgap"] <= 1e-8
+    assert relinf(h, ho) <= 1e-6
