@@ -8,6 +8,9 @@ four1.c} where they lie under /root/reference; nothing of them is copied here). 
   rf_c    cabc2rf.code.c(conj(a_c), b)                        -- reference output, verbatim; conj(a_c) is the
           alpha on MATLAB's frequency axis (oracle/slr.py header explains the conjugate)
   tol_a   agreement the two paddings (8 n vs power of two) allow for b2a at that max|B|
+slr_newmat.json is the reference's own data file rf_tools/mex5/new.mat converted to JSON (scipy.io.loadmat; variables
+h, hn, rf, rfm), nothing computed: the only stored output of the reference's b2rf chain.  Its beta has max|B| = 1.0014,
+i.e. it sits on the clipping branch where alpha touches zero, so it pins the chain to 1e-2 only.
 Run:  python tests/golden/make_golden_slr.py
 """
 import json
@@ -62,6 +65,16 @@ def main():
     with open(os.path.join(HERE, "slr_golden.json"), "w") as f:
         json.dump(out, f)
     print("wrote %d cases" % len(out))
+    mat = "/root/reference/rf_tools/mex5/new.mat"
+    if os.path.exists(mat):
+        import scipy.io as sio
+        m = sio.loadmat(mat)
+        nm = dict(source="rf_tools/mex5/new.mat of the reference (variables h, hn, rf, rfm): a 64-tap beta polynomial "
+                         "and the RF its MEX chain produced")
+        for k in ("h", "hn", "rf", "rfm"):
+            nm[k] = cplx(m[k].ravel())
+        with open(os.path.join(HERE, "slr_newmat.json"), "w") as f:
+            json.dump(nm, f)
 
 
 if __name__ == "__main__":

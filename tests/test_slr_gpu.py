@@ -72,3 +72,11 @@ def test_ab2rf_rejects_long_and_ragged_inputs():
         mbfir.b2rf(np.ones(2049) * 1e-4)
     with pytest.raises(ValueError):
         mbfir.ab2rf(np.ones(4), np.ones(5))
+
+
+def test_device_chain_on_the_reference_data_file():
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "slr_newmat.json")))
+    h, rfm = cx(g["h"]), cx(g["rfm"])
+    got = mbfir.b2rf(h)
+    assert np.max(np.abs(got - rfm)) / np.max(np.abs(rfm)) < 5e-3
+    assert np.max(np.abs(got - slr.b2rf(h))) / np.max(np.abs(rfm)) < 1e-6        # alpha -> 0 amplifies rounding
