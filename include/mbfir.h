@@ -179,6 +179,19 @@ int mbfir_ab2rf(mbfir_ctx* ctx, int n, const double* a_re, const double* a_im, c
                 const double* b_im, double* rf_re, double* rf_im);
 int mbfir_b2rf(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* rf_re, double* rf_im);
 
+/* ---- Forward simulation over off-resonance ----------------------------------------------
+ * Cayley-Klein parameters (a, b) of the rotation an n-sample pulse produces at nx positions x
+ * (rf in radians per sample; g: n per-sample gradient / time weights, NULL = 2 pi / n each, so that x counts
+ * cycles over the pulse = frequency x duration).
+ *  mode 0: `[a b] = abrm(rf, g, x)` (rf_tools/abrm.m:24-62, the .m twin of the MEX abrx that abr.m:26-30 calls
+ *          and that sim_rf_spectral.m's blochC run agrees with for T1, T2 >> pulse length): one rotation about
+ *          (Re rf, Im rf, x g) per sample;
+ *  mode 1: the hard-pulse model that ab2rf inverts exactly (precession, then the hard pulse) -- closes the loop
+ *          b -> mbfir_b2rf -> mbfir_abr -> B(w) to rounding.
+ * abr.m's convention is b = -conj(b) of mode 0; mxy = 2 conj(a) b, mz = 1 - 2 |b|^2 (abr.m:11-14). */
+int mbfir_abr(mbfir_ctx* ctx, int n, const double* rf_re, const double* rf_im, const double* g, int nx,
+              const double* x, int mode, double* a_re, double* a_im, double* b_re, double* b_im);
+
 /* Device kernel test hooks (need a GPU; host arrays in, host arrays out):
  *  mbfir_test_gram: T = A' diag(dk) A for nw weight vectors; A is m x nt row-major,
  *     d is nw x m, out is nw x nt x nt (full symmetric).

@@ -91,6 +91,7 @@ SYMBOLS = {
     "mbfir_b2a": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
     "mbfir_ab2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mbfir_b2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
+    "mbfir_abr": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp]),
     "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mbfir_program_free": (None, [C.c_void_p]),
@@ -353,6 +354,29 @@ def b2rf(bc, *, ctx=None):
     return rre + 1j * rim
 
 
+def abrm(rf, g=None, x=None, *, hard_pulse=False, ctx=None):
+    """`[a b] = abrm(rf, g, x)` (rf_tools/abrm.m): Cayley-Klein parameters of the pulse at positions x; with two
+    arguments the second one is x.  hard_pulse=True simulates the model ab2rf inverts exactly instead."""
+    ctx = ctx or get_context()
+    if x is None:
+        x, g = g, None
+    rre, rim = _split(rf)
+    xv = _vec(x)
+    gv = _vec(g) if g is not None else None
+    if gv is not None and len(gv) != len(rre):
+        raise ValueError("abrm: g must have one entry per rf sample")
+    out = [np.zeros(len(xv)) for _ in range(4)]
+    _check(ctx, load_library().mbfir_abr(ctx._h, len(rre), _ptr(rre), _ptr(rim), _ptr(gv) if gv is not None else None,
+                                         len(xv), _ptr(xv), 1 if hard_pulse else 0, *[_ptr(o) for o in out]))
+    return out[0] + 1j * out[1], out[2] + 1j * out[3]
+
+
+def abr(rf, g=None, x=None, *, ctx=None):
+    """`[a b] = abr(rf, g, x)` (rf_tools/abr.m:19-34): abrm with Le Roux's convention on beta, b = -conj(b)."""
+    a, b = abrm(rf, g, x, ctx=ctx)
+    return a, -np.conj(b)
+
+
 def rfscaleg(rf, t, gamma):
     """`rfs = rfscaleg(rf, t, gamma)` (rfscaleg.m:12-16): radians -> Gauss; t in ms, gamma in kHz/G."""
     rf = np.asarray(rf)
@@ -360,6 +384,7 @@ def rfscaleg(rf, t, gamma):
 
 
 from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)
+from .dzrf import dzrf_mb, fir_upsample, rf_mrange_desired   # noqa: E402  (dzrf_mb.m driver)
 from .search import fir_ap, fir_qp, fir_min_order_linprog, fir_min_order_qprog_phs   # noqa: E402  (outer bisections)
 
 _WHICH = {"fir_ap_cvx": 0, "fir_qp_cvx": 1, "fir_linprog": 2, "fir_qprog_phs": 3}

@@ -301,6 +301,12 @@ int mbfir_b2rf(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, do
     if (!ctx || n < 1 || n > 2048 || !b_re || !b_im || !rf_re || !rf_im) return MBFIR_E_ARG;
     MBFIR_TRY(ctx, ctx->solver->slr(n, b_re, b_im, nullptr, nullptr, nullptr, nullptr, rf_re, rf_im));
 }
+int mbfir_abr(mbfir_ctx* ctx, int n, const double* rf_re, const double* rf_im, const double* g, int nx, const double* x,
+              int mode, double* a_re, double* a_im, double* b_re, double* b_im) {
+    if (!ctx || n < 1 || nx < 1 || !rf_re || !rf_im || !x || !a_re || !a_im || !b_re || !b_im || (mode != 0 && mode != 1))
+        return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->abr(n, rf_re, rf_im, g, nx, x, mode, a_re, a_im, b_re, b_im));
+}
 int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tf_mfma, double* tf_valu) {
     MBFIR_TRY(ctx, ctx->solver->test_mfma_peak(tf_mfma, tf_valu));
 }

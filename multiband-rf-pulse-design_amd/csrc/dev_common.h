@@ -101,6 +101,8 @@ void specfact_launch(const double* x, int n, double* work, double* hout, hipStre
 // Inverse SLR (slr.hip; b2a.m:15-32, ab2rf.m:14-29).  b2a: work holds 48 n doubles; a_il / b_il / rf_il are
 // interleaved (re, im) device arrays of 2 n doubles.  ab2rf: n <= 2048.
 void slr_b2a_launch(const double* b_re, const double* b_im, int n, double* work, double* a_il, hipStream_t st);
+void slr_abr_launch(const double* rf_il, const double* g, int n, const double* x, int nx, int mode, double* a_il, double* b_il,
+                    hipStream_t st);
 void slr_ab2rf_launch(const double* a_il, const double* b_il, int n, double* rf_il, hipStream_t st);
 
 }  // namespace mbfir

@@ -128,6 +128,63 @@ __global__ __launch_bounds__(1024) void k_ab2rf(const double* __restrict__ a_il,
     }
 }
 
+// Forward simulation of an RF pulse over off-resonance: Cayley-Klein parameters per position.
+//   mode 0: rf_tools/abrm.m:40-57 -- one rotation about (Re rf, Im rf, x g_m) per sample
+//   mode 1: the hard-pulse model the inverse SLR transform inverts exactly -- free precession by x g_m on beta, then
+//           the hard pulse of the sample
+// one thread per position, the pulse staged through LDS; g may be null (2 pi / n per sample).
+__global__ __launch_bounds__(256) void k_abr(const double* __restrict__ rf_il, const double* __restrict__ g, int n,
+                                             const double* __restrict__ x, int nx, int mode, double* __restrict__ a_il,
+                                             double* __restrict__ b_il) {
+    __shared__ double2 srf[256];
+    __shared__ double sg[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double xv = i < nx ? x[i] : 0.0;
+    double2 a = make_double2(1, 0), b = make_double2(0, 0);
+    const double g0 = 2.0 * M_PI / n;
+    for (int m0 = 0; m0 < n; m0 += 256) {
+        __syncthreads();
+        const int mm = m0 + threadIdx.x;
+        if (mm < n) { srf[threadIdx.x] = make_double2(rf_il[2 * mm], rf_il[2 * mm + 1]); sg[threadIdx.x] = g ? g[mm] : g0; }
+        __syncthreads();
+        const int cnt = min(256, n - m0);
+        for (int q = 0; q < cnt; ++q) {
+            const double2 r = srf[q];
+            const double om = xv * sg[q];
+            double2 av, bv;                              // step: a' = av a - conj(bv) b ; b' = bv a + conj(av) b
+            if (mode == 0) {
+                const double phi = sqrt(r.x * r.x + r.y * r.y + om * om);
+                double sn, cs;
+                sincos(0.5 * phi, &sn, &cs);
+                const double inv = phi > 0 ? sn / phi : 0.0;
+                av = make_double2(cs, -om * inv);
+                bv = make_double2(r.y * inv, -r.x * inv);                  // -i (n1 + i n2) sin
+                const double2 an = make_double2(av.x * a.x - av.y * a.y - (bv.x * b.x + bv.y * b.y),
+                                                av.x * a.y + av.y * a.x - (bv.x * b.y - bv.y * b.x));
+                const double2 bn = make_double2(bv.x * a.x - bv.y * a.y + (av.x * b.x + av.y * b.y),
+                                                bv.x * a.y + bv.y * a.x + (av.x * b.y - av.y * b.x));
+                a = an; b = bn;
+            } else {
+                const double th = hypot(r.x, r.y);
+                double sn, cs, sz, cz;
+                sincos(0.5 * th, &sn, &cs);
+                sincos(-om, &sz, &cz);                                   // z^-1
+                const double2 zb = make_double2(cz * b.x - sz * b.y, cz * b.y + sz * b.x);
+                const double inv = th > 0 ? sn / th : 0.0;
+                const double2 S = make_double2(-r.y * inv, r.x * inv);    // i e^{i arg rf} sin(th/2)
+                const double2 an = make_double2(cs * a.x - (S.x * zb.x + S.y * zb.y), cs * a.y - (S.x * zb.y - S.y * zb.x));
+                const double2 bn = make_double2(S.x * a.x - S.y * a.y + cs * zb.x, S.x * a.y + S.y * a.x + cs * zb.y);
+                a = an; b = bn;
+            }
+        }
+    }
+    if (i < nx) { a_il[2 * i] = a.x; a_il[2 * i + 1] = a.y; b_il[2 * i] = b.x; b_il[2 * i + 1] = b.y; }
+}
+void slr_abr_launch(const double* rf_il, const double* g, int n, const double* x, int nx, int mode, double* a_il, double* b_il,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(k_abr, dim3(cdiv(nx, 256)), dim3(256), 0, st, rf_il, g, n, x, nx, mode, a_il, b_il);
+}
+
 // work: 3 * 8n double2.  a_il / rf_il: device arrays of 2n doubles (interleaved).
 void slr_b2a_launch(const double* b_re, const double* b_im, int n, double* work, double* a_il, hipStream_t st) {
     const int N = 8 * n;

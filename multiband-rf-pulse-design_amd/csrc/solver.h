@@ -42,6 +42,9 @@ public:
     // a_out (optional) receives a; rf (optional) receives ab2rf(a, b) (ab2rf.m:14-29).
     void slr(int n, const double* b_re, const double* b_im, const double* a_in_re, const double* a_in_im,
              double* a_re, double* a_im, double* rf_re, double* rf_im);
+    // Forward simulation (slr.hip k_abr): a, b over nx positions; g null = 2 pi / n per sample; mode 0 abrm.m, 1 hard pulse.
+    void abr(int n, const double* rf_re, const double* rf_im, const double* g, int nx, const double* x, int mode,
+             double* a_re, double* a_im, double* b_re, double* b_im);
     // kernel test hooks
     void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
     void test_chol(int n, const double* H, double* out_l, double* out_m);

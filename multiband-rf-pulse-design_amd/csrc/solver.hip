@@ -2265,6 +2265,25 @@ void Solver::slr(int n, const double* b_re, const double* b_im, const double* a_
     MBFIR_HIP(hipGetLastError());
 }
 
+void Solver::abr(int n, const double* rf_re, const double* rf_im, const double* g, int nx, const double* x, int mode,
+                 double* a_re, double* a_im, double* b_re, double* b_im) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const size_t N = (size_t)n, X = (size_t)nx;
+    DevBuf drf(2 * N * 8), dg(N * 8), dx(X * 8), da(2 * X * 8), db(2 * X * 8);
+    std::vector<double> h(2 * N), oa(2 * X), ob(2 * X);
+    for (size_t i = 0; i < N; ++i) { h[2 * i] = rf_re[i]; h[2 * i + 1] = rf_im[i]; }
+    MBFIR_HIP(hipMemcpyAsync(drf.p, h.data(), 2 * N * 8, hipMemcpyHostToDevice, S.st));
+    if (g) MBFIR_HIP(hipMemcpyAsync(dg.p, g, N * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dx.p, x, X * 8, hipMemcpyHostToDevice, S.st));
+    slr_abr_launch(drf.as<double>(), g ? dg.as<double>() : nullptr, n, dx.as<double>(), nx, mode, da.as<double>(), db.as<double>(), S.st);
+    MBFIR_HIP(hipMemcpyAsync(oa.data(), da.p, 2 * X * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(ob.data(), db.p, 2 * X * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+    for (size_t i = 0; i < X; ++i) { a_re[i] = oa[2 * i]; a_im[i] = oa[2 * i + 1]; b_re[i] = ob[2 * i]; b_im[i] = ob[2 * i + 1]; }
+}
+
 // fp64 peak microbenchmarks (roofline denominators; the local hardware guide lists no fp64
 // matrix peak).  One wave per SIMD, 8 independent accumulators, operands in registers.
 __global__ __launch_bounds__(256) void k_peak_mfma(double* out, int iters) {
