@@ -1,5 +1,5 @@
 /* Minimal stand-in for MATLAB's mex.h -- TEST INFRASTRUCTURE ONLY (tests/test_host_cpu.py uses it to
- * syntax-check matlab/mbfir_mex.c where no MATLAB exists).  Declares only what the gateway calls; it is
+ * syntax-check matlab/mbfir_mex.c and matlab/mbfir_slr_mex.c where no MATLAB exists).  Declares only what the gateway calls; it is
  * not used to build anything that runs. */
 #ifndef MBFIR_STUB_MEX_H
 #define MBFIR_STUB_MEX_H
@@ -14,6 +14,7 @@ size_t mxGetM(const mxArray*);
 size_t mxGetN(const mxArray*);
 double mxGetScalar(const mxArray*);
 int mxIsComplex(const mxArray*);
+int mxIsEmpty(const mxArray*);
 double* mxGetPr(const mxArray*);
 double* mxGetPi(const mxArray*);
 double* mxGetDoubles(const mxArray*);
