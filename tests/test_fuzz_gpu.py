@@ -1,0 +1,63 @@
+"""Seeded random band specs through all four designers: device (default path) against the CPU oracle -- same verdict,
+taps within 1e-6 relative l-inf whenever both solves are clean (not the reduced-accuracy exit)."""
+import warnings
+
+import numpy as np
+import pytest
+from conftest import relinf
+
+import mbfir
+from oracle import conic_ipm, designers
+
+pytestmark = pytest.mark.gpu
+
+
+def random_bands(rng, lo, hi, kmax):
+    k = int(rng.integers(2, kmax + 1))
+    widths = rng.uniform(0.03, 0.12, k) * (hi - lo) / 2
+    gaps = rng.uniform(0.06, 0.2, k + 1) * (hi - lo) / 2
+    scale = (hi - lo) / (widths.sum() + gaps.sum())
+    edges, x = [], lo + gaps[0] * scale
+    for w, g in zip(widths, gaps[1:]):
+        edges += [x, x + w * scale]
+        x += (w + g) * scale
+    return np.array(edges), k
+
+
+def make_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    which = ["fir_ap_cvx", "fir_qp_cvx", "fir_linprog", "fir_qprog_phs"][seed % 4]
+    n = int(rng.integers(16, 56))
+    if which == "fir_linprog" and rng.random() < 0.5:
+        f, k = random_bands(rng, 0.0, 1.0, 3)
+    else:
+        f, k = random_bands(rng, -1.0, 1.0, 4)
+    amp = np.where(rng.random(k) < 0.5, 0.0, rng.uniform(0.3, 1.0, k))
+    if not np.any(amp > 0):
+        amp[int(rng.integers(0, k))] = 0.8
+    a = np.repeat(amp, 2)
+    d = rng.uniform(0.01, 0.05, k)
+    if which == "fir_ap_cvx":
+        return which, (n, f, a * 0.3, d * 0.3, 0.1, 10 ** rng.uniform(-2.5, -1))
+    if which == "fir_qp_cvx":
+        return which, (n, f, a, d, float(rng.uniform(2, 20)), [10.0, [0.1, 5.0]][seed // 4 % 2])
+    if which == "fir_linprog":
+        return which, (n, f, a, d)
+    ph = np.repeat(np.exp(1j * rng.uniform(-0.3, 0.3, k)), 2)
+    dc = np.where(amp > 0, d * np.exp(0.3j), d.astype(complex))       # pass bands carry a phase ripple (fir_qprog_phs.m)
+    return which, (n, f, a * ph, dc)
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_spec_matches_the_oracle(seed):
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    which, args = make_case(seed)
+    hg, sg, ig = getattr(mbfir, which)(*args, info=True)
+    ho, so, io = getattr(designers, which)(*args, info=True)
+    assert sg == so, (which, args[0], ig["rc"], io["status"])
+    if sg == "Solved":
+        clean = io["status"] == conic_ipm.STATUS_OPTIMAL and ig["relgap"] <= 1e-6
+        assert abs(ig["pcost"] - io["pcost"]) <= 1e-6 * max(1.0, abs(io["pcost"]))
+        if clean:
+            # absolute floor: a spec whose optimum is h ~ 1e-10 has nothing to compare relatively
+            assert np.max(np.abs(hg - ho)) <= 1e-6 * max(np.max(np.abs(ho)), 1e-3), (which, args[0], ig["iters"], io["iters"])
