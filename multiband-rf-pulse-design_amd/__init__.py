@@ -466,10 +466,11 @@ def _check_spec(f, a, d):
 
 
 # ---- host-only introspection (no GPU): structured program -> dense (c, G, h) -------------------
-def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None):
+def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None, rows=None):
     """Run the product's C++ problem assembly for designer `which` (0 ap, 1 qp, 2 linprog,
     3 qprog_phs; for 3 pass complex a, d) and expand the structured rows to dense arrays.
     shard=(rank, size) returns the rows that rank keeps in a row-sharded solve.
+    rows: expand only these rows of G / h (a program too large to expand whole, e.g. n=2048, m=131072).
     Returns (rc, dict) -- used by the CPU tests to compare against the oracle."""
     lib = load_library()
     f = _vec(f)
@@ -512,16 +513,25 @@ def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None):
                                _ptr(ey), _ptr(h))
     finally:
         lib.mbfir_program_free(out)
-    arg = np.outer(w, tau)
+    if rows is not None:
+        rows = np.asarray(rows, dtype=np.int64)
+        freq, col, al, be, ey, h = freq[rows], col[rows], al[rows], be[rows], ey[rows], h[rows]
+        used, inv = np.unique(freq[freq >= 0], return_inverse=True)
+        wsub = w[used]
+        fmap = np.full(len(freq), -1, dtype=np.int64)
+        fmap[freq >= 0] = inv
+    else:
+        wsub, fmap = w, freq
+    arg = np.outer(wsub, tau)
     A1 = scale * np.where(kind == 0, np.cos(arg), np.sin(arg))
     A2 = psign * A1[:, pcol] if quad else np.zeros_like(A1)
-    G = np.zeros((R, Nt + Ne))
-    tr = freq >= 0
-    G[tr, :Nt] = al[tr, None] * A1[freq[tr]] + be[tr, None] * A2[freq[tr]]
+    G = np.zeros((len(freq), Nt + Ne))
+    tr = fmap >= 0
+    G[tr, :Nt] = al[tr, None] * A1[fmap[tr]] + be[tr, None] * A2[fmap[tr]]
     idr = np.nonzero(col >= 0)[0]
     G[idr, col[idr]] += al[idr]
     G[:, Nt:] = ey[:, :Ne]
-    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad, freq=freq)
+    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad, freq=freq, R=R)
 
 
 # ---- device kernel test hooks --------------------------------------------------------------------

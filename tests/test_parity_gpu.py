@@ -139,6 +139,31 @@ def test_full_size_c3_properties(dense):
     assert abs(info["pcost"] - 6.534911e-4) <= 1e-9          # oracle optimum of this instance (163 s on 8 cores)
 
 
+def test_config5_2048_taps_131072_grid_properties():
+    """BASELINE config 5 on one GPU: n=2048 taps, m=131072 grid points (N=4096 unknowns, 268k rows), lattice path.
+    The dense program would be 8.8 GB, so feasibility is checked on every cone row and 8000 random LP rows, expanded
+    from the product's structured assembly (which tests/test_host_cpu.py holds to the oracle's dense G at small sizes)."""
+    n, m = 2048, 131072
+    f, a, d = c13(n, "duration")
+    h, status, info = mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=mbfir.make_opts(grid_m=m), info=True)
+    assert status == "Solved" and h.shape == (n,) and info["lattice"] == 1
+    assert info["n_unknowns"] == 4096 and info["n_freq"] == m + 10
+    z = mbfir.get_context().last_solution(info["n_unknowns"])
+    rc, P0 = mbfir.assemble_dense(0, n, f, a, d, (0.1, 1e-3), m, rows=[0])
+    assert rc == 0
+    l, R = P0["l"], P0["R"]
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([np.sort(rng.choice(l, 8000, replace=False)), np.arange(l, R)])
+    rc, P = mbfir.assemble_dense(0, n, f, a, d, (0.1, 1e-3), m, rows=rows)
+    s = P["h"] - P["G"] @ z
+    scale = np.abs(P["h"][:8000]).max()
+    assert s[:8000].min() >= -1e-9 * scale
+    q = s[8000:].reshape(-1, 3)
+    assert len(q) == P["nq3"] and (q[:, 0] - np.hypot(q[:, 1], q[:, 2])).min() >= -1e-12
+    assert abs(P["c"] @ z - info["pcost"]) <= 1e-9 * max(1.0, abs(info["pcost"]))
+    assert info["pres"] <= 1e-8 and info["dres"] <= 1e-8 and (info["gap"] <= 1e-10 or info["relgap"] <= 1e-8)
+
+
 def test_config3_h1_dualband_ap_form():
     """BASELINE config 3 spec (specsat_H1_dualband.m) at n=512, m=16384 in the form the script really
     runs (dzrf_mb 'ap_*' -> fir_ap_cvx, obj=0.1)."""
