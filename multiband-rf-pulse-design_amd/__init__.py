@@ -386,6 +386,7 @@ def rfscaleg(rf, t, gamma):
 from . import spec          # noqa: E402  (physical multiband description -> (f, a, d); host only)
 from . import io            # noqa: E402  (rfwrite / rfwrite_varian / signa)
 from .io import rfwrite, rfwrite_varian, signa   # noqa: E402
+from .flipzero import fir_flip_zero   # noqa: E402  (fir_flip_zero.m)
 from .dzrf import dzrf_mb, fir_upsample, rf_mrange_desired   # noqa: E402  (dzrf_mb.m driver)
 from .search import fir_ap, fir_qp, fir_min_order_linprog, fir_min_order_qprog_phs   # noqa: E402  (outer bisections)
 

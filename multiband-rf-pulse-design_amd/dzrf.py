@@ -1,8 +1,7 @@
 """dzrf_mb.m, host side: physical multiband spec -> beta polynomial (device designers) -> inverse SLR (device)
 -> RF pulse in Gauss.  Mirrors the reference's signature, defaults, option strings and quirks; plots are dropped.
 
-What is not carried over, and says so when asked for: ftype 'ms' (undefined TBW in the reference,
-dzrf_mb.m:165), flip_zero / min_peak (fir_flip_zero.m, a root-flipping search outside the built path).
+What is not carried over, and says so when asked for: ftype 'ms' (undefined TBW in the reference, dzrf_mb.m:165).
 """
 import math
 
@@ -125,8 +124,8 @@ def dzrf_mb(n, dt, mb_cf, mb_range, mb_FA, mb_ripple, ptype="sat", ftype="ap_cvx
     if status == "Failed":                                                                  # :216-218
         return np.zeros(0, dtype=np.complex128), np.zeros(0, dtype=np.complex128), rf_spec, b_spec
     b = np.asarray(b, dtype=np.complex128).ravel()[::-1]                                    # :220
-    if flip_zero:
-        raise NotImplementedError("flip_zero (fir_flip_zero.m) is outside the built path")
+    if flip_zero:                                                                           # :223-225
+        b = mbfir.fir_flip_zero(b, dbg)
     if downsampling >= 2:                                                                   # :228-231
         b = fir_upsample(b, dt, dt / downsampling)
     dt = dt / downsampling

@@ -29,8 +29,6 @@ def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *,
     import mbfir
     if n is None or f is None or a is None or d is None:
         raise ValueError("not enough input")
-    if min_peak:
-        raise NotImplementedError("min_peak (fir_flip_zero.m) is outside the built path")
     if not 0 <= min_tran <= 1:
         raise ValueError("invalid input of min_tran")
     if not 0 <= min_order <= 1:
@@ -104,6 +102,8 @@ def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *,
             n_op = int(math.ceil(n * (1 - min_order) + n_top * min_order))
             h, status = design([(n_op, f)])[0]
             note("n_final", n_op, status)
+    if min_peak and len(h):                                            # fir_ap.m:199-211 (skipped by the early return above)
+        h = mbfir.fir_flip_zero(h, dbg)
     return h, status, n_op, f_op
 
 
@@ -119,8 +119,6 @@ def fir_qp(n, f, a, d, min_order=0, min_tran=0, min_peak=0, dbg=0, *, opts=None,
     import mbfir
     if n is None or f is None or a is None or d is None:
         raise ValueError("not enough input")                                          # fir_qp.m:33
-    if min_peak:
-        raise NotImplementedError("min_peak (fir_flip_zero.m) is outside the built path")
     f = np.asarray(f, dtype=np.float64).ravel()
     note = (lambda *t: log.append(t)) if log is not None else (lambda *t: None)
     design = designer or (lambda nn, ff: mbfir.fir_ap_cvx(nn, ff, a, d, QP_LAMBDA, opts=opts))
@@ -170,6 +168,8 @@ def fir_qp(n, f, a, d, min_order=0, min_tran=0, min_peak=0, dbg=0, *, opts=None,
         n_new = int(math.ceil(n * (1 - min_order) + n_top * min_order))
         h, status = design(n_new, f)
         note("n_final", n_new, status)
+    if min_peak and len(h):                                                           # fir_qp.m:139-151
+        h = mbfir.fir_flip_zero(h, dbg)
     return h, status
 
 

@@ -123,8 +123,11 @@ def test_dzrf_mb_filter_types_and_options():
         mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_cvx", "N-15")
     with pytest.raises(ValueError):
         mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_cvx", "C-13", 0, 3)
-    with pytest.raises(NotImplementedError):
-        mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_cvx", "C-13", 1)
+    # flip_zero = 1: pass-band zeros reflected for a lower peak of beta, same |B(w)| -- the profile still meets the spec
+    rf0, b0, _, _ = mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_minorder_cvx", "C-13", 0, 1, None, 0, 58)
+    rf1, b1, rf_spec, _ = mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_minorder_cvx", "C-13", 1, 1, None, 0, 58)
+    assert len(b1) == 58 and np.max(np.abs(b1)) <= np.max(np.abs(b0)) * (1 + 1e-9)
+    check_profile(rf1, 0.04, 1.0705, rf_spec, slack=1.15)
     rf_pulse, b, rf_spec, b_spec = mbfir.dzrf_mb(100, 0.04, cf, rng, FA, rp, "ex", "ap_minorder_cvx", "C-13", 0, 1, None, 0, 40)
     assert len(rf_pulse) == 0 and len(b) == 0 and len(rf_spec["d"]) == 5      # 40 taps: 'Filter design failed.'
 

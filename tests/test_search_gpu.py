@@ -47,8 +47,8 @@ def test_argument_errors_and_tight_spec():
         mbfir.fir_ap(100, f, a, d, 1e-3, 0, 2)
     with pytest.raises(ValueError, match="invalid input of min_order"):
         mbfir.fir_ap(100, f, a, d, 1e-3, -1, 0)
-    with pytest.raises(NotImplementedError):
-        mbfir.fir_ap(100, f, a, d, 1e-3, 0, 0, 1)
+    h0, s0, _, _ = mbfir.fir_ap(100, f, a, d, 1e-3, 0, 0, 1)   # no search: early return, min_peak not applied (fir_ap.m:55-59)
+    assert s0 == "Solved" and len(h0) == 100
     with pytest.raises(ValueError, match="original parameters are too tight"):
         mbfir.fir_ap(40, f, a, d, 1e-3, 1, 0)           # infeasible at 40 taps (fir_ap.m:52-54)
 
