@@ -43,7 +43,7 @@ for case in range(ncase):
     else: args = (n, f, a * np.exp(1j * rng.uniform(-0.3, 0.3, 2 * k).round(1).repeat(1)), d.astype(complex))
     if which == "fir_qprog_phs":                    # phase constant inside a band
         ph = np.repeat(np.exp(1j * rng.uniform(-0.3, 0.3, k)), 2)
-        args = (n, f, a * ph, d.astype(complex))
+        args = (n, f, a * ph, np.where(amp > 0, d * np.exp(0.3j), d.astype(complex)))   # pass bands need a phase ripple
     res = []
     for dense in (0, 1):
         try:
