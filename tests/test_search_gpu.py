@@ -112,3 +112,17 @@ def test_lattice_numerical_failure_is_retried_on_the_dense_path():
     ho, so = designers.fir_ap_cvx(20, f, a, d, 1e5)
     assert s == so == "Solved" and i["lattice"] == 0 and i["relgap"] <= 1e-8
     assert relinf(h, ho) <= 1e-6
+
+
+def test_dense_retry_inside_a_batch():
+    """The retry runs per job inside mbfir_solve_batch's worker threads (own context, own arena)."""
+    from oracle import designers
+    f, a, d = [-0.25, 0.25, 0.45, 1.0], [0.15, 0.15, 0, 0], [0.004, 0.002]
+    jobs = [("fir_ap_cvx", (20, f, a, d, 1e5, 1e-3)), ("fir_ap_cvx", (24, f, a, d, 0.1, 1e-2)), ("fir_ap_cvx", (20, f, a, d, 1e5, 1e-3)),
+            ("fir_linprog", (33, [0, 0.25, 0.45, 1], [1, 1, 0, 0], [0.02, 0.02])), ("fir_ap_cvx", (20, f, a, d, 1e5, 1e-3))]
+    res = mbfir.solve_batch(jobs, streams=4, info=True)
+    ho, so = designers.fir_ap_cvx(20, f, a, d, 1e5, 1e-3)
+    for k in (0, 2, 4):
+        h, s, i = res[k]
+        assert s == so == "Solved" and i["lattice"] == 0 and relinf(h, ho) <= 1e-6
+    assert res[1][1] == "Solved" and res[1][2]["lattice"] == 1 and res[3][1] == "Solved"
