@@ -93,7 +93,10 @@ typedef struct mbfir_info {
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to
  * `count` doubles on the context's stream-ordered memory; op 0 = sum, 1 = max.  The hook must
  * return after the reduction is complete and visible to the device (0 = ok).  The Python host
- * wires this to torch.distributed (RCCL over xGMI). */
+ * wires this to torch.distributed (RCCL over xGMI).  What goes through it per IPM iteration: the
+ * trigonometric moments of the normal matrix (~100 KB; dense_trig: the np x np normal matrix itself),
+ * every G'v and preconditioner application (N doubles each) and a few scalars -- all ranks make the
+ * same sequence of calls. */
 typedef int (*mbfir_allreduce_fn)(void* buf, long count, int op, void* user);
 
 mbfir_ctx*  mbfir_create(int device_id);

@@ -1325,6 +1325,11 @@ __device__ __forceinline__ double lat_T(const DProg& P, const double* __restrict
     }
     return 0.5 * v * P.col_scale[j] * P.col_scale[k];
 }
+// mode 1: slot = flag (rank 0), mode 0: slot = 0 (the others), mode 2: flag = slot after the all-reduce
+__global__ void k_flag_share(int* flag, double* slot, int mode) {
+    if (mode == 2) flag[0] = int(slot[0] + 0.5);
+    else slot[0] = mode == 1 ? double(flag[0]) : 0.0;
+}
 __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const double* __restrict__ MomB,
                                  double* __restrict__ H, double pad_diag) {
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
@@ -1388,8 +1393,9 @@ __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const doubl
     }
 }
 // y-y block: sum over rows with a non-zero ey (LP rows and Q3 cones); one block
+// out[(base + e) * ld + base + f] += ... : (H, np, Nt), or a 3 x 3 scratch (ld 3, base 0) that the lead-factor mode all-reduces
 __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                              double* __restrict__ H) {
+                                              double* __restrict__ H, long ld, long base) {
     __shared__ double sh[17];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
@@ -1411,8 +1417,12 @@ __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict_
     for (int e = 0; e < P.Ne; ++e)
         for (int f = 0; f < P.Ne; ++f) {
             double t = block_sum(acc[3 * e + f], sh);
-            if (threadIdx.x == 0) H[(long)(P.Nt + e) * P.np + P.Nt + f] += t;
+            if (threadIdx.x == 0) H[(base + e) * ld + base + f] += t;
         }
+}
+__global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
+    const int e = threadIdx.x / 3, f = threadIdx.x % 3;
+    if (threadIdx.x < 9 && e < P.Ne && f < P.Ne) H[(long)(P.Nt + e) * P.np + P.Nt + f] += yy[3 * e + f];
 }
 // big cone: q = G_b'(J wbar)  then  H += eta^-2 (2 q q' - G_b' J G_b)
 __global__ void k_big_q(DProg P, const double* __restrict__ wbb, double* __restrict__ qv, double* __restrict__ qd) {
@@ -1705,10 +1715,22 @@ struct Solver::Impl {
         hipLaunchKernelGGL(k_winv2<NV>, dim3(cdiv(P.l + P.nq3, 256)), dim3(256), 0, st, P, dl, w3, in, sub, out, mode);
         if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, in, sub, out, mode);
     }
+    // Row-sharded solves on the lattice path: the normal matrix is a linear function of ~100 KB of trigonometric
+    // moments, so the ranks all-reduce the MOMENTS, rank 0 alone assembles and factorises H (it also owns every
+    // non-frequency row) and shares each preconditioner application M'(M b) -- N doubles -- instead of every rank
+    // receiving H (np^2 doubles) and repeating the factorisation.  The other ranks wait in the collective meanwhile.
+    bool lead_factor() const { return shard_size > 1 && P.trig; }
+    // out = M' M (rhs + rhs2)
     template <int NV>
-    void hsolve(const double* rhs, double* out) {
-        trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st);
-        trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
+    void hsolve(const double* rhs, double* out, const double* rhs2 = nullptr) {
+        if (!lead_factor() || shard_rank == 0) {
+            trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2);
+            trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
+        }
+        if (lead_factor()) {
+            if (shard_rank != 0) hipMemsetAsync(out, 0, sizeof(double) * NV * P.LDV, st);
+            allreduce(out, (long)NV * P.LDV, 0);
+        }
     }
     // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  The Cholesky solve is refined by `nsweep`
     // iterations of preconditioned CG on (G' W^-2 G) dx = rhs with the operator applied exactly
@@ -1722,8 +1744,7 @@ struct Solver::Impl {
         if (!wbz_ready) winv2<NV>(bz, nullptr, wbz, 0);
         else if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
-        trigemv_launch(M, P.np, 0, bx, yN, NV, P.LDV, st, tmpN);                            // M (bx + G' W^-2 bz)
-        trigemv_launch(Mt, P.np, 1, yN, dx, NV, P.LDV, st);
+        hsolve<NV>(bx, dx, tmpN);                                                           // M'M (bx + G' W^-2 bz)
         apply_G_winv2<NV>(dx, gdx, wbz, dz);
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
@@ -1772,7 +1793,16 @@ struct Solver::Impl {
                 moments_array(nwv, Dw, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
                 if (P.Ne > 0) moments_array(nvb, BB, P.seed_tau, P.D1, 0, MomB);
             }
-            hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
+            if (lead_factor()) {
+                if (momb == MomB) {
+                    allreduce(Mom, 2L * nwv * P.LDM, 0);
+                    if (P.Ne > 0) allreduce(MomB, 2L * nvb * P.LDM, 0);
+                } else {
+                    allreduce(Mom, 2L * (nwv + nvb) * P.LDM, 0);
+                }
+            }
+            if (!lead_factor() || shard_rank == 0)
+                hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
         } else {
         gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
@@ -1783,16 +1813,37 @@ struct Solver::Impl {
         }
         hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         }
-        hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
-        if (P.Ne > 0 && P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H);
-        if (P.big) {
-            hipMemsetAsync(qv, 0, sizeof(double) * 2 * P.LDV, st);
-            hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
-            hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+        const bool mine = !lead_factor() || shard_rank == 0;     // lead mode: only rank 0 holds H
+        if (lead_factor() && P.Ne > 0) {
+            // the y-y block also gets terms from frequency rows (rho, delta columns), which live on every rank
+            hipMemsetAsync(RB, 0, sizeof(double) * 9, st);
+            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, RB, 3L, 0L);
+            allreduce(RB, 9, 0);
+            if (mine) hipLaunchKernelGGL(k_H_yy_add, dim3(1), dim3(16), 0, st, P, RB, H);
         }
-        allreduce(H, (long)P.np * P.np, 0);               // sum the shards' normal matrices
+        if (mine) {
+            hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
+            if (!lead_factor() && P.Ne > 0 && P.nyrows > 0)
+                hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H, (long)P.np, (long)P.Nt);
+            if (P.big) {
+                hipMemsetAsync(qv, 0, sizeof(double) * 2 * P.LDV, st);
+                hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
+                hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+            }
+        }
+        if (!lead_factor()) allreduce(H, (long)P.np * P.np, 0);   // dense path: sum the shards' normal matrices
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
-        chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1);
+        if (mine) {
+            chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1);
+        } else {
+            if (c0) hipEventRecord(c0, st);
+            if (c1) hipEventRecord(c1, st);
+        }
+        if (lead_factor()) {                                      // everybody needs the pivot-replacement count (wall exit)
+            hipLaunchKernelGGL(k_flag_share, dim3(1), dim3(1), 0, st, flag, RB + 9, shard_rank == 0 ? 1 : 0);
+            allreduce(RB + 9, 1, 0);
+            hipLaunchKernelGGL(k_flag_share, dim3(1), dim3(1), 0, st, flag, RB + 9, 2);
+        }
     }
     // events are recorded as (gram begin, gram end, chol begin, chol end) per build_H
     void collect_times(double& gram_ms, double& chol_ms, int& builds) {

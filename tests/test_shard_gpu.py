@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 warnings.filterwarnings("ignore", category=RuntimeWarning)
 
 
-def _run_sharded(fn, args, size):
+def _run_sharded(fn, args, size, dense=0):
     import torch
     torch.zeros(1, device="cuda")                   # initialise torch's HIP context on the main thread
     ctxs = [mbfir.Context(0) for _ in range(size)]
@@ -46,7 +46,7 @@ def _run_sharded(fn, args, size):
 
     def work(rank):
         ctxs[rank].set_allreduce(make_hook(rank))
-        opts = mbfir.make_opts(shard_rank=rank, shard_size=size)
+        opts = mbfir.make_opts(shard_rank=rank, shard_size=size, dense_trig=dense)
         try:
             results[rank] = getattr(mbfir, fn)(*args, opts=opts, ctx=ctxs[rank], info=True)
         except Exception as e:                      # noqa: BLE001
@@ -78,4 +78,18 @@ def test_row_sharded_solve_matches_unsharded(name, size):
             assert abs(info["pcost"] - i0["pcost"]) <= 1e-8 * max(1.0, abs(i0["pcost"]))
             assert np.array_equal(h, res[0][0])      # every rank returns the same taps, bit for bit
     assert sum(i["n_freq"] for _, _, i in res) == i0["n_freq"]
+    assert all(abs(i["iters"] - i0["iters"]) <= 1 for _, _, i in res)     # same preconditioner quality as the unsharded solve
+
+
+@pytest.mark.parametrize("name", ["ap_c13_64", "qp_modelB25"])
+def test_row_sharded_dense_path_all_reduces_the_normal_matrix(name):
+    """opts.dense_trig = 1: no moments to share, the shards' Gram matrices are summed and every rank factorises."""
+    fn, args = CASES[name]
+    h0, s0, i0 = getattr(mbfir, fn)(*args, info=True)
+    res = _run_sharded(fn, args, 2, dense=1)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for h, s, info in res:
+        assert s == s0 == "Solved" and info["lattice"] == 0 and relinf(h, h0) <= 1e-6
+        assert np.array_equal(h, res[0][0])
     assert sum(i["n_rows"] for _, _, i in res) == i0["n_rows"]
