@@ -114,9 +114,23 @@ def main():
     ctxs = [mbfir.Context(local_rank) for _ in range(nstream)]
     ctx = ctxs[0]
     if shard:
-        # ONE design, its frequency rows split over the ranks; per iteration RCCL all-reduces the
-        # normal matrix, every G'v and the step / residual scalars (mbfir_set_allreduce hook)
-        ctx.set_allreduce(mbfir.make_torch_allreduce())
+        # ONE design, its frequency rows split over the ranks; per iteration RCCL all-reduces the moments of the
+        # normal matrix (dense path: the matrix), every G'v / preconditioner application and the step / residual
+        # scalars (mbfir_set_allreduce hook)
+        if args.backend == "nccl":
+            ctx.set_allreduce(mbfir.make_torch_allreduce())
+        else:                                            # gloo rehearsal: stage the device buffer through the host
+            import torch
+
+            def hook(ptr, count, op, _t=torch):
+                import torch.distributed as dist
+                t = mbfir.device_tensor(ptr, count)
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+                t.copy_(c)
+                _t.cuda.synchronize()
+                return 0
+            ctx.set_allreduce(hook)
         opts = mbfir.make_opts(grid_m=args.grid_m, shard_rank=rank, shard_size=world, dense_trig=int(args.dense))
     else:
         opts = mbfir.make_opts(grid_m=args.grid_m, dense_trig=int(args.dense))
