@@ -28,7 +28,7 @@ bad = 0
 t0 = time.time()
 for case in range(ncase):
     which = ["fir_ap_cvx", "fir_qp_cvx", "fir_linprog", "fir_qprog_phs"][case % 4]
-    n = int(rng.integers(24, 140))
+    n = int(rng.integers(int(sys.argv[3]) if len(sys.argv) > 3 else 24, int(sys.argv[4]) if len(sys.argv) > 4 else 140))
     if which == "fir_linprog" and rng.random() < 0.5:
         f, k = random_bands(0.0, 1.0, 4)            # real filter
     else:
