@@ -101,3 +101,20 @@ def test_rf_mrange_desired():
         mbfir.rf_mrange_desired(200, 0.01, "ex")
     with pytest.raises(ValueError):
         mbfir.rf_mrange_desired(20, 0.01, "xx")
+
+
+def test_dzrf_mb_argument_errors_need_no_gpu():
+    """dzrf_mb.m:56-98,136-157: the checks that run before any design."""
+    cf = [[-1.0], [1.5]]
+    with pytest.raises(ValueError, match="nucleus"):
+        mbfir.dzrf_mb(128, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ap_cvx", "N-15")
+    with pytest.raises(ValueError, match="not an integer"):
+        mbfir.dzrf_mb(127, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ap_cvx", "H-1", 0, 2)
+    with pytest.raises(ValueError, match="shift_f"):
+        mbfir.dzrf_mb(128, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ap_cvx", "H-1", 0, 1, None, 0, None, None, 3)
+    with pytest.raises(NameError, match="TBW"):
+        mbfir.dzrf_mb(128, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ms", "H-1")
+    with pytest.raises(ValueError, match="sampling rate"):
+        mbfir.dzrf_mb(128, 0.5, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ap_cvx", "H-1")      # fs/2 = 1 kHz < 1.7 kHz
+    with pytest.raises(ValueError, match="broken in the reference"):
+        mbfir.dzrf_mb(128, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "st", "ap_cvx", "H-1")
