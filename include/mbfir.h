@@ -56,14 +56,16 @@ typedef struct mbfir_opts {
     double feastol;    /* 0 -> 1e-8  relative primal/dual residual                              */
     double abstol;     /* 0 -> 1e-10 absolute gap                                               */
     double reltol;     /* 0 -> 1e-8  relative gap                                               */
-    int refine;        /* -1 -> 2  iterative-refinement sweeps per KKT solve                    */
+    int refine;        /* -1 -> 2  iterative-refinement sweeps per KKT solve; values above 8 are clamped to 8 */
     int verbose;       /* 1: one line per IPM iteration on stderr                               */
     int shard_rank;    /* frequency-row sharding (multi-GPU): this process's rank ...           */
     int shard_size;    /* ... out of shard_size (0 or 1 = not sharded)                          */
     int dense_trig;    /* 0: use the lattice structure of the trig columns / frequency grid when it
                           is there (no trig matrix, moments instead of the dense Gram products);
                           1: always materialise the trig matrix and use the dense MFMA Gram kernel */
-    int reserved_;
+    int ddkkt;         /* extended-precision (double-double) KKT solve for nearly active cones whose NT weights
+                          exceed 1e6 x the typical weight (fir_qp_cvx's error cones):
+                          0 = automatic (on for mbfir_qp_solve, off for the other designers), 1 = on, -1 = off */
 } mbfir_opts;
 
 /* Per-solve report. */
@@ -88,6 +90,8 @@ typedef struct mbfir_info {
     double chol_flop;    /* flop of one factorisation + triangular inverse: 2/3 np^3                      */
     int chol_launches;   /* k_chol_step launches behind ms_chol (= builds * (np/64 + 1))                  */
     int builds;          /* normal-matrix builds (= iterations + 1)                                       */
+    int dd_iters;        /* iterations that ran the extended-precision KKT solve (opts.ddkkt)              */
+    int dd_kmax;         /* largest number of strong eigen-directions it carried                          */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to
@@ -204,6 +208,11 @@ int mbfir_abr(mbfir_ctx* ctx, int n, const double* rf_re, const double* rf_im, c
 int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, const double* d, double* out);
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m);
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im);
+/*  mbfir_test_ddsolve: x = (H + U' diag(X) U)^-1 b through the double-double kernels of the extended-precision
+ *     KKT solve; H n x n, U k x n (row-major), b and x as (hi, lo) pairs of nrhs x n arrays, nrhs <= 2;
+ *     nfix receives the number of replaced pivots; Lh / Ll (optional, n x n) the Cholesky factor.            */
+int mbfir_test_ddsolve(mbfir_ctx* ctx, int n, int k, const double* H, const double* U, const double* X, int nrhs,
+                       const double* bh, const double* bl, double* xh, double* xl, int* nfix, double* Lh, double* Ll);
 int mbfir_test_mfma_peak(mbfir_ctx* ctx, double* tflops_f64_mfma, double* tflops_f64_valu);
 /* Device time (ms per call, HIP events, averaged over reps) of the Cholesky+inverse phase on a random SPD
  * n x n matrix, and of the Gram launches on a random m x nt matrix -- kernel tuning aid. */

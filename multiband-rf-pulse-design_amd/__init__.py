@@ -38,7 +38,7 @@ class Opts(C.Structure):
     _fields_ = [("grid_m", C.c_int), ("max_iter", C.c_int), ("feastol", C.c_double),
                 ("abstol", C.c_double), ("reltol", C.c_double), ("refine", C.c_int),
                 ("verbose", C.c_int), ("shard_rank", C.c_int), ("shard_size", C.c_int),
-                ("dense_trig", C.c_int), ("reserved_", C.c_int)]
+                ("dense_trig", C.c_int), ("ddkkt", C.c_int)]
 
 
 class Info(C.Structure):
@@ -50,7 +50,8 @@ class Info(C.Structure):
                 ("ms_assemble", C.c_double), ("ms_solve", C.c_double), ("ms_post", C.c_double),
                 ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
                 ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("lattice", C.c_int),
-                ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int)]
+                ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int),
+                ("dd_iters", C.c_int), ("dd_kmax", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -102,6 +103,7 @@ SYMBOLS = {
     "mbfir_test_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_specfact": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_ddsolve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp]),
     "mbfir_test_mfma_peak": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mbfir_test_time_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
 }
@@ -559,6 +561,26 @@ def test_chol(H, ctx=None):
     L, M = np.zeros((n, n)), np.zeros((n, n))
     _check(ctx, load_library().mbfir_test_chol(ctx._h, n, _ptr(H), _ptr(L), _ptr(M)))
     return L, M
+
+
+def test_ddsolve(H, U, X, bh, bl, ctx=None, factor=False):
+    """(H + U' diag(X) U)^-1 b through the device's double-double kernels; b, x: (nrhs, n) hi / lo parts.
+    factor=True also returns the Cholesky factor (hi, lo)."""
+    ctx = ctx or get_context()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, H.shape[0])
+    X = _vec(X)
+    bh = np.ascontiguousarray(np.atleast_2d(bh), dtype=np.float64)
+    bl = np.ascontiguousarray(np.atleast_2d(bl), dtype=np.float64)
+    xh, xl = np.zeros_like(bh), np.zeros_like(bh)
+    nfix = C.c_int(0)
+    Lh, Ll = (np.zeros_like(H), np.zeros_like(H)) if factor else (None, None)
+    _check(ctx, load_library().mbfir_test_ddsolve(ctx._h, H.shape[0], U.shape[0], _ptr(H), _ptr(U), _ptr(X), bh.shape[0],
+                                                  _ptr(bh), _ptr(bl), _ptr(xh), _ptr(xl), C.byref(nfix),
+                                                  _ptr(Lh) if factor else None, _ptr(Ll) if factor else None))
+    if factor:
+        return xh, xl, nfix.value, np.tril(Lh), np.tril(Ll)
+    return xh, xl, nfix.value
 
 
 def test_specfact(x, n, ctx=None):

@@ -28,14 +28,20 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-SolveOpts to_opts(const mbfir_opts* o) {
+constexpr double DDKKT_THETA = 1e6;       // oracle/designers.py uses the same value
+
+// which: the designer (DES_*): the extended-precision KKT solve is on by default for fir_qp_cvx only
+SolveOpts to_opts(const mbfir_opts* o, int which) {
     SolveOpts s;
+    s.ddkkt_theta = which == DES_QP ? DDKKT_THETA : 0.0;
     if (!o) return s;
+    if (o->ddkkt > 0) s.ddkkt_theta = DDKKT_THETA;
+    if (o->ddkkt < 0) s.ddkkt_theta = 0.0;
     if (o->max_iter > 0) s.max_iter = o->max_iter;
     if (o->feastol > 0) s.feastol = o->feastol;
     if (o->abstol > 0) s.abstol = o->abstol;
     if (o->reltol > 0) s.reltol = o->reltol;
-    if (o->refine >= 0) s.refine = o->refine;
+    if (o->refine >= 0) s.refine = o->refine > 8 ? 8 : o->refine;   // MAX_SWEEPS of solver.hip: the norm slots hold 9 values
     s.verbose = o->verbose;
     s.shard_rank = o->shard_rank;
     s.shard_size = o->shard_size;
@@ -68,6 +74,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->gram_launches = si.lattice ? 0 : si.h_builds * (P.quad ? 3 : 1);
     info->lattice = si.lattice;
     info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
+    info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax;
 }
 
 // Common driver: `asm_rc` is the assembly result, `post` maps the solution vector to taps.
@@ -89,7 +96,7 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         double t_asm = now_ms();
         SolveInfo si;
         std::vector<double> x;
-        SolveOpts so = to_opts(opts);
+        SolveOpts so = to_opts(opts, P.which);
         int st = ctx->solver->solve(P, so, x, si);
         // The lattice path forms the normal matrix from trigonometric moments; its rounding noise (recurrences,
         // ~1e-14 relative) is above that of the dense Gram products, so on programs that end near cond(H) ~ 1e14
@@ -102,7 +109,7 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
             st = ctx->solver->solve(P, so, x, si);
             si.ms_assemble += first.ms_assemble; si.ms_solve += first.ms_solve; si.ms_chol += first.ms_chol;
             si.ms_gram += first.ms_gram; si.h_builds += first.h_builds; si.chol_launches += first.chol_launches;
-            si.chol_flop += first.chol_flop; si.iters += first.iters;
+            si.chol_flop += first.chol_flop; si.iters += first.iters; si.dd_iters += first.dd_iters;
         }
         ctx->last_x = x;
         double t_solved = now_ms();
@@ -284,6 +291,11 @@ int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, cons
 }
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m) {
     MBFIR_TRY(ctx, ctx->solver->test_chol(n, H, out_l, out_m));
+}
+int mbfir_test_ddsolve(mbfir_ctx* ctx, int n, int k, const double* H, const double* U, const double* X, int nrhs,
+                       const double* bh, const double* bl, double* xh, double* xl, int* nfix, double* Lh, double* Ll) {
+    if (!ctx || n < 1 || k < 0 || nrhs < 1 || nrhs > 2 || !H || !bh || !bl || !xh || !xl || !nfix) return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->test_ddsolve(n, k, H, U, X, nrhs, bh, bl, xh, xl, nfix, Lh, Ll));
 }
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im) {
     MBFIR_TRY(ctx, ctx->solver->test_specfact(n, x, h_re, h_im));

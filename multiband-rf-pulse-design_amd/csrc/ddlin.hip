@@ -1,0 +1,336 @@
+// Double-double dense kernels of the extended-precision KKT solve (see ddkkt in solver.hip):
+//   k_dd_syrk        H (dd) = H_w (double) + sum_r X_r u_r u_r'      -- the strongly weighted rows
+//   k_ddchol_*       blocked right-looking Cholesky of H in dd (32-wide panels), L and L' kept
+//   k_dd_trsv        (L L')^-1 b for 1 or 2 right-hand sides in dd
+// The strongly active second-order cones of fir_qp_cvx (fir_qp_cvx.m:145-166) carry NT weights up to 1e16
+// times the median weight; in double precision the weakly weighted directions of G' W^-2 G drown in the
+// rounding of the strong ones.  With the strong rank-one terms accumulated, and the
+// sum factorised, in dd they survive.  Everything here is fp64 VALU work with error-free transformations:
+// there is no matrix-core path for dd.
+#include "dev_common.h"
+#include "dd_dev.h"
+#include "solver.h"
+
+#pragma clang fp contract(off)
+
+namespace mbfir {
+
+constexpr int DNB = 32;          // panel width of the dd Cholesky
+constexpr int DT = 64;           // output tile of the dd rank-k kernels
+
+// ------------------------------------------------------------------------------------------------
+// H(dd, lower-triangle tiles) = Hh (as given, double) + sum_{r < *kcount} X[r] U[r][i] U[r][j]
+__global__ __launch_bounds__(256) void k_dd_syrk(const double* __restrict__ U, int ldu, const double* __restrict__ X,
+                                                 const int* __restrict__ kcount, int np, double* __restrict__ Hh,
+                                                 double* __restrict__ Hl) {
+    __shared__ double ui[8][DT], uj[8][DT], xs[8];
+    // linear block index -> (bi >= bj)
+    int bi = int((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+    while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+    const int bj = blockIdx.x - bi * (bi + 1) / 2;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = bi * DT + ty * 4, j0 = bj * DT + tx * 4;
+    dd acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], 0.0);
+    const int k = *kcount;
+    for (int r0 = 0; r0 < k; r0 += 8) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 8 * DT; e += 256) {
+            const int q = e / DT, c = e - q * DT, r = r0 + q;
+            ui[q][c] = r < k ? U[(long)r * ldu + bi * DT + c] : 0.0;
+            uj[q][c] = r < k ? U[(long)r * ldu + bj * DT + c] : 0.0;
+        }
+        if (threadIdx.x < 8) xs[threadIdx.x] = r0 + threadIdx.x < k ? X[r0 + threadIdx.x] : 0.0;
+        __syncthreads();
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q) {
+            const double x = xs[q];
+            dd ax[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ax[p] = two_prod(ui[q][ty * 4 + p], x);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double b = uj[q][tx * 4 + s];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p][s] = dd_add(acc[p][s], dd_mul_d(ax[p], b));
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Hh[(long)(i0 + p) * np + j0 + s] = acc[p][s].h;
+            Hl[(long)(i0 + p) * np + j0 + s] = acc[p][s].l;
+        }
+}
+
+__global__ void k_dd_diag_copy(const double* __restrict__ Hh, int np, double* __restrict__ d0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) d0[i] = Hh[(long)i * np + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cholesky, panel step k0: (1) factorise the 32 x 32 diagonal block in one workgroup
+// pivot rule of oracle/ddlin.c dd_chol: a pivot not above pivtol * d0 is replaced by d0 (counted in flag[0])
+__global__ __launch_bounds__(256) void k_ddchol_diag(double* __restrict__ Hh, double* __restrict__ Hl,
+                                                     double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
+                                                     const double* __restrict__ d0, double pivtol, int* __restrict__ flag,
+                                                     double* __restrict__ rih, double* __restrict__ ril) {
+    __shared__ double Dh[DNB][DNB + 1], Dl[DNB][DNB + 1];
+    __shared__ double rh[DNB], rl[DNB];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DNB * DNB; e += 256) {
+        const int i = e / DNB, c = e - i * DNB;
+        const bool lo = c <= i;
+        Dh[i][c] = lo ? Hh[(long)(k0 + i) * np + k0 + c] : 0.0;
+        Dl[i][c] = lo ? Hl[(long)(k0 + i) * np + k0 + c] : 0.0;
+    }
+    for (int j = 0; j < DNB; ++j) {
+        __syncthreads();
+        if (tid == 0) {
+            dd p = dd_make(Dh[j][j], Dl[j][j]);
+            const double dj = d0[k0 + j];
+            if (!(p.h > pivtol * dj)) {
+                p = dd_make(dj > 1e-300 ? dj : 1e-300, 0.0);
+                atomicAdd(flag, 1);
+            }
+            const dd r = dd_sqrt(p);
+            Dh[j][j] = r.h; Dl[j][j] = r.l;
+            const dd ri = dd_div(dd_make(1.0), r);
+            rh[j] = ri.h; rl[j] = ri.l;
+        }
+        __syncthreads();
+        if (tid > j && tid < DNB) {
+            const dd v = dd_mul(dd_make(Dh[tid][j], Dl[tid][j]), dd_make(rh[j], rl[j]));
+            Dh[tid][j] = v.h; Dl[tid][j] = v.l;
+        }
+        __syncthreads();
+        for (int e = tid; e < DNB * DNB; e += 256) {
+            const int i = e / DNB, c = e - i * DNB;
+            if (c > j && i >= c) {
+                const dd v = dd_fnma(dd_make(Dh[i][c], Dl[i][c]), dd_make(Dh[i][j], Dl[i][j]), dd_make(Dh[c][j], Dl[c][j]));
+                Dh[i][c] = v.h; Dl[i][c] = v.l;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < DNB * DNB; e += 256) {
+        const int i = e / DNB, c = e - i * DNB;
+        if (c <= i) {
+            Hh[(long)(k0 + i) * np + k0 + c] = Dh[i][c]; Hl[(long)(k0 + i) * np + k0 + c] = Dl[i][c];
+            Lth[(long)(k0 + c) * np + k0 + i] = Dh[i][c]; Ltl[(long)(k0 + c) * np + k0 + i] = Dl[i][c];
+        }
+    }
+    if (tid < DNB) { rih[k0 + tid] = rh[tid]; ril[k0 + tid] = rl[tid]; }
+}
+
+// (2) panel rows below the diagonal block: X D' = A by forward substitution, one thread per row, the row and
+// the diagonal block in LDS
+__global__ __launch_bounds__(64) void k_ddchol_trsm(double* __restrict__ Hh, double* __restrict__ Hl,
+                                                    double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
+                                                    const double* __restrict__ rih, const double* __restrict__ ril) {
+    __shared__ double Dh[DNB][DNB], Dl[DNB][DNB];
+    __shared__ double ah[DNB][65], al[DNB][65];
+    __shared__ double rh[DNB], rl[DNB];
+    const int tid = threadIdx.x, i = k0 + DNB + blockIdx.x * 64 + tid;
+    for (int e = tid; e < DNB * DNB; e += 64) {
+        const int r = e / DNB, c = e - r * DNB;
+        Dh[r][c] = Hh[(long)(k0 + r) * np + k0 + c];
+        Dl[r][c] = Hl[(long)(k0 + r) * np + k0 + c];
+    }
+    if (tid < DNB) { rh[tid] = rih[k0 + tid]; rl[tid] = ril[k0 + tid]; }
+    const bool live = i < np;
+    for (int c = 0; c < DNB; ++c) {
+        ah[c][tid] = live ? Hh[(long)i * np + k0 + c] : 0.0;
+        al[c][tid] = live ? Hl[(long)i * np + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int c = 0; c < DNB; ++c) {
+        dd v = dd_make(ah[c][tid], al[c][tid]);
+        for (int q = 0; q < c; ++q) v = dd_fnma(v, dd_make(ah[q][tid], al[q][tid]), dd_make(Dh[c][q], Dl[c][q]));
+        v = dd_mul(v, dd_make(rh[c], rl[c]));
+        ah[c][tid] = v.h; al[c][tid] = v.l;
+    }
+    for (int c = 0; c < DNB; ++c) {
+        Hh[(long)i * np + k0 + c] = ah[c][tid]; Hl[(long)i * np + k0 + c] = al[c][tid];
+        Lth[(long)(k0 + c) * np + i] = ah[c][tid]; Ltl[(long)(k0 + c) * np + i] = al[c][tid];
+    }
+}
+
+// (3) trailing update A[i][j] -= sum_c L[i][k0+c] L[j][k0+c] for i >= j >= k0 + 32, lower-triangle 64 x 64 tiles
+// on the global 64-grid (entries of a tile above k1 = k0 + 32 are skipped)
+constexpr int UPD_LD = DT + 1;                                // panel staged as [column][row], conflict-free both ways
+constexpr size_t UPD_LDS = 4 * (size_t)DNB * UPD_LD * sizeof(double);
+__global__ __launch_bounds__(256) void k_ddchol_update(double* __restrict__ Hh, double* __restrict__ Hl, int np, int k0) {
+    extern __shared__ double upd_sm[];
+    double* Lih = upd_sm;
+    double* Lil = Lih + DNB * UPD_LD;
+    double* Ljh = Lil + DNB * UPD_LD;
+    double* Ljl = Ljh + DNB * UPD_LD;
+    const int k1 = k0 + DNB, b0 = k1 / DT;
+    int bi = int((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
+    while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
+    const int bj = blockIdx.x - bi * (bi + 1) / 2;
+    const int ti = (b0 + bi) * DT, tj = (b0 + bj) * DT;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (int e = threadIdx.x; e < DT * DNB; e += 256) {
+        const int r = e / DNB, c = e - r * DNB;
+        const bool vi = ti + r >= k1, vj = tj + r >= k1;
+        Lih[c * UPD_LD + r] = vi ? Hh[(long)(ti + r) * np + k0 + c] : 0.0;
+        Lil[c * UPD_LD + r] = vi ? Hl[(long)(ti + r) * np + k0 + c] : 0.0;
+        Ljh[c * UPD_LD + r] = vj ? Hh[(long)(tj + r) * np + k0 + c] : 0.0;
+        Ljl[c * UPD_LD + r] = vj ? Hl[(long)(tj + r) * np + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    const int i0 = ti + ty * 4, j0 = tj + tx * 4;
+    if (i0 + 3 < j0) return;                                  // 4 x 4 patch entirely above the diagonal
+    dd acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], Hl[(long)(i0 + p) * np + j0 + s]);
+    for (int c = 0; c < DNB; ++c) {
+        dd a[4], b[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p] = dd_make(Lih[c * UPD_LD + ty * 4 + p], Lil[c * UPD_LD + ty * 4 + p]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = dd_make(Ljh[c * UPD_LD + tx * 4 + s], Ljl[c * UPD_LD + tx * 4 + s]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[p][s] = dd_fnma(acc[p][s], a[p], b[s]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (i0 + p >= k1 && j0 + s >= k1 && i0 + p >= j0 + s) {
+                Hh[(long)(i0 + p) * np + j0 + s] = acc[p][s].h;
+                Hl[(long)(i0 + p) * np + j0 + s] = acc[p][s].l;
+            }
+}
+
+void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount, int np, double* Hh, double* Hl,
+                    hipStream_t st) {
+    const int nt = np / DT;
+    hipLaunchKernelGGL(k_dd_syrk, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, U, ldu, X, kcount, np, Hh, Hl);
+}
+
+// In-place lower Cholesky of the dd matrix (Hh, Hl) (np x np row-major, np a multiple of 64); on exit the lower
+// triangle holds L, (Lth, Ltl) hold L' (upper triangle, row-major), (rih, ril) the reciprocals of diag(L);
+// flag[0] counts replaced pivots; d0 is a work vector of np doubles.
+void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
+                    double pivtol, int* flag, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update), hipFuncAttributeMaxDynamicSharedMemorySize, int(UPD_LDS));
+        attr_set = true;
+    }
+    hipMemsetAsync(flag, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_dd_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, Hh, np, d0);
+    for (int k0 = 0; k0 < np; k0 += DNB) {
+        hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
+        const int rows = np - k0 - DNB;
+        if (rows <= 0) break;
+        hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 64)), dim3(64), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
+        const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
+        hipLaunchKernelGGL(k_ddchol_update, dim3(nt * (nt + 1) / 2), dim3(256), UPD_LDS, st, Hh, Hl, np, k0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B (NV right-hand sides, dd, stride ldv) <- (L L')^-1 B.  One workgroup; the right-hand sides live in LDS.
+// Forward sweep over 32-row blocks with L (rows), backward sweep with L' (rows of Lt): the diagonal block is
+// solved by one wave per right-hand side (lane = row, the solved unknown broadcast by shuffles), the rest of
+// the block column is applied by all threads.
+constexpr int DD_NP_MAX = 4608;
+template <int NV>
+__global__ __launch_bounds__(1024) void k_dd_trsv(const double* __restrict__ Lh, const double* __restrict__ Ll,
+                                                  const double* __restrict__ Lth, const double* __restrict__ Ltl,
+                                                  const double* __restrict__ rih, const double* __restrict__ ril, int np,
+                                                  double* __restrict__ Bh, double* __restrict__ Bl, int ldv) {
+    extern __shared__ double smem[];
+    double* yh = smem;                        // NV * np
+    double* yl = yh + (size_t)NV * np;        // NV * np
+    double* Dh = yl + (size_t)NV * np;        // 32 * 33
+    double* Dl = Dh + DNB * (DNB + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < NV * np; e += 1024) {
+        const int v = e / np, i = e - v * np;
+        yh[e] = Bh[(long)v * ldv + i]; yl[e] = Bl[(long)v * ldv + i];
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* Th = pass == 0 ? Lh : Lth;
+        const double* Tl = pass == 0 ? Ll : Ltl;
+        for (int bb = 0; bb < np / DNB; ++bb) {
+            const int b0 = pass == 0 ? bb * DNB : np - DNB - bb * DNB;
+            __syncthreads();
+            for (int e = tid; e < DNB * DNB; e += 1024) {
+                const int r = e / DNB, c = e - r * DNB;
+                Dh[r * (DNB + 1) + c] = Th[(long)(b0 + r) * np + b0 + c];
+                Dl[r * (DNB + 1) + c] = Tl[(long)(b0 + r) * np + b0 + c];
+            }
+            __syncthreads();
+            if (wv < NV && lane < DNB) {
+                dd y = dd_make(yh[wv * np + b0 + lane], yl[wv * np + b0 + lane]);
+                for (int s = 0; s < DNB; ++s) {
+                    const int q = pass == 0 ? s : DNB - 1 - s;           // forward: ascending, backward: descending
+                    const dd t = dd_mul(dd_shfl(y, q), dd_make(rih[b0 + q], ril[b0 + q]));
+                    if (lane == q) y = t;
+                    const bool pending = pass == 0 ? lane > q : lane < q;
+                    if (pending) y = dd_fnma(y, dd_make(Dh[lane * (DNB + 1) + q], Dl[lane * (DNB + 1) + q]), t);
+                }
+                yh[wv * np + b0 + lane] = y.h; yl[wv * np + b0 + lane] = y.l;
+            }
+            __syncthreads();
+            // rest of the block column: forward rows i >= b0 + 32 (row i of L, columns b0..b0+31),
+            // backward rows i < b0 (row i of L', columns b0..b0+31)
+            const int lo = pass == 0 ? b0 + DNB : 0, hi = pass == 0 ? np : b0;
+            for (int i = lo + tid; i < hi; i += 1024) {
+                dd acc[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] = dd_make(yh[v * np + i], yl[v * np + i]);
+                const double* th = Th + (long)i * np + b0;
+                const double* tl = Tl + (long)i * np + b0;
+                for (int c = 0; c < DNB; ++c) {
+                    const dd lv = dd_make(th[c], tl[c]);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] = dd_fnma(acc[v], lv, dd_make(yh[v * np + b0 + c], yl[v * np + b0 + c]));
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { yh[v * np + i] = acc[v].h; yl[v * np + i] = acc[v].l; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NV * np; e += 1024) {
+        const int v = e / np, i = e - v * np;
+        Bh[(long)v * ldv + i] = yh[e]; Bl[(long)v * ldv + i] = yl[e];
+    }
+}
+
+void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st) {
+    if (np > DD_NP_MAX) throw HipError("dd solve: matrix too large for the LDS-resident right-hand sides");
+    const size_t sh = (2 * (size_t)nv * np + 2 * DNB * (DNB + 1)) * sizeof(double);
+    if (nv == 1) {
+        static bool set1 = false;
+        if (!set1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set1 = true; }
+        hipLaunchKernelGGL(k_dd_trsv<1>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
+    } else if (nv == 2) {
+        static bool set2 = false;
+        if (!set2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set2 = true; }
+        hipLaunchKernelGGL(k_dd_trsv<2>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
+    } else {
+        throw HipError("dd solve: unsupported number of right-hand sides");
+    }
+}
+
+}  // namespace mbfir

@@ -93,6 +93,16 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
                     hipStream_t st, const double* b2 = nullptr);
 
+// Double-double dense kernels (ddlin.hip): H(dd) = Hh + sum_{r < *kcount} X[r] U[r] U[r]' on the lower-triangle
+// tiles; in-place dd Cholesky (L in the lower triangle of (Hh, Hl), L' in (Lth, Ltl), 1/diag(L) in (rih, ril),
+// flag[0] = replaced pivots, d0 = np doubles of work space); (L L')^-1 B for nv = 1 or 2 dd right-hand sides.
+void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount, int np, double* Hh, double* Hl,
+                    hipStream_t st);
+void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
+                    double pivtol, int* flag, hipStream_t st);
+void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st);
+
 // Spectral factorisation (fir_ap_cvx.m:185-186,264-304): x (2n-1) -> n taps (re, im interleaved
 // in hout[2n]).  work must hold 6*lp doubles, lp = 8*2^ceil(log2(2n-1)).
 int specfact_lp(int n);

@@ -15,6 +15,7 @@ struct SolveOpts {
     int verbose = 0;
     int shard_rank = 0, shard_size = 1;     // frequency-row sharding (one process per GPU)
     bool dense_trig = false; // keep the materialised trig matrix and the dense MFMA Gram even when the lattice structure is there
+    double ddkkt_theta = 0; // > 0: extended-precision (double-double) KKT solve for every NT weight above theta x the typical weight
     bool timing = true;     // HIP-event timing of the k_gram launches and the Cholesky phase (events read at the end)
 };
 
@@ -25,6 +26,7 @@ struct SolveInfo {
     int h_builds = 0;       // number of (Gram, Cholesky) builds = iterations + 1 (initial point)
     int chol_launches = 0;  // k_chol_step launches timed in ms_chol
     double chol_flop = 0;   // factorisation + triangular inverse, per build
+    int dd_iters = 0, dd_kmax = 0;   // iterations that ran the extended-precision solve; largest strong set
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
 };
 
@@ -49,6 +51,8 @@ public:
     void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
     void test_chol(int n, const double* H, double* out_l, double* out_m);
     void test_specfact(int n, const double* x, double* h_re, double* h_im);
+    void test_ddsolve(int n, int k, const double* H, const double* U, const double* X, int nrhs, const double* bh,
+                      const double* bl, double* xh, double* xl, int* nfix, double* Lh_out = nullptr, double* Ll_out = nullptr);
     void test_mfma_peak(double* tf_mfma, double* tf_valu);
     void test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, double* ms_gram);
     void* stream() const;

@@ -23,6 +23,7 @@
 // One host synchronisation per iteration (termination test on 24 doubles).
 #include "dev_common.h"
 #include "cone_dev.h"
+#include "dd_dev.h"
 #include "program.h"
 #include "solver.h"
 #include <algorithm>
@@ -1242,8 +1243,13 @@ __global__ void k_update(DProg P, const double* __restrict__ Sc, const double* _
 // ------------------------------------------------------------------------------------------------
 // H assembly
 // per-frequency 2x2 weight block [D11 D12; D12 D22] and border vectors B1[e], B2[e]
+// m3c != null: the (capped, eigen-form) 3x3 blocks of the extended-precision solve replace soc3_inv2(w3)
+__device__ __forceinline__ void load_m3(const double* __restrict__ w3, const double* __restrict__ m3c, int c, double m[6]) {
+    if (m3c) { for (int q = 0; q < 6; ++q) m[q] = m3c[6L * c + q]; }
+    else soc3_inv2(load_w3(w3, c), m);
+}
 __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                              double* __restrict__ Dw, double* __restrict__ BB) {
+                              double* __restrict__ Dw, double* __restrict__ BB, const double* __restrict__ m3c) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.Mf) return;
     double d11 = 0, d12 = 0, d22 = 0, b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0};
@@ -1258,7 +1264,7 @@ __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const doub
             if (a != 1) continue;                       // a cone is handled once, at its first trig row
             int r0 = P.l + 3 * c;
             double m[6];
-            soc3_inv2(load_w3(w3, c), m);
+            load_m3(w3, m3c, c, m);
             double al[3] = {0, P.alpha[r0 + 1], P.alpha[r0 + 2]}, be[3] = {0, P.beta[r0 + 1], P.beta[r0 + 2]};
             for (int p = 1; p < 3; ++p)
                 for (int s = 1; s < 3; ++s) {
@@ -1360,7 +1366,7 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
 }
 // identity rows: thread j owns row j of H (and the mirrored border entries)
 __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                             double* __restrict__ H) {
+                             double* __restrict__ H, const double* __restrict__ m3c) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
     const long np = P.np;
@@ -1378,7 +1384,7 @@ __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const doubl
         } else if (r < P.l + 3 * P.nq3) {
             int c = (r - P.l) / 3, a = (r - P.l) - 3 * c, r0 = P.l + 3 * c;
             double m[6];
-            soc3_inv2(load_w3(w3, c), m);
+            load_m3(w3, m3c, c, m);
             for (int b = 0; b < 3; ++b) {
                 double mm = sym3(m, a, b);
                 int cb = P.col[r0 + b];
@@ -1395,7 +1401,7 @@ __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const doubl
 // y-y block: sum over rows with a non-zero ey (LP rows and Q3 cones); one block
 // out[(base + e) * ld + base + f] += ... : (H, np, Nt), or a 3 x 3 scratch (ld 3, base 0) that the lead-factor mode all-reduces
 __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                              double* __restrict__ H, long ld, long base) {
+                                              double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
     __shared__ double sh[17];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
@@ -1407,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict_
         } else if (r < P.l + 3 * P.nq3) {
             int c = (r - P.l) / 3, a = (r - P.l) - 3 * c, r0 = P.l + 3 * c;
             double m[6];
-            soc3_inv2(load_w3(w3, c), m);
+            load_m3(w3, m3c, c, m);
             for (int b = 0; b < 3; ++b)
                 for (int e = 0; e < P.Ne; ++e)
                     for (int f = 0; f < P.Ne; ++f)
@@ -1511,6 +1517,8 @@ __global__ void k_finish_x(DProg P, const double* __restrict__ x, const double* 
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < P.N) out[j] = x[j] / Sc[S_TAU];
 }
+#include "ddkkt.inc"
+
 // ================================================================================================
 // host driver
 // ================================================================================================
@@ -1623,6 +1631,12 @@ struct Solver::Impl {
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
     double *partR, *partR2, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
+    // extended-precision KKT solve (ddkkt.inc): H = H_w + U'XU and its Cholesky factor in double-double.
+    // The dd factor reuses the buffers of the double-precision inverse: Hl = M, L' = (Mt, W1).
+    DDev D{};
+    double *ddB = nullptr, *ddtS = nullptr, *ddzeta = nullptr, *ddri = nullptr, *ddd0 = nullptr;
+    int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
+    int dd_iters = 0, dd_kmax_seen = 0;
 
     void ensure_arena(size_t bytes) {
         if (bytes <= ar.cap) { ar.reset(); return; }
@@ -1764,6 +1778,57 @@ struct Solver::Impl {
             if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
         }
     }
+    // Extended-precision solve, step 1 (after the NT scaling): eigen data, cap, strong set.  Returns the number of
+    // strong eigen-directions (0: nothing above the cap, the plain solve is exact enough).  One host
+    // synchronisation (the count decides which solve runs).
+    int dd_prepare(double theta) {
+        const int nb = std::max(nbC, 1);
+        hipLaunchKernelGGL(k_dd_prep, dim3(nb), dim3(256), 0, st, P, dl, w3, D, partR);
+        int nbp = nb;
+        if (P.big) {
+            hipLaunchKernelGGL(k_dd_prep_big, dim3(1), dim3(1024), 0, st, P, wbb, Sc, D, partR + 2L * nb);
+            nbp += 1;
+        }
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            hipMemsetAsync(D.kcnt, 0, sizeof(int), st);
+            hipLaunchKernelGGL(k_dd_select, dim3(nb), dim3(256), 0, st, P, dl, D, partR, nbp, theta);
+            MBFIR_HIP(hipMemcpyAsync(hostFlag + 1, D.kcnt, sizeof(int), hipMemcpyDeviceToHost, st));
+            MBFIR_HIP(hipStreamSynchronize(st));
+            if (hostFlag[1] <= DD_KMAX) return hostFlag[1];
+            theta *= 100.0;                                   // more strong directions than U has rows: raise the cap
+        }
+        throw HipError("extended-precision solve: strong set does not fit");
+    }
+    // [0 G'; G -W^2][dx; dz] = [bx; bz] by iterative refinement around the double-double normal-equation solve
+    // (mirrors oracle/conic_ipm.py kkt_solve_dd, nref = 2).  Residual norms ||bx - G'dz|| before each pass go
+    // to Sc[slot ..].
+    template <int NV>
+    void kkt_solve_dd(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int slot) {
+        const dim3 gC(std::max(nbC, 1)), b256(256);
+        const int k = dd_k;
+        double *Bh = ddB, *Bl = ddB + 2L * P.LDV;
+        hipMemsetAsync(dx, 0, sizeof(double) * NV * P.LDV, st);
+        hipMemsetAsync(dz, 0, sizeof(double) * NV * P.Rp, st);
+        hipMemsetAsync(gdx, 0, sizeof(double) * NV * P.Rp, st);
+        for (int it = 0; it < 2; ++it) {
+            apply_GT<NV>(dz, tmpN);
+            hipLaunchKernelGGL(k_resid_norm<NV>, dim3(1), dim3(1024), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
+            hipLaunchKernelGGL(k_dd_r2<NV>, gC, b256, 0, st, P, D, dl, bz, gdx, dz, tmpR, ddtS);                  // r2, t
+            if (P.big) hipLaunchKernelGGL(k_dd_r2_big<NV>, dim3(1), dim3(1024), 0, st, P, D, bz, gdx, dz, tmpR, ddtS, scratch);
+            hipLaunchKernelGGL(k_dd_winv2c<NV>, gC, b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
+            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, dim3(1), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
+            apply_GT<NV>(wbz, tmpN2);
+            hipLaunchKernelGGL(k_dd_rhs<NV>, dim3(cdiv(P.np, 256)), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
+            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st);
+            apply_G<NV>(Bh, wpR);
+            hipLaunchKernelGGL(k_dd_winv2c<NV>, gC, b256, 0, st, P, D, wpR, tmpR, wbz);
+            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, dim3(1), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
+            hipLaunchKernelGGL(k_dd_zeta<NV>, dim3(k), dim3(64), 0, st, P, D, Bh, Bl, ddtS, ddzeta);
+            hipLaunchKernelGGL(k_dd_accum<NV>, gC, b256, 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
+            if (P.big) hipLaunchKernelGGL(k_dd_accum_big<NV>, dim3(1), dim3(1024), 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
+            hipLaunchKernelGGL(k_dd_accum_x<NV>, dim3(nbN), b256, 0, st, P, Bh, dx);
+        }
+    }
     // H = G' W^-2 G from the current scaling, then Cholesky + inverse.  Timing events are pooled
     // and read once at the end of the solve, so measuring does not serialise the host.
     bool timing = true;
@@ -1777,8 +1842,12 @@ struct Solver::Impl {
         }
         return evpool[evused++];
     }
-    void build_H() {
-        hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dl, w3, Dw, BB);
+    // ddk > 0: this iteration runs the extended-precision solve -- H_w from the capped weights (D.dlc, D.m3c),
+    // then H = H_w + U'XU and its Cholesky factor in double-double
+    void build_H(int ddk = 0) {
+        const double* dlw = ddk > 0 ? D.dlc : dl;
+        const double* m3c = ddk > 0 ? D.m3c : nullptr;
+        hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
         hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
         if (P.trig) {
             if (g0) hipEventRecord(g0, st);
@@ -1817,23 +1886,34 @@ struct Solver::Impl {
         if (lead_factor() && P.Ne > 0) {
             // the y-y block also gets terms from frequency rows (rho, delta columns), which live on every rank
             hipMemsetAsync(RB, 0, sizeof(double) * 9, st);
-            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, RB, 3L, 0L);
+            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dlw, w3, RB, 3L, 0L, m3c);
             allreduce(RB, 9, 0);
             if (mine) hipLaunchKernelGGL(k_H_yy_add, dim3(1), dim3(16), 0, st, P, RB, H);
         }
         if (mine) {
-            hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dl, w3, H);
+            hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dlw, w3, H, m3c);
             if (!lead_factor() && P.Ne > 0 && P.nyrows > 0)
-                hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dl, w3, H, (long)P.np, (long)P.Nt);
+                hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dlw, w3, H, (long)P.np, (long)P.Nt, m3c);
             if (P.big) {
-                hipMemsetAsync(qv, 0, sizeof(double) * 2 * P.LDV, st);
-                hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
-                hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+                hipMemsetAsync(qv, 0, sizeof(double) * 3 * P.LDV, st);
+                if (ddk > 0) {
+                    hipLaunchKernelGGL(k_big_q_dd, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV);
+                    hipLaunchKernelGGL(k_H_big_dd, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV, H);
+                } else {
+                    hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
+                    hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+                }
             }
         }
         if (!lead_factor()) allreduce(H, (long)P.np * P.np, 0);   // dense path: sum the shards' normal matrices
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
-        if (mine) {
+        if (ddk > 0) {
+            if (c0) hipEventRecord(c0, st);
+            hipLaunchKernelGGL(k_dd_rows, dim3(ddk), dim3(256), 0, st, P, D, P.np);
+            dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
+            dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st);
+            if (c1) hipEventRecord(c1, st);
+        } else if (mine) {
             chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1);
         } else {
             if (c0) hipEventRecord(c0, st);
@@ -1952,6 +2032,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     const int lp = Q.which == DES_AP ? specfact_lp(Q.n) : 0;
     std::vector<int> tiles(2 * S.gp.ntiles);
     gram_tiles_host(S.gp, tiles.data());
+    const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1;    // extended-precision KKT solve (ddkkt.inc)
     Arena& ar = S.ar;
     char* zero_from = nullptr;
     size_t zero_bytes = 0;
@@ -1983,7 +2064,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
     S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.pN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
     S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV);
-    S.bxc = ar.get<double>(LDV); S.dxc = ar.get<double>(LDV); S.qv = ar.get<double>(2 * LDV);
+    S.bxc = ar.get<double>(LDV); S.dxc = ar.get<double>(LDV); S.qv = ar.get<double>(3 * LDV);
     S.XX = ar.get<double>(4 * LDV); S.TT = ar.get<double>(6 * LDV); S.TT2 = ar.get<double>(4 * LDV); S.xout = ar.get<double>(LDV);
     S.s = ar.get<double>(Rp); S.z = ar.get<double>(Rp); S.lam = ar.get<double>(Rp); S.dl = ar.get<double>(Rp);
     S.wl = ar.get<double>(Rp); S.w3 = ar.get<double>(4 * (size_t)std::max(P.nq3, 1)); S.wbb = ar.get<double>(std::max(P.big, 1));
@@ -1995,6 +2076,16 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(P.trig ? (size_t)P.nchunk * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
+    if (use_dd) {
+        DDev& D = S.D;
+        D.e3 = ar.get<double>(8 * (size_t)std::max(P.nq3, 1)); D.eb = ar.get<double>(8); D.whb = ar.get<double>(std::max(P.big, 1));
+        D.dlc = ar.get<double>(Rp); D.m3c = ar.get<double>(6 * (size_t)std::max(P.nq3, 1));
+        D.slotl = ar.get<int>(std::max(P.l, 1)); D.slot3 = ar.get<int>(3 * (size_t)std::max(P.nq3, 1)); D.slotb = ar.get<int>(2);
+        D.kcnt = ar.get<int>(1); D.skind = ar.get<int>(DD_KMAX); D.sidx = ar.get<int>(DD_KMAX); D.sdir = ar.get<int>(DD_KMAX);
+        D.sX = ar.get<double>(DD_KMAX); D.U = ar.get<double>((size_t)DD_KMAX * np);
+        S.ddB = ar.get<double>(4 * LDV); S.ddtS = ar.get<double>(2 * (size_t)DD_KMAX); S.ddzeta = ar.get<double>(2 * (size_t)DD_KMAX);
+        S.ddri = ar.get<double>(2 * np); S.ddd0 = ar.get<double>(np);
+    }
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
     zero_bytes = size_t(ar.base + ar.off - zero_from);
@@ -2027,6 +2118,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.timing = o.timing;
 
     const bool sharded = S.shard_size > 1;
+    S.dd_iters = 0; S.dd_kmax_seen = 0;
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
         hipLaunchKernelGGL(k_cone_resid, dim3(nb), dim3(256), 0, st, P, v, S.partR);
@@ -2055,6 +2147,8 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     SolveInfo best_info;
     bool have_best = false;
     int wall = 0;
+    bool dd_now = false, dd_prev = false;
+    (void)dd_prev;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
@@ -2074,7 +2168,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
         MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
-        if (it > 0) {
+        if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
             // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
             // measured before each sweep of the two KKT solves of the previous iteration
             const double tol = REFTOL * hs[S_NRMC];
@@ -2124,9 +2218,13 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
             const long ob = P.l + 3L * P.nq3;
             hipLaunchKernelGGL(k_big_scaling, dim3(1), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc);
         }
-        S.build_H();
+        S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
+        if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
+        dd_prev = dd_now; dd_now = S.dd_k > 0;
+        S.build_H(S.dd_k);
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
-        S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA, true);       // W^-2 bz2 came with k_scaling
+        if (S.dd_k > 0) S.kkt_solve_dd<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, S_RNA);
+        else S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA, true);  // W^-2 bz2 came with k_scaling
         double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
         auto dots = [&](const double* xx2, const double* zz2, int mode) -> int {
             hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
@@ -2170,7 +2268,8 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
         if (P.big)
             hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
-        S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB, true);
+        if (S.dd_k > 0) S.kkt_solve_dd<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
+        else S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB, true);
         const int nd1 = dots(S.dxc, S.dzc, 1);
         dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
         hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
@@ -2196,6 +2295,7 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.collect_times(info.ms_gram, info.ms_chol, info.h_builds);
     info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
     info.lattice = P.trig;
+    info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
     info.chol_launches = info.h_builds * (P.np / 64 + 1);
     info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
     info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
@@ -2267,6 +2367,46 @@ void Solver::test_chol(int n, const double* Hh, double* out_l, double* out_m) {
     MBFIR_HIP(hipMemcpy2DAsync(out_m, (size_t)n * 8, dM.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));
     MBFIR_HIP(hipGetLastError());
+}
+
+// x = (H + U' diag(X) U)^-1 b through the double-double kernels (ddlin.hip); b and x are dd (hi, lo), nrhs <= 2
+void Solver::test_ddsolve(int n, int k, const double* Hh, const double* U, const double* X, int nrhs, const double* bh,
+                          const double* bl, double* xh, double* xl, int* nfix, double* Lh_out, double* Ll_out) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const size_t np = round_up(n, 64), ldv = np;
+    std::vector<double> Hp(np * np, 0.0), Up((size_t)std::max(k, 1) * np, 0.0), B(2 * ldv, 0.0), Bl(2 * ldv, 0.0);
+    for (size_t i = 0; i < np; ++i) Hp[i * np + i] = 1.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Hp[i * np + j] = Hh[(size_t)i * n + j];
+    for (int r = 0; r < k; ++r)
+        for (int j = 0; j < n; ++j) Up[r * np + j] = U[(size_t)r * n + j];
+    for (int v = 0; v < nrhs; ++v)
+        for (int j = 0; j < n; ++j) { B[v * ldv + j] = bh[(size_t)v * n + j]; Bl[v * ldv + j] = bl[(size_t)v * n + j]; }
+    DevBuf dH(np * np * 8), dHl(np * np * 8), dLt(np * np * 8), dLtl(np * np * 8), dU(Up.size() * 8), dX((size_t)std::max(k, 1) * 8),
+        dri(2 * np * 8), dd0(np * 8), dB(2 * ldv * 8), dBl(2 * ldv * 8), df(16);
+    MBFIR_HIP(hipMemcpyAsync(dH.p, Hp.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dU.p, Up.data(), Up.size() * 8, hipMemcpyHostToDevice, S.st));
+    if (k > 0) MBFIR_HIP(hipMemcpyAsync(dX.p, X, (size_t)k * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dB.p, B.data(), 2 * ldv * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dBl.p, Bl.data(), 2 * ldv * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(df.as<int>() + 1, &k, sizeof(int), hipMemcpyHostToDevice, S.st));
+    dd_syrk_launch(dU.as<double>(), int(np), dX.as<double>(), df.as<int>() + 1, int(np), dH.as<double>(), dHl.as<double>(), S.st);
+    dd_chol_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
+                   dd0.as<double>(), int(np), 1e-28, df.as<int>(), S.st);
+    dd_trsv_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
+                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st);
+    MBFIR_HIP(hipMemcpyAsync(B.data(), dB.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(Bl.data(), dBl.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(nfix, df.p, sizeof(int), hipMemcpyDeviceToHost, S.st));
+    if (Lh_out && Ll_out) {
+        MBFIR_HIP(hipMemcpy2DAsync(Lh_out, (size_t)n * 8, dH.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipMemcpy2DAsync(Ll_out, (size_t)n * 8, dHl.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+    }
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+    for (int v = 0; v < nrhs; ++v)
+        for (int j = 0; j < n; ++j) { xh[(size_t)v * n + j] = B[v * ldv + j]; xl[(size_t)v * n + j] = Bl[v * ldv + j]; }
 }
 
 void Solver::test_specfact(int n, const double* x, double* h_re, double* h_im) {

@@ -130,6 +130,64 @@ class _Scaling:
                                          vb[None, :], inverse)[0]
         return out
 
+    # ---- eigen form of the second-order-cone blocks ---------------------------------------
+    # W^-2 = eta^-2 (2 u u' - J), u = J wbar, has the eigenpairs
+    #   lam_p = (w0+|w1|)^2/eta^2  on  e_p = (1, -what)/sqrt2     ("strong" when the cone is nearly active)
+    #   lam_0 = 1/eta^2            on  {0} x what^perp
+    #   lam_m = 1/(eta^2 (w0+|w1|)^2)  on  e_m = (1, what)/sqrt2
+    # Applying it as  sum_k lam_k e_k e_k'  has no cancellation between the three scales.
+    @staticmethod
+    def _soc_eig(eta, wbar):
+        w0 = wbar[:, 0]
+        n1 = np.sqrt(np.sum(wbar[:, 1:] ** 2, axis=1))
+        what = np.zeros_like(wbar[:, 1:])
+        nz = n1 > 0
+        what[nz] = wbar[nz, 1:] / n1[nz, None]
+        what[~nz, 0] = 1.0
+        g = (w0 + n1) ** 2
+        ep = np.concatenate([np.ones((len(w0), 1)), -what], axis=1) / np.sqrt(2.0)
+        em = np.concatenate([np.ones((len(w0), 1)), what], axis=1) / np.sqrt(2.0)
+        return g / eta ** 2, 1.0 / eta ** 2, 1.0 / (eta ** 2 * g), ep, em
+
+    @staticmethod
+    def _soc_eig_apply(fp, f0, fm, ep, em, V):
+        """sum_k f_k e_k e_k' V for V of shape (ncones, d, ncols)."""
+        cp = np.einsum("ka,kan->kn", ep, V)
+        cm = np.einsum("ka,kan->kn", em, V)
+        rest = V - ep[:, :, None] * cp[:, None, :] - em[:, :, None] * cm[:, None, :]
+        return (ep[:, :, None] * (fp[:, None] * cp)[:, None, :] + em[:, :, None] * (fm[:, None] * cm)[:, None, :]
+                + f0[:, None, None] * rest)
+
+    def eig_weights(self):
+        """(LP weights, (lam_p, lam_0, lam_m, e_p, e_m) of the Q3 cones, the same of the big cone or None)."""
+        c = self.cone
+        q3 = self._soc_eig(self.eta3, self.wb3) if c.nq3 else None
+        bg = self._soc_eig(np.array([self.etab]), self.wbb[None, :]) if c.big else None
+        return self.dl, q3, bg
+
+    def eig_apply(self, V, power, cap=None):
+        """W^(2*power) V (power = -1: W^-2, +1: W^2) in eigen form; with `cap`, every eigenvalue of W^-2
+        above cap is replaced by cap (the capped scaling W_w of the extended-precision solve)."""
+        c = self.cone
+        vec = V.ndim == 1
+        if vec:
+            V = V[:, None]
+        out = np.empty_like(V)
+        dl, q3, bg = self.eig_weights()
+
+        def f(lam):
+            lam = np.minimum(lam, cap) if cap is not None else lam
+            return lam if power < 0 else 1.0 / lam
+        out[: c.l] = f(dl)[:, None] * V[: c.l]
+        if c.nq3:
+            lp, l0, lm, ep, em = q3
+            out[c.o3:c.ob] = self._soc_eig_apply(f(lp), f(l0), f(lm), ep, em,
+                                                 V[c.o3:c.ob].reshape(c.nq3, 3, -1)).reshape(3 * c.nq3, -1)
+        if c.big:
+            lp, l0, lm, ep, em = bg                      # lam_0 has multiplicity big-2: never capped
+            out[c.ob:] = self._soc_eig_apply(f(lp), l0 if power < 0 else 1.0 / l0, f(lm), ep, em, V[None, c.ob:])[0]
+        return out[:, 0] if vec else out
+
     def inv2(self, V):
         """W^-2 V for a vector (R,) or a matrix (R, k)."""
         c = self.cone
@@ -289,7 +347,7 @@ def next_sweeps(norm_lists, nsweep, tol):
 
 
 def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
-          reltol=1e-8, refine=2, verbose=False, history=None):
+          reltol=1e-8, refine=2, verbose=False, history=None, ddkkt=None):
     """Returns dict(status, x, s, z, iters, pcost, dcost, gap, pres, dres).
 
     Stopping rule (all quantities of the de-homogenised point x/tau ...):
@@ -310,6 +368,10 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
     e = cone.e()
 
     def factor(Wm):
+        if ddkkt is not None and Wm is not None:
+            st = factor_dd(Wm)
+            if st is not None:
+                return None, st
         H = G.T @ (Wm.inv2(G) if Wm is not None else G)
         H = 0.5 * (H + H.T)
         if not np.all(np.isfinite(H)):
@@ -324,6 +386,122 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
     def cho_solve(M, b):
         return M.T @ (M @ b)
 
+    # ---- extended-precision KKT solve (ddkkt = dict(theta=..., nref=...)) ----------------------
+    # Every eigenvalue of W^-2 above cap = theta * (median weight) is split  lam = cap + excess.  The capped
+    # scaling W_w goes through the ordinary double-precision Gram product; the excess parts
+    # H_s = U' X U  (U: one row G'e per strong eigen-direction, X = diag(excess)) are accumulated, and
+    # H = H_w + H_s is factorised, in double-double arithmetic (oracle/ddlin.c), so the weakly weighted
+    # directions survive next to weights 1e16 times larger.  The multipliers of the strong directions,
+    # zeta = X (U dx - e_p'bz), are evaluated in double-double from the double-double dx.  Around this
+    # solver runs plain iterative refinement on the augmented system [0 G'; G -W^2] in double precision,
+    # whose residuals involve W^2 (tiny on the strong directions), never W^-2.
+    def factor_dd(Wm):
+        from . import ddlin
+        dl, q3, bg = Wm.eig_weights()
+        typ = [dl] + ([q3[1]] if q3 is not None else []) + ([bg[1]] if bg is not None else [])
+        # "typical" weight: geometric mean of the LP weights and the middle eigenvalues of the cones (a sum
+        # reduction on the device, where a median would need a selection)
+        cap = ddkkt.get("theta", 1e6) * float(np.exp(np.mean(np.log(np.concatenate(typ)))))
+        # strong eigen-directions: (offset of the cone in R, eigenvector over the cone's rows, excess weight)
+        rowsU, X, sel = [], [], []
+        if cone.l:
+            i = np.nonzero(dl > cap)[0]
+            sel.append(("l", i, None))
+            rowsU.append(G[i]); X.append(dl[i] - cap)
+        if cone.nq3:
+            lp, l0, lm, ep, em = q3
+            e0 = np.stack([np.zeros(cone.nq3), -ep[:, 2], ep[:, 1]], 1) * np.sqrt(2.0)   # (0, what_perp)
+            G3 = G[cone.o3:cone.ob].reshape(cone.nq3, 3, N)
+            for lam, ev in ((lp, ep), (l0, e0), (lm, em)):
+                i = np.nonzero(lam > cap)[0]
+                sel.append(("q", i, ev[i]))
+                rowsU.append(np.einsum("ka,kan->kn", ev[i], G3[i])); X.append(lam[i] - cap)
+        if cone.big:
+            for lam, ev in ((bg[0], bg[3]), (bg[2], bg[4])):
+                i = np.nonzero(lam > cap)[0]
+                sel.append(("b", i, ev[i]))
+                rowsU.append(ev[i] @ G[cone.ob:]); X.append(lam[i] - cap)
+        U = np.ascontiguousarray(np.concatenate(rowsU, 0))
+        X = np.ascontiguousarray(np.concatenate(X))
+        if len(X) == 0:
+            return None                                        # nothing above the cap: the plain solve is exact enough
+        Hw = G.T @ Wm.eig_apply(G, -1, cap)
+        Hw = 0.5 * (Hw + Hw.T)
+        if not np.all(np.isfinite(Hw)):
+            raise FloatingPointError("non-finite normal matrix")
+        Hh = np.ascontiguousarray(Hw)
+        Hl = np.zeros_like(Hh)
+        if len(X):
+            ddlin.rank_k(U, X, Hh, Hl)
+        d0 = np.ascontiguousarray(np.diag(Hh)).copy()
+        nfix = ddlin.chol(Hh, Hl, ddkkt.get("pivtol", 1e-28), d0)
+        chol_fixes[0] += nfix
+
+        def comp(V):                                           # e' V_cone for the strong directions
+            out = []
+            for kind, i, ev in sel:
+                if kind == "l":
+                    out.append(V[i])
+                elif kind == "q":
+                    out.append(np.einsum("ka,kan->kn", ev, V[cone.o3:cone.ob].reshape(cone.nq3, 3, -1)[i]))
+                else:
+                    out.append(ev @ V[cone.ob:])
+            return np.concatenate(out, 0)
+
+        def spread(Z, ncol):                                   # rows of R from strong-direction multipliers
+            o = np.zeros((R, ncol))
+            oq = o[cone.o3:cone.ob].reshape(cone.nq3, 3, ncol)
+            k0 = 0
+            for kind, i, ev in sel:
+                k1 = k0 + len(i)
+                if kind == "l":
+                    o[i] += Z[k0:k1]
+                elif kind == "q":
+                    np.add.at(oq, i, ev[:, :, None] * Z[k0:k1][:, None, :])
+                elif len(i):
+                    o[cone.ob:] += ev[0][:, None] * Z[k0][None, :]
+                k0 = k1
+            return o
+        return dict(Wm=Wm, cap=cap, U=U, X=X, Lh=Hh, Ll=Hl, comp=comp, spread=spread, k=len(X), nfix=nfix)
+
+    dd_log = []
+
+    def kkt_solve_dd(st, bx, bz):
+        from . import ddlin
+        Wm, U, X, cap = st["Wm"], st["U"], st["X"], st["cap"]
+        vec = bx.ndim == 1
+        BX = bx[:, None].copy() if vec else bx
+        BZ = bz[:, None].copy() if vec else bz
+        ncol = BX.shape[1]
+        DX = np.zeros((N, ncol)); DZ = np.zeros((R, ncol)); GDX = np.zeros((R, ncol))
+        norms = []
+        for it in range(ddkkt.get("nref", 2) + 1):
+            r1 = BX - G.T @ DZ
+            r2 = BZ - GDX + Wm.eig_apply(DZ, +1)
+            n1 = float(np.max(np.sqrt(np.sum(r1 * r1, axis=0))))
+            n2 = float(np.max(np.abs(r2)))
+            norms.append((n1, n2))
+            if it == ddkkt.get("nref", 2):
+                break
+            t = np.ascontiguousarray(st["comp"](r2))                         # k x ncol
+            rh = np.ascontiguousarray(r1 + G.T @ Wm.eig_apply(r2, -1, cap))
+            rl = np.zeros_like(rh)
+            if st["k"]:
+                yh, yl = ddlin.vec_mul_d(t.ravel(), np.zeros(t.size), np.repeat(X, ncol))
+                ddlin.cols_times_acc(U, yh.reshape(-1, ncol), yl.reshape(-1, ncol), rh, rl)
+            ddlin.cho_solve(st["Lh"], st["Ll"], rh, rl)                      # rh, rl <- delta x (dd)
+            dxh = rh
+            Gd = G @ dxh
+            dz = Wm.eig_apply(Gd - r2, -1, cap)
+            if st["k"]:
+                uh, ul = ddlin.rows_times(U, rh, rl)
+                uh, ul = ddlin.vec_sub(uh.ravel(), ul.ravel(), t.ravel(), np.zeros(t.size))
+                zh, zl = ddlin.vec_mul_d(uh, ul, np.repeat(X, ncol))
+                dz = dz + st["spread"]((zh + zl).reshape(-1, ncol), ncol)
+            DX += dxh; DZ += dz; GDX += Gd
+        dd_log.append(norms)
+        return (DX[:, 0], DZ[:, 0], GDX[:, 0]) if vec else (DX, DZ, GDX)
+
     def kkt_solve(Wm, H, cf, bx, bz):
         """[0 G'; G -W^2][dx; dz] = [bx; bz] for one or two right-hand sides (columns);
         returns (dx, dz, G dx).
@@ -331,6 +509,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         dz is kept as an explicit vector and corrected incrementally, so the dual
         equation G'dz = bx is driven to rounding level even when ||H|| eps is large
         (the residual of an increment scales with the increment, not with dx)."""
+        if isinstance(cf, dict):
+            return kkt_solve_dd(cf, bx, bz)
         wbz = Wm.inv2(bz) if Wm is not None else bz
         rhs = bx + G.T @ wbz
         dx = cho_solve(cf, rhs)
@@ -411,7 +591,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             history.append(dict(info))
         if verbose:
             print("%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e"
-                  % (it, pcost, dcost, gap, pres, dres, kappa / tau, mu))
+                  % (it, pcost, dcost, gap, pres, dres, kappa / tau, mu),
+                  " ".join("[%s]" % " ".join("%.0e/%.0e" % t for t in nn) for nn in dd_log[-2:]) if dd_log and verbose > 1 else "")
         finite = np.isfinite(pres) and np.isfinite(dres) and np.isfinite(gap) and tau > 0
         if not finite:
             status = STATUS_NUMERICAL
@@ -497,7 +678,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             break
         dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, dk_c, x2, z2, Gx2)
         alpha = step_of(dss, wdz, dtau, dkap, STEP)
-        nsweep[0] = next_sweeps(sweep_log, nsweep[0], REFTOL * nrm_c)
+        if sweep_log:                                         # (iterations on the extended-precision path keep the count)
+            nsweep[0] = next_sweeps(sweep_log, nsweep[0], REFTOL * nrm_c)
         if history is not None:
             sl_, zl_ = s[:cone.l], z[:cone.l]
             history[-1].update(alpha=alpha, alpha_a=alpha_a, sigma=sigma,

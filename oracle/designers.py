@@ -32,8 +32,13 @@ def fir_ap_cvx(n, f, a, d, obj=0.0, Peak=1e-3, dbg=0, grid_m=0, info=False, **kw
     return _ret(h, r, info)
 
 
+DDKKT_THETA = 1e6       # csrc/api.cpp uses the same value
+
+
 def fir_qp_cvx(n, f, a, d, k=100.0, obj=0.0, dbg=0, grid_m=0, info=False, **kw):
     P = assemble.assemble_fir_qp_cvx(n, f, a, d, k, obj, grid_m)
+    # the nearly active error cones of this designer need the extended-precision KKT solve (conic_ipm.factor_dd)
+    kw.setdefault("ddkkt", dict(theta=DDKKT_THETA))
     r = _solve(P, kw)
     x = r["x"]
     return _ret(x[:n] + 1j * x[n:2 * n], r, info)                                                  # :209

@@ -50,6 +50,50 @@ def test_cholesky_and_inverse(n):
     assert np.linalg.norm(H @ x - b) <= 1e-10 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("n,k", [(40, 0), (100, 7), (257, 60), (700, 300)])
+def test_double_double_solve_matches_the_oracles_dd_kernels(n, k):
+    """Extended-precision KKT kernels (ddlin.hip): H = H_w + U' X U with X up to 1e16 x the scale of H_w, its
+    Cholesky factor and the two triangular solves, all in double-double.  Checked against the oracle's C twin
+    (oracle/ddlin.c) and against the residual in exact rational-free form: with cond(H) ~ 1e18 a double
+    solver loses everything, the dd solve must still reproduce b to 1e-12 through the split operator."""
+    from oracle import ddlin
+    rng = np.random.default_rng(n + k)
+    B = rng.standard_normal((n + 30, n))
+    Hw = B.T @ B
+    Hw = 0.5 * (Hw + Hw.T)
+    U = rng.standard_normal((k, n))
+    if k:
+        U[1::3] = U[0::3][: len(U[1::3])] * (1 + 1e-9 * rng.standard_normal((len(U[1::3]), 1)))     # nearly dependent rows
+    X = 10.0 ** rng.uniform(8, 16, k)
+    b = rng.standard_normal((2, n))
+    bl = 1e-17 * rng.standard_normal((2, n))
+    xh, xl, nfix = mbfir.test_ddsolve(Hw, U, X, b, bl)
+    # oracle twin
+    Hh, Hl = Hw.copy(), np.zeros_like(Hw)
+    if k:
+        ddlin.rank_k(np.ascontiguousarray(U), X, Hh, Hl)
+    d0 = np.diag(Hh).copy()
+    nfo = ddlin.chol(Hh, Hl, 1e-28, d0)
+    Bh, Bl = np.ascontiguousarray(b.T), np.ascontiguousarray(bl.T)
+    ddlin.cho_solve(Hh, Hl, Bh, Bl)
+    assert nfix == nfo == 0
+    ref = (Bh + Bl).T
+    assert np.abs((xh + xl) - ref).max() <= 1e-24 * np.abs(ref).max() * max(1.0, X.max() if k else 1.0)
+    # residual through the split operator  b - H_w x - U' X (U x), the strong part evaluated in double-double
+    # (a double evaluation of U x would be pure rounding noise next to weights of 1e16)
+    Xh, Xl = np.ascontiguousarray(xh.T), np.ascontiguousarray(xl.T)
+    strong = np.zeros((n, 2))
+    if k:
+        Uc = np.ascontiguousarray(U)
+        uh, ul = ddlin.rows_times(Uc, Xh, Xl)
+        yh, yl = ddlin.vec_mul_d(uh.ravel(), ul.ravel(), np.repeat(X, 2))
+        sh_, sl_ = np.zeros((n, 2)), np.zeros((n, 2))
+        ddlin.cols_times_acc(Uc, yh.reshape(-1, 2), yl.reshape(-1, 2), sh_, sl_)
+        strong = sh_ + sl_
+    r = b.T - Hw @ (Xh + Xl) - strong
+    assert np.abs(r).max() <= 1e-10 * (np.abs(b).max() + np.abs(Hw).max() * np.abs(Xh).max() * n)
+
+
 def test_cholesky_ill_conditioned_scaling():
     """IPM-like matrix: A' D A with D spanning ten decades (cond ~1e9)."""
     rng = np.random.default_rng(11)
