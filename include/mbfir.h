@@ -142,6 +142,9 @@ typedef struct mbfir_job {
     double params[4];
     double *h_re, *h_im;          /* n doubles each, caller-allocated */
     mbfir_info info;
+    double *z;                    /* optional: receives the conic solution (as mbfir_last_solution), up to z_cap doubles */
+    int z_cap;
+    char err[128];                /* message of the context that ran the job when rc < 0 */
 } mbfir_job;
 
 int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njobs,
@@ -198,6 +201,18 @@ int mbfir_b2rf(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, do
  * abr.m's convention is b = -conj(b) of mode 0; mxy = 2 conj(a) b, mz = 1 - 2 |b|^2 (abr.m:11-14). */
 int mbfir_abr(mbfir_ctx* ctx, int n, const double* rf_re, const double* rf_im, const double* g, int nx,
               const double* x, int mode, double* a_re, double* a_im, double* b_re, double* b_im);
+
+/* Bloch-equation simulation with relaxation on the device: replaces the MEX bloch_simulation/blochC.c / blochH.c
+ * (mexFunction :514-933 -> blochsimfz :422-512 -> blochsim :283-418, calcrotmat :171-236) that sim_rf_spectral.m:63-78
+ * runs on the designed pulse.  b1 in Gauss (re / im planes, ntime samples), gx/gy/gz in G/cm (each may be NULL = 0),
+ * tsteps = the ntime interval lengths in s, t1/t2 in s, df in Hz (nfreq), dx/dy/dz in cm (npos; each may be NULL = 0),
+ * mode bit 0: steady state, bit 1: record every sample (the reference's `mode`), gamma in rad/s/G (6726.1 for C-13 =
+ * blochC.c:5, 26754 for H-1 = blochH.c:6).  mx/my/mz: nfreq * npos * (mode & 2 ? ntime : 1) doubles, block (f, p) at
+ * (f * npos + p) * ntout; on entry the first entry of every block holds the initial magnetisation (the gateway's
+ * :826-866 convention; [0 0 1] for equilibrium), on exit the result.  One thread per (frequency, position).      */
+int mbfir_bloch(mbfir_ctx* ctx, int ntime, const double* b1_re, const double* b1_im, const double* gx, const double* gy,
+                const double* gz, const double* tsteps, double t1, double t2, int nfreq, const double* df, int npos,
+                const double* dx, const double* dy, const double* dz, int mode, double gamma, double* mx, double* my, double* mz);
 
 /* Device kernel test hooks (need a GPU; host arrays in, host arrays out):
  *  mbfir_test_gram: T = A' diag(dk) A for nw weight vectors; A is m x nt row-major,

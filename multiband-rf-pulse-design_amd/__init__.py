@@ -62,7 +62,7 @@ class Job(C.Structure):
     _fields_ = [("which", C.c_int), ("n", C.c_int), ("nband", C.c_int), ("rc", C.c_int),
                 ("f", C.POINTER(C.c_double)), ("a", C.POINTER(C.c_double)), ("d", C.POINTER(C.c_double)),
                 ("params", C.c_double * 4), ("h_re", C.POINTER(C.c_double)), ("h_im", C.POINTER(C.c_double)),
-                ("info", Info)]
+                ("info", Info), ("z", C.POINTER(C.c_double)), ("z_cap", C.c_int), ("err", C.c_char * 128)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
@@ -93,6 +93,8 @@ SYMBOLS = {
     "mbfir_ab2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "mbfir_b2rf": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
     "mbfir_abr": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "mbfir_bloch": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, _dp, C.c_int,
+                              _dp, _dp, _dp, C.c_int, C.c_double, _dp, _dp, _dp]),
     "mbfir_assemble": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int,
                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_int]),
     "mbfir_program_free": (None, [C.c_void_p]),
@@ -406,12 +408,13 @@ def get_pool(streams=4, device=None):
     return _pools[key]
 
 
-def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False):
+def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False, solutions=False):
     """Independent designs, `streams` in flight at a time on one GPU (mbfir_solve_batch): the shape of
     the reference's outer loops -- the probes of a min-order / min-duration bisection, parameter sweeps.
     jobs: sequence of (designer, args) with designer in {'fir_ap_cvx', 'fir_qp_cvx', 'fir_linprog',
     'fir_qprog_phs'} and args the positional arguments of that function (n, f, a, d, ...).
-    Returns a list of (h, status) -- or (h, status, info) -- in job order, as the single calls return."""
+    Returns a list of (h, status) -- or (h, status, info) -- in job order, as the single calls return.
+    solutions=True appends the conic solution z of every job (mbfir_last_solution) to its tuple."""
     ctxs = ctxs or get_pool(streams)
     o = opts if opts is not None else make_opts()
     arr = (Job * len(jobs))()
@@ -442,8 +445,11 @@ def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False):
                 params[1:1 + len(objv)] = list(objv)
                 params[3] = float(len(objv))
         hre, him = np.zeros(n), np.zeros(n)
-        keep.append((f, a, d, hre, him))
+        zbuf = np.zeros(2 * n + 8) if solutions else None
+        keep.append((f, a, d, hre, him, zbuf))
         J = arr[q]
+        if solutions:
+            J.z, J.z_cap = _ptr(zbuf), len(zbuf)
         J.which, J.n, J.nband = which, n, nband
         J.f, J.a, J.d, J.h_re, J.h_im = _ptr(f), _ptr(a), _ptr(d), _ptr(hre), _ptr(him)
         for t in range(4):
@@ -458,8 +464,9 @@ def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False):
         if arr[q].rc < 0:
             if arr[q].rc == E_ARG:
                 raise ValueError("job %d: invalid argument" % q)
-            raise MbfirError("job %d failed (%d)" % (q, arr[q].rc))
-        out.append(_finish(ctxs[0], arr[q].rc, hre, him, inf, info))
+            raise MbfirError("job %d failed (%d): %s" % (q, arr[q].rc, arr[q].err.decode(errors="replace")))
+        res = _finish(ctxs[0], arr[q].rc, hre, him, inf, info)
+        out.append(res + (keep[q][5][: inf.n_unknowns],) if solutions else res)
     return out
 
 
@@ -561,6 +568,50 @@ def test_chol(H, ctx=None):
     L, M = np.zeros((n, n)), np.zeros((n, n))
     _check(ctx, load_library().mbfir_test_chol(ctx._h, n, _ptr(H), _ptr(L), _ptr(M)))
     return L, M
+
+
+GAMMA_C13 = 6726.1          # rad/s/G, blochC.c:5
+GAMMA_H1 = 26754.0          # blochH.c:6
+
+
+def bloch(b1, gr, tp, t1, t2, df, dp, mode=0, mx=None, my=None, mz=None, nucleus="C-13", ctx=None):
+    """[mx, my, mz] = bloch(b1, gr, tp, t1, t2, df, dp, mode, mx, my, mz) of bloch_simulation/bloch.m:1-44 on the device
+    (blochC for nucleus 'C-13', blochH for 'H-1', as sim_rf_spectral.m:53-60 picks them).  b1 complex (Gauss), gr (ntime,)
+    or (ntime, 1..3) G/cm, tp a scalar interval, ntime intervals, or ntime monotonically increasing end times
+    (blochC.c:649-681), df Hz, dp (npos,) or (npos, 1..3) cm.  Returns arrays of shape (nfreq, npos) or, with mode & 2,
+    (nfreq, npos, ntime)."""
+    ctx = ctx or get_context()
+    b1 = np.asarray(b1, dtype=np.complex128).ravel()
+    nt = len(b1)
+    gr = np.zeros((nt, 1)) if gr is None else np.asarray(gr, dtype=np.float64).reshape(nt, -1)
+    g3 = [_vec(gr[:, i]) if i < gr.shape[1] else None for i in range(3)]
+    tp = np.asarray(tp, dtype=np.float64).ravel()
+    if tp.size == 1:
+        ts = np.full(nt, tp[0])
+    elif tp.size != nt:
+        raise MbfirError("Time-point length differs from B1 length")
+    else:
+        iv = np.diff(np.concatenate([[0.0], tp]))
+        ts = iv if np.all(iv > 0) else tp                       # increasing end times -> intervals (times2intervals)
+    df = _vec(df)
+    dp = np.asarray(dp, dtype=np.float64)
+    dp = dp.reshape(-1, 1) if dp.ndim < 2 else dp
+    p3 = [_vec(dp[:, i]) if i < dp.shape[1] else None for i in range(3)]
+    nf, npos = len(df), dp.shape[0]
+    ntout = nt if (int(mode) & 2) else 1
+    out = []
+    for init, dflt in ((mx, 0.0), (my, 0.0), (mz, 1.0)):
+        o = np.zeros((nf * npos, ntout))
+        o[:, 0] = dflt if init is None or np.size(init) != nf * npos else np.asarray(init, dtype=np.float64).ravel()
+        out.append(np.ascontiguousarray(o))
+    gamma = GAMMA_C13 if nucleus == "C-13" else GAMMA_H1 if nucleus == "H-1" else float(nucleus)
+    nul = C.cast(None, _dp)
+    _check(ctx, load_library().mbfir_bloch(ctx._h, nt, _ptr(_vec(b1.real)), _ptr(_vec(b1.imag)),
+                                           *[_ptr(g) if g is not None else nul for g in g3], _ptr(_vec(ts)), float(t1), float(t2),
+                                           nf, _ptr(df), npos, *[_ptr(p) if p is not None else nul for p in p3], int(mode),
+                                           gamma, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+    shape = (nf, npos, nt) if ntout > 1 else (nf, npos)
+    return tuple(o.reshape(shape) for o in out)
 
 
 def test_ddsolve(H, U, X, bh, bl, ctx=None, factor=False):

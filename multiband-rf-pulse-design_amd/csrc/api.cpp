@@ -4,6 +4,8 @@
 #include "program.h"
 #include "solver.h"
 #include <chrono>
+#include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <atomic>
 #include <memory>
@@ -267,6 +269,12 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 }
                 default: J.rc = MBFIR_E_ARG;
             }
+            J.err[0] = 0;
+            if (J.rc < 0) std::snprintf(J.err, sizeof(J.err), "%s", ctxs[c]->err.c_str());
+            if (J.z && J.z_cap > 0 && J.rc >= 0) {
+                const std::vector<double>& x = ctxs[c]->last_x;
+                std::memcpy(J.z, x.data(), sizeof(double) * std::min<size_t>(x.size(), size_t(J.z_cap)));
+            }
         }
     };
     const int nthreads = nctx < njobs ? nctx : njobs;
@@ -303,6 +311,14 @@ int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, do
 int mbfir_b2a(mbfir_ctx* ctx, int n, const double* b_re, const double* b_im, double* a_re, double* a_im) {
     if (!ctx || n < 1 || !b_re || !b_im || !a_re || !a_im) return MBFIR_E_ARG;
     MBFIR_TRY(ctx, ctx->solver->slr(n, b_re, b_im, nullptr, nullptr, a_re, a_im, nullptr, nullptr));
+}
+int mbfir_bloch(mbfir_ctx* ctx, int ntime, const double* b1_re, const double* b1_im, const double* gx, const double* gy,
+                const double* gz, const double* tsteps, double t1, double t2, int nfreq, const double* df, int npos,
+                const double* dx, const double* dy, const double* dz, int mode, double gamma, double* mx, double* my, double* mz) {
+    if (!ctx || ntime < 1 || nfreq < 1 || npos < 1 || !b1_re || !b1_im || !tsteps || !df || !mx || !my || !mz || mode < 0 || mode > 3 ||
+        !(t1 > 0) || !(t2 > 0))
+        return MBFIR_E_ARG;
+    MBFIR_TRY(ctx, ctx->solver->bloch(ntime, b1_re, b1_im, gx, gy, gz, tsteps, t1, t2, nfreq, df, npos, dx, dy, dz, mode, gamma, mx, my, mz));
 }
 int mbfir_ab2rf(mbfir_ctx* ctx, int n, const double* a_re, const double* a_im, const double* b_re, const double* b_im,
                 double* rf_re, double* rf_im) {

@@ -113,6 +113,9 @@ void specfact_launch(const double* x, int n, double* work, double* hout, hipStre
 void slr_b2a_launch(const double* b_re, const double* b_im, int n, double* work, double* a_il, hipStream_t st);
 void slr_abr_launch(const double* rf_il, const double* g, int n, const double* x, int nx, int mode, double* a_il, double* b_il,
                     hipStream_t st);
+// Bloch simulation with relaxation (slr.hip k_bloch; blochC.c:283-512).  step: ntime x 8 per-sample quantities.
+void bloch_launch(const double* step, int ntime, const double* df, int nf, const double* pos3, int npos, int mode, double* mx,
+                  double* my, double* mz, hipStream_t st);
 void slr_ab2rf_launch(const double* a_il, const double* b_il, int n, double* rf_il, hipStream_t st);
 
 }  // namespace mbfir

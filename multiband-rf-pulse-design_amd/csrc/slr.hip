@@ -185,6 +185,105 @@ void slr_abr_launch(const double* rf_il, const double* g, int n, const double* x
     hipLaunchKernelGGL(k_abr, dim3(cdiv(nx, 256)), dim3(256), 0, st, rf_il, g, n, x, nx, mode, a_il, b_il);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bloch-equation simulation with relaxation: bloch_simulation/blochC.c calcrotmat (:171-236),
+// blochsim (:283-418), blochsimfz (:422-512).  One thread per (off-resonance, position) pair -- the reference's
+// two outer loops -- and the time loop inside; the per-sample quantities (rotation components of the pulse,
+// gradient, interval, E1, E2) are staged through LDS 256 samples at a time.
+//   mode bit 0: steady state (propagate A, B with M' = A M + B, then M = (I - A)^-1 B), bit 1: record every sample.
+// step[t] = (rotx, roty, gx, gy, gz (each * gamma * dt), dt * TWOPI, e1, e2); pos3 = (x, y, z) per position.
+struct Rot3 {
+    double m[9];           // column-major like the reference: m[i + 3 j]
+};
+__device__ __forceinline__ void bloch_rotmat(double nx, double ny, double nz, Rot3& R) {
+    const double phi = sqrt(nx * nx + ny * ny + nz * nz);
+    if (phi == 0.0) {
+        R.m[0] = 1; R.m[1] = 0; R.m[2] = 0; R.m[3] = 0; R.m[4] = 1; R.m[5] = 0; R.m[6] = 0; R.m[7] = 0; R.m[8] = 1;
+        return;
+    }
+    double sn, cp;
+    sincos(0.5 * phi, &sn, &cp);
+    const double sp = sn / phi;
+    const double ar = cp, ai = -nz * sp, br = ny * sp, bi = -nx * sp;
+    R.m[0] = ar * ar - ai * ai - br * br + bi * bi;
+    R.m[1] = -2 * ar * ai - 2 * br * bi;
+    R.m[2] = -2 * ar * br + 2 * ai * bi;
+    R.m[3] = 2 * ar * ai - 2 * br * bi;
+    R.m[4] = ar * ar - ai * ai + br * br - bi * bi;
+    R.m[5] = -2 * ai * br - 2 * ar * bi;
+    R.m[6] = 2 * ar * br + 2 * ai * bi;
+    R.m[7] = 2 * ar * bi - 2 * ai * br;
+    R.m[8] = ar * ar + ai * ai - br * br - bi * bi;
+}
+__device__ __forceinline__ void rot_vec(const Rot3& R, const double v[3], double o[3]) {
+    o[0] = R.m[0] * v[0] + R.m[3] * v[1] + R.m[6] * v[2];
+    o[1] = R.m[1] * v[0] + R.m[4] * v[1] + R.m[7] * v[2];
+    o[2] = R.m[2] * v[0] + R.m[5] * v[1] + R.m[8] * v[2];
+}
+constexpr int BLOCH_CH = 256;
+__global__ __launch_bounds__(256) void k_bloch(const double* __restrict__ step, int ntime, const double* __restrict__ df, int nf,
+                                               const double* __restrict__ pos3, int npos, int mode, double* __restrict__ mx,
+                                               double* __restrict__ my, double* __restrict__ mz) {
+    __shared__ double sst[BLOCH_CH][8];
+    const long pair = (long)blockIdx.x * 256 + threadIdx.x, npair = (long)nf * npos;
+    const bool live = pair < npair;
+    const int fi = live ? int(pair / npos) : 0, pi = live ? int(pair - (long)fi * npos) : 0;
+    const double dfv = df[fi], px = pos3[3 * pi], py = pos3[3 * pi + 1], pz = pos3[3 * pi + 2];
+    const int ntout = (mode & 2) ? ntime : 1;
+    const long o0 = pair * ntout;
+    double m[3] = {0, 0, 1};
+    if (live) { m[0] = mx[o0]; m[1] = my[o0]; m[2] = mz[o0]; }          // initial magnetisation sits in the output (:826-841)
+    for (int pass = (mode & 1) ? 0 : 1; pass < 2; ++pass) {
+        if (pass == 1 && mode == 1) break;                               // steady state only
+        double A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, B[3] = {0, 0, 0};
+        for (int t0 = 0; t0 < ntime; t0 += BLOCH_CH) {
+            __syncthreads();
+            const int cnt = min(BLOCH_CH, ntime - t0);
+            for (int e = threadIdx.x; e < cnt * 8; e += 256) sst[e >> 3][e & 7] = step[(long)t0 * 8 + e];
+            __syncthreads();
+            if (!live) continue;
+            for (int q = 0; q < cnt; ++q) {
+                const double* s = sst[q];
+                const double rotz = -((s[2] * px + s[3] * py + s[4] * pz) + dfv * s[5]);
+                Rot3 R;
+                bloch_rotmat(s[0], s[1], rotz, R);
+                const double e1 = s[6], e2 = s[7];
+                if (pass == 0) {
+                    double c[3], o[3];
+                    for (int j = 0; j < 3; ++j) {                        // A <- D R A, column by column
+                        c[0] = A[3 * j]; c[1] = A[3 * j + 1]; c[2] = A[3 * j + 2];
+                        rot_vec(R, c, o);
+                        A[3 * j] = e2 * o[0]; A[3 * j + 1] = e2 * o[1]; A[3 * j + 2] = e1 * o[2];
+                    }
+                    rot_vec(R, B, o);
+                    B[0] = e2 * o[0]; B[1] = e2 * o[1]; B[2] = e1 * o[2] + (1 - e1);
+                } else {
+                    double o[3];
+                    rot_vec(R, m, o);
+                    m[0] = e2 * o[0]; m[1] = e2 * o[1]; m[2] = e1 * o[2] + (1 - e1);
+                    if (mode & 2) { mx[o0 + t0 + q] = m[0]; my[o0 + t0 + q] = m[1]; mz[o0 + t0 + q] = m[2]; }
+                }
+            }
+        }
+        if (pass == 0 && live) {
+            // M = (I - A)^-1 B by the adjugate (the reference's invmat)
+            double K[9];
+            for (int e = 0; e < 9; ++e) K[e] = ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0) - A[e];
+            const double c00 = K[4] * K[8] - K[7] * K[5], c01 = K[7] * K[2] - K[1] * K[8], c02 = K[1] * K[5] - K[4] * K[2];
+            const double det = K[0] * c00 + K[3] * c01 + K[6] * c02;
+            const double inv[9] = {c00 / det, c01 / det, c02 / det,
+                                   (K[6] * K[5] - K[3] * K[8]) / det, (K[0] * K[8] - K[6] * K[2]) / det, (K[3] * K[2] - K[0] * K[5]) / det,
+                                   (K[3] * K[7] - K[6] * K[4]) / det, (K[6] * K[1] - K[0] * K[7]) / det, (K[0] * K[4] - K[3] * K[1]) / det};
+            for (int i = 0; i < 3; ++i) m[i] = inv[i] * B[0] + inv[3 + i] * B[1] + inv[6 + i] * B[2];
+        }
+    }
+    if (live && !(mode & 2)) { mx[o0] = m[0]; my[o0] = m[1]; mz[o0] = m[2]; }
+}
+void bloch_launch(const double* step, int ntime, const double* df, int nf, const double* pos3, int npos, int mode, double* mx,
+                  double* my, double* mz, hipStream_t st) {
+    hipLaunchKernelGGL(k_bloch, dim3(cdiv((long)nf * npos, 256)), dim3(256), 0, st, step, ntime, df, nf, pos3, npos, mode, mx, my, mz);
+}
+
 // work: 3 * 8n double2.  a_il / rf_il: device arrays of 2n doubles (interleaved).
 void slr_b2a_launch(const double* b_re, const double* b_im, int n, double* work, double* a_il, hipStream_t st) {
     const int N = 8 * n;

@@ -47,6 +47,11 @@ public:
     // Forward simulation (slr.hip k_abr): a, b over nx positions; g null = 2 pi / n per sample; mode 0 abrm.m, 1 hard pulse.
     void abr(int n, const double* rf_re, const double* rf_im, const double* g, int nx, const double* x, int mode,
              double* a_re, double* a_im, double* b_re, double* b_im);
+    // Bloch simulation with relaxation (slr.hip k_bloch; blochC.c:422-512).  m*: in = initial magnetisation at the first
+    // sample of every (frequency, position) block, out = the result; nfreq * npos * (mode & 2 ? ntime : 1) doubles each.
+    void bloch(int ntime, const double* b1_re, const double* b1_im, const double* gx, const double* gy, const double* gz,
+               const double* tsteps, double t1, double t2, int nfreq, const double* df, int npos, const double* dx,
+               const double* dy, const double* dz, int mode, double gamma, double* mx, double* my, double* mz);
     // kernel test hooks
     void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
     void test_chol(int n, const double* H, double* out_l, double* out_m);

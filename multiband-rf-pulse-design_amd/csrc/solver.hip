@@ -2475,6 +2475,42 @@ void Solver::abr(int n, const double* rf_re, const double* rf_im, const double* 
     for (size_t i = 0; i < X; ++i) { a_re[i] = oa[2 * i]; a_im[i] = oa[2 * i + 1]; b_re[i] = ob[2 * i]; b_im[i] = ob[2 * i + 1]; }
 }
 
+void Solver::bloch(int ntime, const double* b1_re, const double* b1_im, const double* gx, const double* gy, const double* gz,
+                   const double* tsteps, double t1, double t2, int nfreq, const double* df, int npos, const double* dx,
+                   const double* dy, const double* dz, int mode, double gamma, double* mx, double* my, double* mz) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    const double TWOPI_REF = 6.283185;                       // blochC.c:6, the reference's truncated constant
+    const size_t nt = (size_t)ntime, npair = (size_t)nfreq * npos, nout = npair * ((mode & 2) ? nt : 1);
+    std::vector<double> step(nt * 8), pos(3 * (size_t)npos);
+    for (size_t t = 0; t < nt; ++t) {
+        const double dt = tsteps[t];
+        step[8 * t] = -b1_re[t] * gamma * dt;                // rotx  (blochC.c:332)
+        step[8 * t + 1] = b1_im[t] * gamma * dt;             // roty  (:333)
+        step[8 * t + 2] = (gx ? gx[t] : 0.0) * gamma * dt;   // gradient terms of rotz (:317-319, :330)
+        step[8 * t + 3] = (gy ? gy[t] : 0.0) * gamma * dt;
+        step[8 * t + 4] = (gz ? gz[t] : 0.0) * gamma * dt;
+        step[8 * t + 5] = TWOPI_REF * dt;
+        step[8 * t + 6] = std::exp(-dt / t1);                // :460-464
+        step[8 * t + 7] = std::exp(-dt / t2);
+    }
+    for (int p = 0; p < npos; ++p) { pos[3 * p] = dx ? dx[p] : 0.0; pos[3 * p + 1] = dy ? dy[p] : 0.0; pos[3 * p + 2] = dz ? dz[p] : 0.0; }
+    DevBuf dstep(step.size() * 8), dpos(pos.size() * 8), ddf((size_t)nfreq * 8), dmx(nout * 8), dmy(nout * 8), dmz(nout * 8);
+    MBFIR_HIP(hipMemcpyAsync(dstep.p, step.data(), step.size() * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dpos.p, pos.data(), pos.size() * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(ddf.p, df, (size_t)nfreq * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dmx.p, mx, nout * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dmy.p, my, nout * 8, hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipMemcpyAsync(dmz.p, mz, nout * 8, hipMemcpyHostToDevice, S.st));
+    bloch_launch(dstep.as<double>(), ntime, ddf.as<double>(), nfreq, dpos.as<double>(), npos, mode, dmx.as<double>(), dmy.as<double>(),
+                 dmz.as<double>(), S.st);
+    MBFIR_HIP(hipMemcpyAsync(mx, dmx.p, nout * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(my, dmy.p, nout * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(mz, dmz.p, nout * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    MBFIR_HIP(hipGetLastError());
+}
+
 // fp64 peak microbenchmarks (roofline denominators; the local hardware guide lists no fp64
 // matrix peak).  One wave per SIMD, 8 independent accumulators, operands in registers.
 __global__ __launch_bounds__(256) void k_peak_mfma(double* out, int iters) {

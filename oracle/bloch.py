@@ -60,3 +60,91 @@ def hard_pulse_ab(rf, x):
         S = 1j * np.exp(1j * np.angle(rf[m])) * np.sin(th / 2)
         a, b = C * a - np.conj(S) * zi * b, S * a + C * zi * b
     return a, b
+
+
+# ---- Bloch-equation simulator with relaxation (bloch_simulation/blochC.c, blochH.c) ----------------------
+# NumPy restatement of calcrotmat (blochC.c:171-236), blochsim (:283-418) and blochsimfz (:422-512), vectorised
+# over the (frequency, position) pairs.  Parity unpinned against reference outputs: the file holds the MEX
+# gateway and includes mex.h, so it cannot be compiled here; what pins it is the closed loop with abrm above
+# (no relaxation: the same rotation per sample) and the analytic free-precession / recovery solution.
+GAMMA_C13 = 6726.1          # blochC.c:5   (rad/s/G)
+GAMMA_H1 = 26754.0          # blochH.c:6
+TWOPI_REF = 6.283185        # blochC.c:6 -- the reference's truncated constant, kept
+
+
+def calcrotmat(nx, ny, nz):
+    """Rotation by |n| about n (blochC.c:171-236) for arrays of axes; returns R with shape (..., 3, 3),
+    R[..., i, j] = the reference's column-major rmat[i + 3 j]."""
+    nx, ny, nz = np.broadcast_arrays(np.asarray(nx, float), np.asarray(ny, float), np.asarray(nz, float))
+    phi = np.sqrt(nx * nx + ny * ny + nz * nz)
+    safe = np.where(phi > 0, phi, 1.0)
+    hp = phi / 2
+    cp = np.cos(hp)
+    sp = np.sin(hp) / safe
+    ar, ai, br, bi = cp, -nz * sp, ny * sp, -nx * sp
+    R = np.empty(phi.shape + (3, 3))
+    R[..., 0, 0] = ar * ar - ai * ai - br * br + bi * bi
+    R[..., 1, 0] = -2 * ar * ai - 2 * br * bi
+    R[..., 2, 0] = -2 * ar * br + 2 * ai * bi
+    R[..., 0, 1] = 2 * ar * ai - 2 * br * bi
+    R[..., 1, 1] = ar * ar - ai * ai + br * br - bi * bi
+    R[..., 2, 1] = -2 * ai * br - 2 * ar * bi
+    R[..., 0, 2] = 2 * ar * br + 2 * ai * bi
+    R[..., 1, 2] = 2 * ar * bi - 2 * ai * br
+    R[..., 2, 2] = ar * ar + ai * ai - br * br - bi * bi
+    R[phi == 0] = np.eye(3)
+    return R
+
+
+def blochsimfz(b1, grad, tsteps, t1, t2, df, pos, mode=0, m0=None, gamma=GAMMA_C13):
+    """[mx, my, mz] = bloch(b1, grad, tsteps, t1, t2, df, pos, mode, mx0, my0, mz0)  (blochC.c:422-512).
+    b1 complex (Gauss), grad (ntime, 3) or None (G/cm), tsteps interval lengths (s, scalar or ntime), df (Hz),
+    pos (npos, 3) (cm), mode bit 0: steady state, bit 1: record every time point; m0 (nfreq, npos, 3) or None
+    (= equilibrium [0 0 1]).  Returns m of shape (nfreq, npos, ntout, 3), ntout = ntime if mode & 2 else 1."""
+    b1 = np.asarray(b1, dtype=np.complex128).ravel()
+    nt = len(b1)
+    grad = np.zeros((nt, 3)) if grad is None else np.asarray(grad, float).reshape(nt, -1)
+    if grad.shape[1] < 3:
+        grad = np.concatenate([grad, np.zeros((nt, 3 - grad.shape[1]))], 1)
+    ts = np.broadcast_to(np.asarray(tsteps, float).ravel(), (nt,)) if np.size(tsteps) in (1, nt) else None
+    df = np.asarray(df, float).ravel()
+    pos = np.asarray(pos, float).reshape(-1, 3) if np.ndim(pos) > 0 and np.size(pos) % 3 == 0 and np.ndim(pos) == 2 \
+        else np.stack([np.asarray(pos, float).ravel(), np.zeros(np.size(pos)), np.zeros(np.size(pos))], 1)
+    nf, npos = len(df), len(pos)
+    e1 = np.exp(-ts / t1)                                                 # :460-464
+    e2 = np.exp(-ts / t2)
+    m = np.zeros((nf, npos, 3))
+    m[..., 2] = 1.0
+    if m0 is not None:
+        m = np.array(m0, dtype=float).reshape(nf, npos, 3)
+    gpos = pos * gamma                                                    # :317-319 gammadx ...
+
+    def run(mstart, sim_mode):
+        """blochsim for every (f, p): sim_mode 0 endpoint, 1 steady state, 2 all time points."""
+        A = np.broadcast_to(np.eye(3), (nf, npos, 3, 3)).copy()
+        B = np.zeros((nf, npos, 3))
+        mc = mstart.copy()
+        out = np.zeros((nf, npos, nt, 3)) if sim_mode == 2 else None
+        for t in range(nt):
+            rotz = -((grad[t] @ gpos.T)[None, :] + df[:, None] * TWOPI_REF) * ts[t]      # :330-331
+            rotx = -b1[t].real * gamma * ts[t]                                           # :332
+            roty = b1[t].imag * gamma * ts[t]                                            # :333
+            R = calcrotmat(rotx, roty, rotz)
+            dec = np.array([e2[t], e2[t], e1[t]])
+            if sim_mode == 1:
+                A = dec[:, None] * (R @ A)                                               # :336-356
+                B = dec * np.einsum("fpij,fpj->fpi", R, B)
+                B[..., 2] += 1 - e1[t]
+            else:
+                mc = dec * np.einsum("fpij,fpj->fpi", R, mc)
+                mc[..., 2] += 1 - e1[t]
+                if sim_mode == 2:
+                    out[:, :, t] = mc
+        if sim_mode == 1:                                                                # :406-415  M = inv(I - A) B
+            return np.linalg.solve(np.eye(3) - A, B[..., None])[..., 0]
+        return out if sim_mode == 2 else mc
+
+    if mode == 3:                                                                        # :477-490
+        return run(run(m, 1), 2)
+    r = run(m, mode)
+    return r if mode == 2 else r[:, :, None, :]

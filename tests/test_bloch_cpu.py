@@ -118,3 +118,72 @@ def test_dzrf_mb_argument_errors_need_no_gpu():
         mbfir.dzrf_mb(128, 0.5, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "sat", "ap_cvx", "H-1")      # fs/2 = 1 kHz < 1.7 kHz
     with pytest.raises(ValueError, match="broken in the reference"):
         mbfir.dzrf_mb(128, 0.05, cf, [0.4, 0.4], [0, 90], [0.01, 0.01], "st", "ap_cvx", "H-1")
+
+
+# ---- blochsimfz restatement (oracle/bloch.py; bloch_simulation/blochC.c:171-236,283-512) -----------------
+def test_calcrotmat_is_a_proper_rotation_about_its_axis():
+    rng = np.random.default_rng(1)
+    n = rng.standard_normal((50, 3)) * rng.uniform(0, 4, (50, 1))
+    R = bloch.calcrotmat(n[:, 0], n[:, 1], n[:, 2])
+    assert np.abs(R @ np.transpose(R, (0, 2, 1)) - np.eye(3)).max() <= 1e-14
+    assert np.abs(np.linalg.det(R) - 1).max() <= 1e-14
+    assert np.abs(np.einsum("kij,kj->ki", R, n) - n).max() <= 1e-13          # the axis is fixed
+    assert np.array_equal(bloch.calcrotmat(0.0, 0.0, 0.0), np.eye(3))         # blochC.c:182-193
+    # right-handed rotation by |n| about n (rmat[1] = -arai2 = +sin for n = z); off-resonance enters as rotz = -2 pi df dt
+    Rz = bloch.calcrotmat(0.0, 0.0, 0.3)
+    assert np.allclose(Rz @ [1, 0, 0], [np.cos(0.3), np.sin(0.3), 0])
+
+
+def test_blochsimfz_free_precession_and_relaxation_are_analytic():
+    nt, ts, t1, t2 = 80, 0.5e-3, 0.3, 0.05
+    df = np.array([0.0, 10.0, -35.0, 400.0])
+    m0 = np.zeros((4, 1, 3))
+    m0[:, 0, 0] = 1.0
+    m = bloch.blochsimfz(np.zeros(nt), None, ts, t1, t2, df, np.zeros((1, 3)), 0, m0)
+    T = nt * ts
+    ph = -df * bloch.TWOPI_REF * T
+    assert np.abs(m[:, 0, 0, 0] - np.exp(-T / t2) * np.cos(ph)).max() <= 1e-13
+    assert np.abs(m[:, 0, 0, 1] - np.exp(-T / t2) * np.sin(ph)).max() <= 1e-13
+    assert np.abs(m[:, 0, 0, 2] - (1 - np.exp(-T / t1))).max() <= 1e-13
+    # a gradient acts like an off-resonance gamma G x / TWOPI
+    G, x = 0.2, 1.7
+    mg = bloch.blochsimfz(np.zeros(nt), np.full((nt, 1), G), ts, t1, t2, [0.0], np.array([[x, 0, 0]]), 0, m0[:1])
+    mf = bloch.blochsimfz(np.zeros(nt), None, ts, t1, t2, [bloch.GAMMA_C13 * G * x / bloch.TWOPI_REF], np.zeros((1, 3)), 0, m0[:1])
+    assert np.abs(mg - mf).max() <= 1e-12
+
+
+def test_blochsimfz_without_relaxation_is_the_cayley_klein_simulation():
+    """T1 = T2 -> infinity: the same rotation per sample as rf_tools/abrm.m, so Mxy = 2 a conj(b), Mz = 1 - 2 |b|^2
+    (abr.m:11-12 up to the conjugation of the two simulators' axis conventions)."""
+    rng = np.random.default_rng(0)
+    n = 64
+    rf = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.05          # radians per sample
+    dt = 4e-3 / n
+    dfs = np.linspace(-800, 800, 11)
+    m = bloch.blochsimfz(rf / (bloch.GAMMA_C13 * dt), None, dt, 1e12, 1e12, dfs, np.zeros((1, 3)), 0)
+    a, b = bloch.abrm(rf, np.ones(n) * dt * bloch.TWOPI_REF, dfs)
+    assert np.abs(m[:, 0, 0, 0] + 1j * m[:, 0, 0, 1] - 2 * a * np.conj(b)).max() <= 1e-11
+    assert np.abs(m[:, 0, 0, 2] - (1 - 2 * np.abs(b) ** 2)).max() <= 1e-11
+
+
+def test_blochsimfz_modes():
+    """mode 2 records every sample and ends at the mode-0 endpoint; mode 1 returns the periodic steady state
+    (one more period reproduces it); mode 3 = that steady state followed through the period."""
+    rng = np.random.default_rng(3)
+    nt = 40
+    b1 = (rng.standard_normal(nt) + 1j * rng.standard_normal(nt)) * 0.02
+    gr = rng.standard_normal((nt, 3)) * 0.1
+    ts = rng.uniform(0.5e-4, 2e-4, nt)
+    df = np.array([-120.0, 0.0, 77.0])
+    pos = rng.standard_normal((2, 3))
+    args = (b1, gr, ts, 0.08, 0.03, df, pos)
+    m0 = bloch.blochsimfz(*args, 0)
+    m2 = bloch.blochsimfz(*args, 2)
+    assert m0.shape == (3, 2, 1, 3) and m2.shape == (3, 2, nt, 3)
+    assert np.abs(m2[:, :, -1] - m0[:, :, 0]).max() <= 1e-15
+    ss = bloch.blochsimfz(*args, 1)
+    again = bloch.blochsimfz(*args, 0, ss[:, :, 0])
+    assert np.abs(again - ss).max() <= 1e-13
+    m3 = bloch.blochsimfz(*args, 3)
+    assert np.abs(m3[:, :, -1] - ss[:, :, 0]).max() <= 1e-13
+    assert np.abs(m3 - bloch.blochsimfz(*args, 2, ss[:, :, 0])).max() <= 1e-15

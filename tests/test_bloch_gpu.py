@@ -139,3 +139,44 @@ def test_dzrf_mb_downsampled_design():
     rf_pulse, b, rf_spec, b_spec = mbfir.dzrf_mb(160, 0.04, cf, rng, FA, rp, "ex", "ap_cvx", "C-13", 0, 2)
     assert len(rf_pulse) == len(b) == 160
     check_profile(rf_pulse, 0.04, 1.0705, rf_spec, slack=1.5)                         # resample's pass-band droop
+
+
+# ---- mbfir_bloch: the device twin of bloch_simulation/blochC.c (blochsimfz) --------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_device_bloch_matches_the_oracle_in_every_mode(mode):
+    rng = np.random.default_rng(10 + mode)
+    nt = 300                                                 # more than one LDS chunk of 256 samples
+    b1 = (rng.standard_normal(nt) + 1j * rng.standard_normal(nt)) * 0.02
+    gr = rng.standard_normal((nt, 3)) * 0.1
+    ts = rng.uniform(0.5e-4, 2e-4, nt)
+    df = np.linspace(-500, 500, 37)
+    pos = rng.standard_normal((5, 3))
+    m0 = rng.standard_normal((37, 5, 3)) * 0.3
+    ref = bloch.blochsimfz(b1, gr, ts, 0.08, 0.03, df, pos, mode, m0)
+    mx, my, mz = mbfir.bloch(b1, gr, ts, 0.08, 0.03, df, pos, mode, m0[..., 0], m0[..., 1], m0[..., 2])
+    got = np.stack([mx, my, mz], -1).reshape(ref.shape)
+    assert np.abs(got - ref).max() <= 1e-12
+    # end times instead of intervals (blochC.c:669-681) and the H-1 constant (blochH.c:6)
+    refh = bloch.blochsimfz(b1, gr[:, :1], ts, 0.5, 0.1, df, pos[:, :1], mode & 2, gamma=bloch.GAMMA_H1)
+    mx, my, mz = mbfir.bloch(b1, gr[:, 0], np.cumsum(ts), 0.5, 0.1, df, pos[:, 0], mode & 2, nucleus="H-1")
+    assert np.abs(np.stack([mx, my, mz], -1).reshape(refh.shape) - refh).max() <= 1e-12
+
+
+def test_device_bloch_closes_the_loop_with_abr_as_sim_rf_spectral_runs_it():
+    """sim_rf_spectral.m:63-78 simulates the designed pulse with T1 = T2 = 1e3 s over 2048 off-resonances.  Without
+    relaxation blochsimfz applies the same rotation per sample as abrm.m, so |Mxy| = 2 |a b| and Mz = 1 - 2 |b|^2 of
+    mbfir_abr; with T1 = T2 = 1e3 s and a 4 ms pulse the relaxation moves that by 4e-6."""
+    n = 58
+    f, a, d = mbfir.spec.spec_c13_bssfp(n) if hasattr(mbfir.spec, "spec_c13_bssfp") else (None, None, None)
+    h, status = mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3)
+    assert status == "Solved"
+    rf = np.asarray(mbfir.b2rf(h[::-1])).ravel()                  # radians per sample (dzrf_mb.m:220,239-240)
+    dt = 4e-3 / n
+    b1 = rf / (mbfir.GAMMA_C13 * dt)                              # Gauss (rfscaleg)
+    df = np.linspace(-3000, 3000, 2048)                           # N_simu = 256*8 (sim_rf_spectral.m:63)
+    av, bv = mbfir.abrm(rf, np.ones(n) * dt * 6.283185, df)
+    for T, tol in ((1e3, 1e-5), (1e12, 1e-10)):
+        mx, my, mz = mbfir.bloch(b1, np.zeros(n), dt, T, T, df, 0.0, 0)
+        assert mx.shape == (2048, 1)
+        assert np.abs(mx[:, 0] + 1j * my[:, 0] - 2 * av * np.conj(bv)).max() <= tol
+        assert np.abs(mz[:, 0] - (1 - 2 * np.abs(bv) ** 2)).max() <= tol

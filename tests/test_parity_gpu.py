@@ -242,6 +242,49 @@ def test_config3_h1_dualband_qp_form_full_size(key):
     assert abs(P["c"] @ z - info["pcost"]) <= 1e-9 * abs(info["pcost"])
 
 
+def test_config4_full_sweep_of_256_designs():
+    """BASELINE config 4 at its stated size: 256 independent n=200, m=4096 designs = 16 Peak values log-spaced in
+    [1e-4, 1e-2] (bSSFP_pulse_diff_Peak.m:68-77 sweeps Peak) x 16 ripple pairs (d1, d2) = (0.01, 0.005) 2^(j/4)
+    (SURVEY 8d), handed to mbfir_solve_batch as one batch.  Every result is checked against the program itself
+    (primal feasibility of the returned autocorrelation for the reference's constraints, objective, certificate);
+    eight of them, spread over the grid, against the live oracle's taps."""
+    n, m = 200, 4096
+    peaks = np.logspace(-4, -2, 16)
+    jobs, keys = [], []
+    for j in range(16):
+        f, a, d = mbfir.spec.spec_c13_bssfp(n, d1=0.01 * 2 ** (j / 4), d2=0.005 * 2 ** (j / 4))
+        for pk in peaks:
+            jobs.append(("fir_ap_cvx", (n, f, a, d, 0.1, float(pk))))
+            keys.append((j, float(pk)))
+    res = mbfir.solve_batch(jobs, streams=4, info=True, solutions=True, opts=mbfir.make_opts(grid_m=m))
+    assert len(res) == 256
+    cost = {}
+    for key, job, (h, status, info, z) in zip(keys, jobs, res):
+        assert status == "Solved" and h.shape == (n,), key
+        assert info["pres"] <= 1e-8 and info["dres"] <= 1e-8 and (info["gap"] <= 1e-10 or info["relgap"] <= 1e-8), key
+        _check_ap_solution(*job[1], m, info, z)
+        cost[key] = info["pcost"]
+    for j in range(16):                                           # a looser end-spike bound can only lower the optimum
+        c = [cost[(j, float(pk))] for pk in peaks]
+        assert all(c[i] >= c[i + 1] - 1e-9 for i in range(15)), j
+    for q in (0, 37, 74, 111, 148, 185, 222, 255):
+        ho, so = designers.fir_ap_cvx(*jobs[q][1], grid_m=m)
+        assert so == "Solved"
+        assert relinf(res[q][0], ho) <= TAP_TOL, keys[q]
+
+
+def test_config1_linear_phase_lp_at_512_grid_points():
+    """BASELINE config 1 as stated: n=64 linear-phase LP (ss/fir_linprog.m), single passband, m=512 frequencies
+    (the reference's own grid rule gives 960 + edges -- golden case lin_real64; this is the synthetic size)."""
+    args = (64, [0, 0.2, 0.3, 1], [1, 1, 0, 0], [0.01, 0.01])
+    ho, so, io = designers.fir_linprog(*args, grid_m=512, info=True)
+    hg, sg, info = mbfir.fir_linprog(*args, opts=mbfir.make_opts(grid_m=512), info=True)
+    assert so == sg == "Solved" and info["n_freq"] == 512 + 4
+    assert hg.shape == (64,) and np.abs(hg.imag).max() == 0 and np.allclose(hg, hg[::-1], rtol=0, atol=0)   # real, symmetric
+    assert abs(info["pcost"] - io["pcost"]) <= 1e-9 * max(1.0, abs(io["pcost"]))
+    assert relinf(hg, ho) <= TAP_TOL
+
+
 def test_config4_peak_ripple_sweep_as_one_batch():
     """BASELINE config 4 (bSSFP_pulse_diff_Peak.m:68 sweep) in miniature: n=200 designs over a Peak x ripple
     grid handed to mbfir_solve_batch; every job equals its single-call result, and a looser end-spike
