@@ -66,6 +66,9 @@ typedef struct mbfir_opts {
     int ddkkt;         /* extended-precision (double-double) KKT solve for nearly active cones whose NT weights
                           exceed 1e6 x the typical weight (fir_qp_cvx's error cones):
                           0 = automatic (on for mbfir_qp_solve, off for the other designers), 1 = on, -1 = off */
+    int lanes;         /* mbfir_solve_batch: designs of one shape that advance in LOCK STEP on one context (one stream,
+                          one launch per phase, the design index a grid dimension).  0 = automatic (as many as the
+                          shape allows while every context still gets a unit), 1 = never, k > 1 = k per unit   */
 } mbfir_opts;
 
 /* Per-solve report. */
@@ -92,6 +95,8 @@ typedef struct mbfir_info {
     int builds;          /* normal-matrix builds (= iterations + 1)                                       */
     int dd_iters;        /* iterations that ran the extended-precision KKT solve (opts.ddkkt)              */
     int dd_kmax;         /* largest number of strong eigen-directions it carried                          */
+    int lanes;           /* designs that shared this design's lock-step batch (ms_solve, ms_gram, ms_chol are then
+                            those of the whole batch)                                                      */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to

@@ -38,7 +38,7 @@ class Opts(C.Structure):
     _fields_ = [("grid_m", C.c_int), ("max_iter", C.c_int), ("feastol", C.c_double),
                 ("abstol", C.c_double), ("reltol", C.c_double), ("refine", C.c_int),
                 ("verbose", C.c_int), ("shard_rank", C.c_int), ("shard_size", C.c_int),
-                ("dense_trig", C.c_int), ("ddkkt", C.c_int)]
+                ("dense_trig", C.c_int), ("ddkkt", C.c_int), ("lanes", C.c_int)]
 
 
 class Info(C.Structure):
@@ -51,7 +51,7 @@ class Info(C.Structure):
                 ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
                 ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("lattice", C.c_int),
                 ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int),
-                ("dd_iters", C.c_int), ("dd_kmax", C.c_int)]
+                ("dd_iters", C.c_int), ("dd_kmax", C.c_int), ("lanes", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

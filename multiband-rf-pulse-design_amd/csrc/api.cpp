@@ -6,8 +6,10 @@
 #include <chrono>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <thread>
 
@@ -76,7 +78,42 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->gram_launches = si.lattice ? 0 : si.h_builds * (P.quad ? 3 : 1);
     info->lattice = si.lattice;
     info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
-    info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax;
+    info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes;
+}
+
+// Solution vector -> taps, per designer.  lane: which design of the solver's last lock-step batch (fir_ap_cvx runs
+// the spectral factorisation on the device from the solution left there).
+void taps_from_solution(Solver& solver, const TrigProgram& P, const std::vector<double>& x, int lane, double* h_re, double* h_im) {
+    const int n = P.n;
+    switch (P.which) {
+        case DES_AP:
+            solver.specfact_last(n, h_re, h_im, lane);           // fir_ap_cvx.m:185-186,202
+            break;
+        case DES_LINPROG: {
+            // fill_h, ss/fir_linprog.m:274-296: Hermitian extension of the half filter
+            const int nh = P.nhalf;
+            for (int i = 0; i < n; ++i) { h_re[i] = 0; h_im[i] = 0; }
+            if (P.real_filter) {
+                if (P.odd_filter) for (int k = 0; k < nh; ++k) { h_re[nh - 1 + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
+                else for (int k = 0; k < nh; ++k) { h_re[nh + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
+            } else if (P.odd_filter) {
+                for (int k = 0; k < nh; ++k) {
+                    double re = x[k], im = k == 0 ? 0.0 : x[nh + k - 1];
+                    h_re[nh - 1 + k] = re; h_im[nh - 1 + k] = im;
+                    h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
+                }
+            } else {
+                for (int k = 0; k < nh; ++k) {
+                    double re = x[k], im = x[nh + k];
+                    h_re[nh + k] = re; h_im[nh + k] = im;
+                    h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
+                }
+            }
+            break;
+        }
+        default:                                                 // fir_qp_cvx.m:209, ss/fir_qprog_phs.m:389
+            for (int i = 0; i < n; ++i) { h_re[i] = x[i]; h_im[i] = x[n + i]; }
+    }
 }
 
 // Common driver: `asm_rc` is the assembly result, `post` maps the solution vector to taps.
@@ -175,9 +212,7 @@ int mbfir_ap_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const doub
     TrigProgram P;
     std::string e;
     int rc = assemble_ap(n, nband, f, a, d, obj, peak, opts ? opts->grid_m : 0, P, e);
-    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>&) {
-        ctx->solver->specfact_last(n, h_re, h_im);           // fir_ap_cvx.m:185-186,202
-    });
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) { taps_from_solution(*ctx->solver, P, x, 0, h_re, h_im); });
 }
 
 int mbfir_qp_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,
@@ -187,9 +222,7 @@ int mbfir_qp_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const doub
     TrigProgram P;
     std::string e;
     int rc = assemble_qp(n, nband, f, a, d, kquad, obj, nobj, opts ? opts->grid_m : 0, P, e);
-    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
-        for (int i = 0; i < n; ++i) { h_re[i] = x[i]; h_im[i] = x[n + i]; }     // fir_qp_cvx.m:209
-    });
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) { taps_from_solution(*ctx->solver, P, x, 0, h_re, h_im); });
 }
 
 int mbfir_linprog_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* a, const double* d,
@@ -198,27 +231,7 @@ int mbfir_linprog_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const
     TrigProgram P;
     std::string e;
     int rc = assemble_linprog(n, nband, f, a, d, opts ? opts->grid_m : 0, P, e);
-    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
-        // fill_h, ss/fir_linprog.m:274-296: Hermitian extension of the half filter
-        const int nh = P.nhalf;
-        for (int i = 0; i < n; ++i) { h_re[i] = 0; h_im[i] = 0; }
-        if (P.real_filter) {
-            if (P.odd_filter) for (int k = 0; k < nh; ++k) { h_re[nh - 1 + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
-            else for (int k = 0; k < nh; ++k) { h_re[nh + k] = x[k]; h_re[nh - 1 - k] = x[k]; }
-        } else if (P.odd_filter) {
-            for (int k = 0; k < nh; ++k) {
-                double re = x[k], im = k == 0 ? 0.0 : x[nh + k - 1];
-                h_re[nh - 1 + k] = re; h_im[nh - 1 + k] = im;
-                h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
-            }
-        } else {
-            for (int k = 0; k < nh; ++k) {
-                double re = x[k], im = x[nh + k];
-                h_re[nh + k] = re; h_im[nh + k] = im;
-                h_re[nh - 1 - k] = re; h_im[nh - 1 - k] = -im;
-            }
-        }
-    });
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) { taps_from_solution(*ctx->solver, P, x, 0, h_re, h_im); });
 }
 
 int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f, const double* ac_re,
@@ -228,56 +241,146 @@ int mbfir_qprog_phs_solve(mbfir_ctx* ctx, int n, int nband, const double* f, con
     TrigProgram P;
     std::string e;
     int rc = assemble_qprog_phs(n, nband, f, ac_re, ac_im, dc_re, dc_im, opts ? opts->grid_m : 0, P, e);
-    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) {
-        for (int i = 0; i < n; ++i) { h_re[i] = x[i]; h_im[i] = x[n + i]; }     // ss/fir_qprog_phs.m:389
-    });
+    return run(ctx, rc, e, P, opts, info, t0, [&](const std::vector<double>& x) { taps_from_solution(*ctx->solver, P, x, 0, h_re, h_im); });
 }
 
 // ---- batch of independent designs --------------------------------------------------------------
-// One host thread per context pulls jobs from a shared counter; every context owns a HIP stream, so
-// the latency-bound phases of different designs (Cholesky panels, reductions, the host's
-// per-iteration check) overlap on the device.  Measured on MI355X: 4 contexts give 3.3x the
-// single-stream design rate at n=512, m=16384.
+// The jobs are assembled on the host, grouped by shape (Solver::shape_key: same dimensions, same lattice
+// structure) and cut into units of up to `lanes` designs.  A unit of one design runs as a single solve; a unit of
+// several runs in LOCK STEP on one context: one stream, one launch per phase with the design index as a grid
+// dimension, finished designs masked out (Solver::solve_lanes).  One host thread per context pulls units from a
+// shared counter, so units also overlap across the contexts' streams.  The dependency-chain phases of one design
+// (Cholesky panels, reductions) leave most of the chip idle; the other lanes' blocks fill it.
+static int one_job(mbfir_ctx* ctx, mbfir_job& J, const mbfir_opts* opts) {
+    switch (J.which) {
+        case DES_AP:
+            return mbfir_ap_solve(ctx, J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params[1], opts, J.h_re, J.h_im, &J.info);
+        case DES_QP:
+            return mbfir_qp_solve(ctx, J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params + 1, int(J.params[3]), opts, J.h_re, J.h_im, &J.info);
+        case DES_LINPROG:
+            return mbfir_linprog_solve(ctx, J.n, J.nband, J.f, J.a, J.d, opts, J.h_re, J.h_im, &J.info);
+        case DES_QPROG_PHS: {
+            std::vector<double> are(2 * J.nband), aim(2 * J.nband), dre(J.nband), dim(J.nband);
+            for (int i = 0; i < 2 * J.nband; ++i) { are[i] = J.a[2 * i]; aim[i] = J.a[2 * i + 1]; }
+            for (int i = 0; i < J.nband; ++i) { dre[i] = J.d[2 * i]; dim[i] = J.d[2 * i + 1]; }
+            return mbfir_qprog_phs_solve(ctx, J.n, J.nband, J.f, are.data(), aim.data(), dre.data(), dim.data(), opts, J.h_re, J.h_im, &J.info);
+        }
+        default: return MBFIR_E_ARG;
+    }
+}
+static int assemble_job(const mbfir_job& J, int grid_m, TrigProgram& P, std::string& e) {
+    switch (J.which) {
+        case DES_AP: return assemble_ap(J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params[1], grid_m, P, e);
+        case DES_QP: return assemble_qp(J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params + 1, int(J.params[3]), grid_m, P, e);
+        case DES_LINPROG: return assemble_linprog(J.n, J.nband, J.f, J.a, J.d, grid_m, P, e);
+        case DES_QPROG_PHS: {
+            std::vector<double> are(2 * J.nband), aim(2 * J.nband), dre(J.nband), dim(J.nband);
+            for (int i = 0; i < 2 * J.nband; ++i) { are[i] = J.a[2 * i]; aim[i] = J.a[2 * i + 1]; }
+            for (int i = 0; i < J.nband; ++i) { dre[i] = J.d[2 * i]; dim[i] = J.d[2 * i + 1]; }
+            return assemble_qprog_phs(J.n, J.nband, J.f, are.data(), aim.data(), dre.data(), dim.data(), grid_m, P, e);
+        }
+        default: e = "unknown designer"; return MBFIR_E_ARG;
+    }
+}
+
 int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njobs, const mbfir_opts* opts) {
     if (!ctxs || nctx < 1 || (!jobs && njobs > 0) || njobs < 0) return MBFIR_E_ARG;
     for (int c = 0; c < nctx; ++c)
         if (!ctxs[c]) return MBFIR_E_ARG;
+    const double t0 = now_ms();
+    const bool sharded = opts && opts->shard_size > 1;
+    int lanes_cap = opts && opts->lanes != 0 ? opts->lanes : 0;              // 0 = automatic, 1 = never lock-step
+    if (const char* ev = std::getenv("MBFIR_LANES")) lanes_cap = std::atoi(ev);
+    // ---- host assembly, in parallel --------------------------------------------------------------
+    std::vector<TrigProgram> progs(njobs);
+    std::vector<int> arc(njobs, 0);
+    {
+        std::atomic<int> next(0);
+        auto asm_work = [&]() {
+            for (;;) {
+                const int q = next.fetch_add(1);
+                if (q >= njobs) break;
+                std::string e;
+                jobs[q].err[0] = 0;
+                arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
+                if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
+            }
+        };
+        const int nth = std::max(1, std::min(njobs, std::min(8, int(std::thread::hardware_concurrency()))));
+        std::vector<std::thread> th;
+        for (int c = 1; c < nth; ++c) th.emplace_back(asm_work);
+        asm_work();
+        for (auto& t : th) t.join();
+    }
+    // ---- units: designs of one shape, up to `lanes` of them ------------------------------------------
+    std::vector<std::vector<int>> units;
+    if (sharded || lanes_cap == 1) {
+        for (int q = 0; q < njobs; ++q) units.push_back({q});
+    } else {
+        std::map<std::vector<long>, std::vector<int>> groups;
+        for (int q = 0; q < njobs; ++q) {
+            if (arc[q] != 0) { units.push_back({q}); continue; }             // the single-design path reports the assembly error
+            const SolveOpts so = to_opts(opts, progs[q].which);
+            std::vector<long> key = Solver::shape_key(progs[q], so);
+            key.push_back(Solver::max_lanes(progs[q], so));
+            groups[key].push_back(q);
+        }
+        for (auto& g : groups) {
+            const int cap = int(g.first.back()), G = int(g.second.size());
+            // enough units to occupy every context, no more lanes per unit than the shape allows
+            int per = std::min(cap, std::max(1, (G + nctx - 1) / nctx));
+            if (lanes_cap > 1) per = std::min(std::min(lanes_cap, 64), G);
+            for (int i = 0; i < G; i += per) units.emplace_back(g.second.begin() + i, g.second.begin() + std::min(G, i + per));
+        }
+    }
     std::atomic<int> next(0);
     auto work = [&](int c) {
+        mbfir_ctx* ctx = ctxs[c];
         for (;;) {
-            const int q = next.fetch_add(1);
-            if (q >= njobs) break;
-            mbfir_job& J = jobs[q];
-            switch (J.which) {
-                case DES_AP:
-                    J.rc = mbfir_ap_solve(ctxs[c], J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params[1], opts, J.h_re, J.h_im, &J.info);
-                    break;
-                case DES_QP:
-                    J.rc = mbfir_qp_solve(ctxs[c], J.n, J.nband, J.f, J.a, J.d, J.params[0], J.params + 1, int(J.params[3]), opts,
-                                          J.h_re, J.h_im, &J.info);
-                    break;
-                case DES_LINPROG:
-                    J.rc = mbfir_linprog_solve(ctxs[c], J.n, J.nband, J.f, J.a, J.d, opts, J.h_re, J.h_im, &J.info);
-                    break;
-                case DES_QPROG_PHS: {
-                    std::vector<double> are(2 * J.nband), aim(2 * J.nband), dre(J.nband), dim(J.nband);
-                    for (int i = 0; i < 2 * J.nband; ++i) { are[i] = J.a[2 * i]; aim[i] = J.a[2 * i + 1]; }
-                    for (int i = 0; i < J.nband; ++i) { dre[i] = J.d[2 * i]; dim[i] = J.d[2 * i + 1]; }
-                    J.rc = mbfir_qprog_phs_solve(ctxs[c], J.n, J.nband, J.f, are.data(), aim.data(), dre.data(), dim.data(), opts,
-                                                 J.h_re, J.h_im, &J.info);
-                    break;
+            const int u = next.fetch_add(1);
+            if (u >= int(units.size())) break;
+            const std::vector<int>& U = units[u];
+            auto finish_job = [&](int q) {
+                mbfir_job& J = jobs[q];
+                if (J.rc < 0 && !J.err[0]) std::snprintf(J.err, sizeof(J.err), "%s", ctx->err.c_str());
+                if (J.z && J.z_cap > 0 && J.rc >= 0) {
+                    const std::vector<double>& x = ctx->last_x;
+                    std::memcpy(J.z, x.data(), sizeof(double) * std::min<size_t>(x.size(), size_t(J.z_cap)));
                 }
-                default: J.rc = MBFIR_E_ARG;
+            };
+            if (U.size() == 1) {
+                jobs[U[0]].rc = one_job(ctx, jobs[U[0]], opts);
+                finish_job(U[0]);
+                continue;
             }
-            J.err[0] = 0;
-            if (J.rc < 0) std::snprintf(J.err, sizeof(J.err), "%s", ctxs[c]->err.c_str());
-            if (J.z && J.z_cap > 0 && J.rc >= 0) {
-                const std::vector<double>& x = ctxs[c]->last_x;
-                std::memcpy(J.z, x.data(), sizeof(double) * std::min<size_t>(x.size(), size_t(J.z_cap)));
+            try {
+                const double t_asm = now_ms();
+                std::vector<const TrigProgram*> Ps;
+                for (int q : U) Ps.push_back(&progs[q]);
+                std::vector<std::vector<double>> xs;
+                std::vector<SolveInfo> sis;
+                const SolveOpts so = to_opts(opts, progs[U[0]].which);
+                ctx->solver->solve_lanes(Ps, so, xs, sis);
+                const double t_solved = now_ms();
+                std::vector<int> redo;
+                for (size_t b = 0; b < U.size(); ++b) {
+                    mbfir_job& J = jobs[U[b]];
+                    const int rc = status_to_rc(sis[b].status);
+                    if (rc == MBFIR_NUMERICAL) { redo.push_back(U[b]); continue; }   // single path: retries on the dense path
+                    if (rc == MBFIR_SOLVED) taps_from_solution(*ctx->solver, progs[U[b]], xs[b], int(b), J.h_re, J.h_im);
+                    fill_info(&J.info, progs[U[b]], sis[b], rc, t0, t_asm, t_solved, now_ms());
+                    J.rc = rc;
+                    ctx->last_x = xs[b];
+                    finish_job(U[b]);
+                }
+                for (int q : redo) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
+            } catch (const std::exception& e) {
+                ctx->err = e.what();
+                for (int q : U) { jobs[q].rc = MBFIR_E_HIP; jobs[q].info.status = MBFIR_E_HIP; finish_job(q); }
             }
         }
     };
-    const int nthreads = nctx < njobs ? nctx : njobs;
+    const int nthreads = std::min(nctx, int(units.size()));
     std::vector<std::thread> th;
     for (int c = 1; c < nthreads; ++c) th.emplace_back(work, c);
     if (nthreads > 0) work(0);

@@ -3,6 +3,7 @@
 // two triangular GEMVs (x = M'(M b)) instead of two latency-bound substitutions.
 // All fp64; tile products on v_mfma_f64_16x16x4_f64.
 #include "dev_common.h"
+#include <type_traits>
 
 namespace mbfir {
 
@@ -294,6 +295,8 @@ struct CholStep {
     double* dinvG;           // 1 / diag(L)
     int* flag;
     int nP, nMS, nT;
+    size_t lane_bytes;       // lock-step batch: blockIdx.y = lane, every pointer moves by lane * lane_bytes
+    const int* mask;         // nlanes ints (or null): lanes switched off
 };
 
 constexpr int YLD = 65;                                  // staging tiles that are read one row per lane
@@ -465,8 +468,17 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
     *reinterpret_cast<double2*>(dst + 2) = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
 }
 
+template <class T>
+__device__ __forceinline__ T* lane_at(T* p, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + off); }
+
 __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    if (a.mask && !a.mask[blockIdx.y]) return;
+    if (blockIdx.y) {
+        const size_t off = (size_t)blockIdx.y * a.lane_bytes;
+        a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
+        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
+    }
     int b = blockIdx.x;
     if (b < a.nP) { panel_block(a, b, smem); return; }
     b -= a.nP;
@@ -486,7 +498,13 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np);
 }
 
-__global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M) {
+// also clears the lane's pivot-replacement counter
+__global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M,
+                            int* __restrict__ flag, size_t lane_bytes, const int* __restrict__ mask) {
+    if (mask && !mask[blockIdx.y]) return;
+    const size_t off = (size_t)blockIdx.y * lane_bytes;
+    H = lane_at(H, off); d0 = lane_at(d0, off); M = lane_at(M, off); flag = lane_at(flag, off);
+    if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < np) { d0[j] = H[(long)j * np + j]; M[(long)j * np + j] = 1.0; }      // R starts as the identity
 }
@@ -503,8 +521,11 @@ __global__ void k_extract_L(const double* __restrict__ H, int np, const double* 
     Lout[e] = v;
 }
 
-__global__ void k_transpose(const double* __restrict__ M, double* __restrict__ Mt, int np) {
+__global__ void k_transpose(const double* __restrict__ M, double* __restrict__ Mt, int np, size_t lane_bytes,
+                            const int* __restrict__ mask) {
     __shared__ double tile[32][33];
+    if (mask && !mask[blockIdx.z]) return;
+    M = lane_at(M, (size_t)blockIdx.z * lane_bytes); Mt = lane_at(Mt, (size_t)blockIdx.z * lane_bytes);
     int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int r = threadIdx.y; r < 32; r += blockDim.y) tile[r][threadIdx.x] = M[(long)(by + r) * np + bx + threadIdx.x];
     __syncthreads();
@@ -512,16 +533,17 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
 }
 
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy, hipEvent_t e0, hipEvent_t e1) {
+                     double* Lcopy, hipEvent_t e0, hipEvent_t e1, int nlanes, size_t lane_bytes, const int* mask) {
     const int nblk = np / CB;
     // W1 layout: np doubles: original diagonal | 64 np doubles: images of the L_kk blocks | np: 1 / diag(L)
     CholStep a;
     a.H = H; a.M = M; a.np = np; a.nblk = nblk;
     a.d0 = W1; a.Dfac = W1 + np; a.dinvG = W1 + (long)(CB + 1) * np; a.flag = flag;
     a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
-    hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
-    hipMemsetAsync(flag, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, H, np, W1, M);
+    a.lane_bytes = lane_bytes; a.mask = mask;
+    if (nlanes > 1) hipMemset2DAsync(M, lane_bytes, 0, sizeof(double) * np * np, nlanes, st);
+    else hipMemsetAsync(M, 0, sizeof(double) * np * np, st);
+    hipLaunchKernelGGL(k_diag_copy, dim3(cdiv(np, 256), nlanes), dim3(256), 0, st, H, np, W1, M, flag, lane_bytes, mask);
     if (e0) hipEventRecord(e0, st);
     for (int k = 0; k <= nblk; ++k) {
         const int nrem = nblk - k - 1;
@@ -530,18 +552,25 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
         a.nMS = k >= 1 ? 4 * k : 0;
         a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
         const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU, nlanes), dim3(256), 0, st, a);
     }
     if (e1) hipEventRecord(e1, st);
     if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
-    hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32), dim3(32, 8), 0, st, M, Mt, np);
+    hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32, nlanes), dim3(32, 8), 0, st, M, Mt, np, lane_bytes, mask);
 }
 
 // y[v][i] = sum_j T[i][j] b[v][j] over the stored triangle; one wave per row, 16-byte loads.
 template <int NV>
 __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, int np, int upper,
                                                  const double* __restrict__ b, const double* __restrict__ b2,
-                                                 double* __restrict__ y, int ldv) {
+                                                 double* __restrict__ y, int ldv, size_t lane_bytes,
+                                                 const int* __restrict__ mask) {
+    if (mask && !mask[blockIdx.y]) return;
+    if (blockIdx.y) {
+        const size_t off = (size_t)blockIdx.y * lane_bytes;
+        T = lane_at(T, off); b = lane_at(b, off); y = lane_at(y, off);
+        if (b2) b2 = lane_at(b2, off);
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     if (i >= np) return;
@@ -571,10 +600,10 @@ __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, i
 }
 
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
-                    hipStream_t st, const double* b2) {
-    dim3 grid(cdiv(np, 4));
-    if (nv == 1) hipLaunchKernelGGL(k_trigemv<1>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv);
-    else if (nv == 2) hipLaunchKernelGGL(k_trigemv<2>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv);
+                    hipStream_t st, const double* b2, int nlanes, size_t lane_bytes, const int* mask) {
+    dim3 grid(cdiv(np, 4), nlanes);
+    if (nv == 1) hipLaunchKernelGGL(k_trigemv<1>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv, lane_bytes, mask);
+    else if (nv == 2) hipLaunchKernelGGL(k_trigemv<2>, grid, dim3(256), 0, st, T, np, upper, b, b2, y, ldv, lane_bytes, mask);
     else throw HipError("trigemv_launch: nv must be 1 or 2");
 }
 

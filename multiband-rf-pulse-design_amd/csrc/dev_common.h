@@ -85,13 +85,15 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 // triangle referenced; on exit M = L^-1 (lower), Mt = M'.
 // W1 is a workspace of 66*np doubles.  flag[0] counts replaced (noise-level) pivots.
 // e0 / e1 (optional) are recorded right before / after the np/64 + 1 k_chol_step launches.
+// Lock-step batch: nlanes designs, the buffers of lane b at + b * lane_bytes, mask (nlanes ints or null) = lanes to do.
 void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
+                     double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int nlanes = 1,
+                     size_t lane_bytes = 0, const int* mask = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
 // y[v] = Lo * (b[v] + b2[v]) for a row-major lower (upper=0) or upper (upper=1) triangular np x np
 // matrix; b2 may be null.
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
-                    hipStream_t st, const double* b2 = nullptr);
+                    hipStream_t st, const double* b2 = nullptr, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
 
 // Double-double dense kernels (ddlin.hip): H(dd) = Hh + sum_{r < *kcount} X[r] U[r] U[r]' on the lower-triangle
 // tiles; in-place dd Cholesky (L in the lower triangle of (Hh, Hl), L' in (Lth, Ltl), 1/diag(L) in (rih, ril),

@@ -27,6 +27,7 @@ struct SolveInfo {
     int chol_launches = 0;  // k_chol_step launches timed in ms_chol
     double chol_flop = 0;   // factorisation + triangular inverse, per build
     int dd_iters = 0, dd_kmax = 0;   // iterations that ran the extended-precision solve; largest strong set
+    int lanes = 1;          // designs that shared the lock-step batch (ms_* are those of the whole batch)
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
 };
 
@@ -38,8 +39,14 @@ public:
     Solver& operator=(const Solver&) = delete;
     // Solve the conic program; xout = x / tau (N entries).  Returns ST_*; throws HipError.
     int solve(const TrigProgram& P, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info);
-    // fir_ap_cvx tap extraction on the device from the solution left by the last solve().
-    void specfact_last(int n, double* h_re, double* h_im);
+    // Lock-step batch: the programs (all of one shape, see shape_key) advance together through one stream, one
+    // launch per phase with the design index as a grid dimension; designs that finish are masked out.
+    void solve_lanes(const std::vector<const TrigProgram*>& Ps, const SolveOpts& o, std::vector<std::vector<double>>& xouts,
+                     std::vector<SolveInfo>& infos);
+    static std::vector<long> shape_key(const TrigProgram& P, const SolveOpts& o);   // equal keys = may share a batch
+    static int max_lanes(const TrigProgram& P, const SolveOpts& o);
+    // fir_ap_cvx tap extraction on the device from the solution left by the last solve() / lane of solve_lanes().
+    void specfact_last(int n, double* h_re, double* h_im, int lane = 0);
     // Inverse SLR on the device (slr.hip).  b: n complex taps.  a_in null: a = b2a(b) (b2a.m:15-32), else a = a_in.
     // a_out (optional) receives a; rf (optional) receives ab2rf(a, b) (ab2rf.m:14-29).
     void slr(int n, const double* b_re, const double* b_im, const double* a_in_re, const double* a_in_im,

@@ -44,6 +44,7 @@ enum {
 constexpr double STEP = 0.99;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int MAX_SWEEPS = 8;
+constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
 constexpr int WALL_ITERS = 3;
 constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
 
@@ -74,7 +75,40 @@ struct DProg {
     const double4* seed_tau;          // [nchunk][D1]   (cos, sin)(w0 t), (cos, sin)(dw t), t = tmin + m
     const double4* seed_h;            // [nchunk][3 D1 - 1]  same for the difference | sum progressions of the H moments
     const double4* seed_eval;         // [useg][Mpad]   (cos, sin)(w_i (tmin + sg seg)), (cos, sin)(w_i)
+    // Lock-step batch ("lanes"): B designs of identical shape advance together, blockIdx.z = lane.  Every device
+    // buffer of lane b -- program arrays and work vectors alike -- sits lane_bytes after the same buffer of lane
+    // b-1 (one arena, identical layout per lane), so a kernel shifts all its pointers by blockIdx.z * lane_bytes.
+    // mask (not shifted; nlanes ints) switches lanes off: finished designs, refinement sweeps a lane does not need.
+    size_t lane_bytes;
+    const int* mask;
+    template <class T>
+    __device__ __forceinline__ static void sh(const T*& p, size_t off) { p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + off); }
+    __device__ __forceinline__ void shift(size_t off) {
+        sh(w, off); sh(col_tau, off); sh(col_scale, off); sh(psign, off); sh(c, off); sh(col_kind, off); sh(pcol, off);
+        sh(freq, off); sh(col, off); sh(alpha, off); sh(beta, off); sh(ey, off); sh(h, off);
+        sh(f_ptr, off); sh(f_rows, off); sh(c_ptr, off); sh(c_rows, off); sh(yrows, off);
+        sh(lat, off); sh(lat_col, off); sh(lat_qcol, off); sh(lat_scale, off); sh(lat_qscale, off);
+        sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off);
+        sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off);
+    }
 };
+// Kernel prologue: leave if the lane is masked off, then move the program and the listed pointer arguments to
+// the block's lane (null pointers stay null).
+template <class... Ptr>
+__device__ __forceinline__ void lane_shift(size_t off, Ptr&... p) {
+    ((p = p ? (Ptr)((const char*)p + off) : p), ...);
+}
+#define LANES(P, ...)                                                \
+    if ((P).mask && !(P).mask[blockIdx.z]) return;                    \
+    if (blockIdx.z) {                                                 \
+        const size_t loff_ = (size_t)blockIdx.z * (P).lane_bytes;     \
+        (P).shift(loff_);                                             \
+        lane_shift(loff_, __VA_ARGS__);                               \
+    }
+#define LANES_RAW(lane_bytes, mask, ...)                              \
+    if ((mask) && !(mask)[blockIdx.z]) return;                        \
+    if (blockIdx.z) lane_shift((size_t)blockIdx.z * (lane_bytes), __VA_ARGS__);
+inline dim3 lane_grid(dim3 g, int nlanes) { g.z = nlanes; return g; }
 
 // ------------------------------------------------------------------------------------------------
 // trig matrix
@@ -151,6 +185,7 @@ __device__ __forceinline__ double row_value(const DProg& P, const double* __rest
 template <int NV>
 __global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* __restrict__ X,
                          double* __restrict__ out) {
+    LANES(P, UU, X, out);
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P.R) return;
     const int f = P.freq[r], cl = P.col[r];
@@ -252,7 +287,8 @@ __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restri
 
 // fold the split partials: TT[v][j] = sum_s partial[s][v][j].  Block = 64 columns x 16 split groups.
 __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld,
-                                                        int ldo, double* __restrict__ TT) {
+                                                        int ldo, double* __restrict__ TT, size_t lane_bytes, const int* lane_mask) {
+    LANES_RAW(lane_bytes, lane_mask, partial, TT);
     __shared__ double sh[16][65];
     const int c = threadIdx.x, sg = threadIdx.y, j = blockIdx.x * 64 + c, v = blockIdx.y;
     double t = 0;
@@ -282,6 +318,7 @@ constexpr int GTC = 32, GTG = 32;
 template <int NV>
 __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
                                                     const double* __restrict__ val, double* __restrict__ out) {
+    LANES(P, partial, val, out);
     __shared__ double sh[2 * NV][GTG][GTC + 1];
     __shared__ double red[17];
     const int c = threadIdx.x, sg = threadIdx.y;
@@ -377,6 +414,7 @@ constexpr int CHK = 128;      // frequencies per chunk
 constexpr int SEGMAX = 128;
 template <int NV>
 __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __restrict__ vin, double* __restrict__ UU) {
+    LANES(P, vin, UU);
     constexpr int NVVMAX = 2 * NV;
     __shared__ double2 cf[NVVMAX][SEGMAX];                // (cos, sin) coefficient pairs
     const int i = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
@@ -419,6 +457,7 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
 
 // seed tables for the recurrences below (once per design)
 __global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb, double4* __restrict__ seeds) {
+    LANES(P, seeds);
     const int m = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
     if (m >= na + nb) return;
     const double t = m < na ? t0a + m : t0b + (m - na);
@@ -428,6 +467,7 @@ __global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb,
     seeds[(long)ch * (na + nb) + m] = make_double4(c, s, cd, sd);
 }
 __global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
+    LANES(P, seeds);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (i >= P.Mf) return;
     const double w = P.w[i];
@@ -448,6 +488,7 @@ constexpr int CGRP = 4;
 template <int NV, bool AGG>
 __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, const double4* __restrict__ seeds,
                                                       int na, int nb, double* __restrict__ partial) {
+    LANES(P, src, seeds, partial);
     __shared__ double pp[NV][CGRP][CHK];
     __shared__ double red[CGRP - 1][2 * NV][64];
     const int tid = threadIdx.x, pt = tid & 63, cl = tid >> 6;
@@ -558,7 +599,8 @@ __device__ __forceinline__ double big_dot(const double* a, const double* b, int 
 // scaling of the big cone: wbb (w0 in [0], w1 in [1..]), eta -> Sc[S_ETAB]; lam = W z
 __global__ __launch_bounds__(1024) void k_big_scaling(int big, const double* __restrict__ s,
                                                       const double* __restrict__ z, double* __restrict__ wbb,
-                                                      double* __restrict__ lam, double* __restrict__ Sc) {
+                                                      double* __restrict__ lam, double* __restrict__ Sc, size_t lane_bytes, const int* lane_mask) {
+    LANES_RAW(lane_bytes, lane_mask, s, z, wbb, lam, Sc);
     __shared__ double sh[17];
     const int n1 = big - 1;
     double ns = sqrt(big_dot(s + 1, s + 1, n1, sh)), nz = sqrt(big_dot(z + 1, z + 1, n1, sh));
@@ -640,6 +682,7 @@ __device__ __forceinline__ double big_step(int big, const double* lam, const dou
 __global__ void k_scaling(DProg P, const double* __restrict__ s, const double* __restrict__ z,
                           double* __restrict__ dl, double* __restrict__ wl, double* __restrict__ w3,
                           double* __restrict__ lam, const double* __restrict__ bz2, double* __restrict__ wbz2) {
+    LANES(P, s, z, dl, wl, w3, lam, bz2, wbz2);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.l) {
         double sv = s[t], zv = z[t];
@@ -675,6 +718,7 @@ template <int NV>
 __global__ void k_winv2(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                         const double* __restrict__ in, const double* __restrict__ sub, double* __restrict__ out,
                         int mode) {
+    LANES(P, dl, w3, in, sub, out);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.l) {
 #pragma unroll
@@ -705,6 +749,7 @@ template <int NV>
 __global__ void k_rows_winv2(DProg P, const double* __restrict__ UU, const double* __restrict__ X,
                              const double* __restrict__ dl, const double* __restrict__ w3,
                              const double* __restrict__ sub, double* __restrict__ gout, double* __restrict__ out) {
+    LANES(P, UU, X, dl, w3, sub, gout, out);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.l) {
 #pragma unroll
@@ -731,6 +776,7 @@ template <int NV>
 __global__ __launch_bounds__(1024) void k_big_winv2(DProg P, const double* __restrict__ wbb,
                                                     const double* __restrict__ Sc, const double* __restrict__ in,
                                                     const double* __restrict__ sub, double* __restrict__ out, int mode) {
+    LANES(P, wbb, Sc, in, sub, out);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     for (int v = 0; v < NV; ++v) {
@@ -748,6 +794,7 @@ __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __res
                                                     double* __restrict__ rz, double* __restrict__ bz2,
                                                     double* __restrict__ part, const double* __restrict__ UU,
                                                     const double* __restrict__ X) {
+    LANES(P, Gx, s, z, Sc, rz, bz2, part, UU, X);
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     double v[4] = {0, 0, 0, 0};
     if (r < P.R) {
@@ -768,6 +815,7 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
                                                      const double* __restrict__ x, double* __restrict__ rx,
                                                      double* __restrict__ bx2, const double* __restrict__ partR, int nbR,
                                                      double* __restrict__ RB, int phase) {
+    LANES(P, Sc, GTz, x, rx, bx2, partR, RB);
     __shared__ double sh[17];
     double rz2, sz, hz, gxs2;
     if (phase != 1) {
@@ -818,6 +866,7 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
 template <int NV>
 __global__ __launch_bounds__(1024) void k_resid_norm(DProg P, const double* __restrict__ bx, const double* __restrict__ t,
                                                      double* __restrict__ out, double* __restrict__ Sc, int slot) {
+    LANES(P, bx, t, out, Sc);
     __shared__ double sh[17];
     double m = 0;
     for (int v = 0; v < NV; ++v) {
@@ -836,6 +885,7 @@ __global__ __launch_bounds__(1024) void k_resid_norm(DProg P, const double* __re
 template <int NV>
 __global__ __launch_bounds__(1024) void k_cg_start(DProg P, double* __restrict__ Sc, const double* __restrict__ r,
                                                    const double* __restrict__ z, double* __restrict__ p, int first) {
+    LANES(P, Sc, r, z, p);
     __shared__ double sh[17];
     for (int v = 0; v < NV; ++v) {
         double a = 0;
@@ -856,6 +906,7 @@ template <int NV>
 __global__ __launch_bounds__(1024) void k_cg_step(DProg P, double* __restrict__ Sc, const double* __restrict__ p,
                                                   const double* __restrict__ Hp, double* __restrict__ dx,
                                                   double* __restrict__ r, int slot) {
+    LANES(P, Sc, p, Hp, dx, r);
     __shared__ double sh[17];
     double m = 0;
     for (int v = 0; v < NV; ++v) {
@@ -881,6 +932,7 @@ __global__ __launch_bounds__(1024) void k_cg_step(DProg P, double* __restrict__ 
 template <int NV>
 __global__ void k_cg_update_r(DProg P, const double* __restrict__ Sc, const double* __restrict__ Gp,
                               const double* __restrict__ Wp, double* __restrict__ gdx, double* __restrict__ dz) {
+    LANES(P, Sc, Gp, Wp, gdx, dz);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.R) return;
 #pragma unroll
@@ -900,6 +952,7 @@ __global__ __launch_bounds__(256) void k_cg_step_update(DProg P, double* __restr
                                                         double* __restrict__ r, int slot, const double* __restrict__ Gp,
                                                         const double* __restrict__ Wp, double* __restrict__ gdx,
                                                         double* __restrict__ dz) {
+    LANES(P, Sc, p, Hp, dx, r, Gp, Wp, gdx, dz);
     __shared__ double sh[17];
     double al[NV];
 #pragma unroll
@@ -939,6 +992,7 @@ __global__ __launch_bounds__(256) void k_cg_step_update(DProg P, double* __restr
 __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restrict__ wl, const double* __restrict__ w3,
                                                 const double* __restrict__ z1, const double* __restrict__ z2,
                                                 double* __restrict__ part) {
+    LANES(P, wl, w3, z1, z2, part);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double v[3] = {0, 0, 0};
     if (t < P.l) {
@@ -958,6 +1012,7 @@ __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restric
 __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __restrict__ wbb, const double* __restrict__ Sc,
                                                    const double* __restrict__ z1, const double* __restrict__ z2,
                                                    double* __restrict__ scratch, double* __restrict__ part_row) {
+    LANES(P, wbb, Sc, z1, z2, scratch, part_row);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     double a = big_dot(P.h + ob, z1 + ob, P.big, sh);
@@ -972,6 +1027,7 @@ __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __rest
 __global__ __launch_bounds__(1024) void k_scal_dtau(DProg P, double* __restrict__ Sc, const double* __restrict__ x1,
                                                     const double* __restrict__ x2, const double* __restrict__ partR,
                                                     int nbR, int mode, double* __restrict__ RB, int phase) {
+    LANES(P, Sc, x1, x2, partR, RB);
     __shared__ double sh[17];
     double hz1, hz2, wz1;
     if (phase != 1) {
@@ -1021,6 +1077,7 @@ __global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restr
                                                   double* __restrict__ Sc, double* __restrict__ outA,
                                                   double* __restrict__ outB, double* __restrict__ part, int mode,
                                                   const double* __restrict__ dpart, int ndp, const double* __restrict__ x2) {
+    LANES(P, wl, w3, lam, z1, z2, g1, g2, rz, Sc, outA, outB, part, dpart, x2);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double dtau;
     if (dpart) {
@@ -1080,6 +1137,7 @@ __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __
                                                        const double* __restrict__ rz, const double* __restrict__ Sc,
                                                        double* __restrict__ outA, double* __restrict__ outB,
                                                        double* __restrict__ scratch, double* __restrict__ part_row, int mode) {
+    LANES(P, wbb, lam, z1, z2, g1, g2, rz, Sc, outA, outB, scratch, part_row);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     const double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
@@ -1107,6 +1165,7 @@ __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __
 __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict__ Sc, const double* __restrict__ part, int nb,
                                                     int mode, const double* __restrict__ rx, double* __restrict__ bxc,
                                                     double* __restrict__ RB, int phase) {
+    LANES(P, Sc, part, rx, bxc, RB);
     __shared__ double sh[17];
     double ts, tz;
     if (phase != 1) {
@@ -1155,6 +1214,7 @@ __global__ __launch_bounds__(256) void k_comb_rhs(DProg P, const double* __restr
                            double* __restrict__ Sc, double* __restrict__ lds, double* __restrict__ bz,
                            const double* __restrict__ spart, int nsp, const double* __restrict__ rx,
                            double* __restrict__ bxc, const double* __restrict__ dl, double* __restrict__ wbz) {
+    LANES(P, wl, w3, lam, dssa, wdza, rz, Sc, lds, bz, spart, rx, bxc, dl, wbz);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double sigma;
     if (spart) {
@@ -1204,6 +1264,7 @@ __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __
                                                        const double* __restrict__ rz, const double* __restrict__ Sc,
                                                        double* __restrict__ lds, double* __restrict__ bz,
                                                        double* __restrict__ scratch) {
+    LANES(P, wbb, lam, dssa, wdza, rz, Sc, lds, bz, scratch);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     const int n1 = P.big - 1;
@@ -1234,6 +1295,7 @@ __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __
 __global__ void k_update(DProg P, const double* __restrict__ Sc, const double* __restrict__ x1,
                          const double* __restrict__ x2, double* __restrict__ x, const double* __restrict__ ds,
                          const double* __restrict__ dz, double* __restrict__ s, double* __restrict__ z) {
+    LANES(P, Sc, x1, x2, x, ds, dz, s, z);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const double a = Sc[S_ALPHA], dtau = Sc[S_DTAU];
     if (t < P.N) x[t] += a * (x2[t] + dtau * x1[t]);
@@ -1250,6 +1312,7 @@ __device__ __forceinline__ void load_m3(const double* __restrict__ w3, const dou
 }
 __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                               double* __restrict__ Dw, double* __restrict__ BB, const double* __restrict__ m3c) {
+    LANES(P, dl, w3, Dw, BB, m3c);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.Mf) return;
     double d11 = 0, d12 = 0, d22 = 0, b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0};
@@ -1338,6 +1401,7 @@ __global__ void k_flag_share(int* flag, double* slot, int mode) {
 }
 __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const double* __restrict__ MomB,
                                  double* __restrict__ H, double pad_diag) {
+    LANES(P, Mom, MomB, H);
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (k >= P.np || j >= P.np) return;
     double v = 0;
@@ -1367,6 +1431,7 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
 // identity rows: thread j owns row j of H (and the mirrored border entries)
 __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                              double* __restrict__ H, const double* __restrict__ m3c) {
+    LANES(P, dl, w3, H, m3c);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
     const long np = P.np;
@@ -1402,6 +1467,7 @@ __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const doubl
 // out[(base + e) * ld + base + f] += ... : (H, np, Nt), or a 3 x 3 scratch (ld 3, base 0) that the lead-factor mode all-reduces
 __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                                               double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
+    LANES(P, dl, w3, H, m3c);
     __shared__ double sh[17];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
@@ -1427,11 +1493,13 @@ __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict_
         }
 }
 __global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
+    LANES(P, yy, H);
     const int e = threadIdx.x / 3, f = threadIdx.x % 3;
     if (threadIdx.x < 9 && e < P.Ne && f < P.Ne) H[(long)(P.Nt + e) * P.np + P.Nt + f] += yy[3 * e + f];
 }
 // big cone: q = G_b'(J wbar)  then  H += eta^-2 (2 q q' - G_b' J G_b)
 __global__ void k_big_q(DProg P, const double* __restrict__ wbb, double* __restrict__ qv, double* __restrict__ qd) {
+    LANES(P, wbb, qv, qd);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     const long ob = P.l + 3L * P.nq3;
     if (t >= P.big) return;
@@ -1446,6 +1514,7 @@ __global__ void k_big_q(DProg P, const double* __restrict__ wbb, double* __restr
 }
 __global__ void k_H_big(DProg P, const double* __restrict__ qv, const double* __restrict__ qd,
                         const double* __restrict__ Sc, double* __restrict__ H) {
+    LANES(P, qv, qd, Sc, H);
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (k >= P.N || j >= P.N) return;
     const double e2 = 1.0 / (Sc[S_ETAB] * Sc[S_ETAB]);
@@ -1459,6 +1528,7 @@ __global__ void k_H_big(DProg P, const double* __restrict__ qv, const double* __
 // initial point helpers -----------------------------------------------------------------------
 // cone "distance outside" (max over cones of -(interior distance)) and ||v||^2
 __global__ __launch_bounds__(256) void k_cone_resid(DProg P, const double* __restrict__ v, double* __restrict__ part) {
+    LANES(P, v, part);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double a[2] = {-1e300, 0};
     if (t < P.l) { a[0] = -v[t]; a[1] = v[t] * v[t]; }
@@ -1472,13 +1542,15 @@ __global__ __launch_bounds__(256) void k_cone_resid(DProg P, const double* __res
     if (threadIdx.x == 0) { part[2L * blockIdx.x] = m; part[2L * blockIdx.x + 1] = s; }
 }
 __global__ __launch_bounds__(1024) void k_big_cone_resid(DProg P, const double* __restrict__ v, double* __restrict__ part_row) {
+    LANES(P, v, part_row);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     double n1 = big_dot(v + ob + 1, v + ob + 1, P.big - 1, sh);
     if (threadIdx.x == 0) { part_row[0] = sqrt(n1) - v[ob]; part_row[1] = n1 + v[ob] * v[ob]; }
 }
 // fold the cone-residual partials: RB[0] = max (distance outside), RB[1] = sum ||v||^2
-__global__ __launch_bounds__(256) void k_cone_fold(const double* __restrict__ part, int nb, double* __restrict__ RB) {
+__global__ __launch_bounds__(256) void k_cone_fold(const double* __restrict__ part, int nb, double* __restrict__ RB, size_t lane_bytes, const int* lane_mask) {
+    LANES_RAW(lane_bytes, lane_mask, part, RB);
     __shared__ double sh[17];
     double tmax = fold_partials(part, nb, 2, 0, true, sh);
     double n2 = fold_partials(part, nb, 2, 1, false, sh);
@@ -1486,6 +1558,7 @@ __global__ __launch_bounds__(256) void k_cone_fold(const double* __restrict__ pa
 }
 // v += (1 + t) e  when  t >= -1e-8 max(1, ||v||)
 __global__ __launch_bounds__(256) void k_cone_shift(DProg P, double* __restrict__ v, const double* __restrict__ RB) {
+    LANES(P, v, RB);
     const double tmax = RB[0], nrm = sqrt(RB[1]);
     if (!(tmax >= -1e-8 * fmax(1.0, nrm))) return;
     const double add = 1.0 + tmax;
@@ -1496,10 +1569,12 @@ __global__ __launch_bounds__(256) void k_cone_shift(DProg P, double* __restrict_
     }
 }
 __global__ void k_neg_copy_r(DProg P, const double* __restrict__ a, double* __restrict__ out, double sgn) {
+    LANES(P, a, out);
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < P.R) out[r] = sgn * a[r];
 }
 __global__ void k_init_rhs(DProg P, double* __restrict__ bx2, double* __restrict__ bz2) {
+    LANES(P, bx2, bz2);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.N) { bx2[t] = 0.0; bx2[P.LDV + t] = -P.c[t]; }
     if (t < P.R) { bz2[t] = P.h[t]; bz2[P.Rp + t] = 0.0; }
@@ -1507,6 +1582,7 @@ __global__ void k_init_rhs(DProg P, double* __restrict__ bx2, double* __restrict
 // H for the initial point (W = I): weights d=1 for LP rows, M = I for cones
 __global__ void k_unit_scaling(DProg P, double* __restrict__ dl, double* __restrict__ wl, double* __restrict__ w3,
                                double* __restrict__ wbb, double* __restrict__ Sc) {
+    LANES(P, dl, wl, w3, wbb, Sc);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < P.l) { dl[t] = 1.0; wl[t] = 1.0; }
     if (t < P.nq3) { w3[4 * t] = 1.0; w3[4 * t + 1] = 1.0; w3[4 * t + 2] = 0.0; w3[4 * t + 3] = 0.0; }
@@ -1514,6 +1590,7 @@ __global__ void k_unit_scaling(DProg P, double* __restrict__ dl, double* __restr
     if (t == 0) { Sc[S_ETAB] = 1.0; Sc[S_WB0] = 1.0; }
 }
 __global__ void k_finish_x(DProg P, const double* __restrict__ x, const double* __restrict__ Sc, double* __restrict__ out) {
+    LANES(P, x, Sc, out);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < P.N) out[j] = x[j] / Sc[S_TAU];
 }
@@ -1613,8 +1690,15 @@ struct Solver::Impl {
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Arena ar;
-    double* hostSc = nullptr;    // pinned
-    int* hostFlag = nullptr;     // pinned
+    double* hostSc = nullptr;    // pinned, S_COUNT per lane
+    int* hostFlag = nullptr;     // pinned, 4 per lane
+    // lock-step batch: nlanes designs of identical shape in one arena, lane b at + b * lane_bytes (see DProg)
+    int nlanes = 1, nlanes_last = 1;
+    size_t lane_bytes = 0;
+    int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
+                                 // still need CG sweep q, row MAX_SWEEPS + 1 = scratch (lanes with a new best iterate)
+    int* hostMask = nullptr;     // pinned twin
+    const int* mask_row(int r) const { return nlanes > 1 ? maskT + (size_t)r * MAX_LANES : nullptr; }
     std::string err;
 
     // per-solve device pointers
@@ -1646,11 +1730,27 @@ struct Solver::Impl {
         ar.cap = bytes;
         ar.reset();
     }
-    template <class T>
-    T* upload(const std::vector<T>& v) {
-        T* p = ar.get<T>(std::max<size_t>(v.size(), 1));
-        if (!v.empty() && !ar.measuring) MBFIR_HIP(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    // one array per lane, all of the same length (the lanes share one arena layout); get(b) returns lane b's vector
+    template <class T, class F>
+    T* upload(F get) {
+        const size_t n0 = get(0).size();
+        T* p = ar.get<T>(std::max<size_t>(n0, 1));
+        if (!ar.measuring)
+            for (int b = 0; b < nlanes; ++b) {
+                const std::vector<T>& v = get(b);
+                if (v.size() != n0) throw HipError("lock-step batch: lanes differ in shape");
+                if (n0) MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(p) + (size_t)b * lane_bytes, v.data(), n0 * sizeof(T), hipMemcpyHostToDevice, st));
+            }
         return p;
+    }
+    // the same stretch of every lane
+    void memset_lanes(void* p, size_t bytes) {
+        if (nlanes > 1) hipMemset2DAsync(p, lane_bytes, 0, bytes, nlanes, st);
+        else hipMemsetAsync(p, 0, bytes, st);
+    }
+    void copy_lanes(void* dst, const void* src, size_t bytes) {
+        if (nlanes > 1) MBFIR_HIP(hipMemcpy2DAsync(dst, lane_bytes, src, lane_bytes, bytes, nlanes, hipMemcpyDeviceToDevice, st));
+        else MBFIR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
     }
 
     // ---- operators ----
@@ -1658,28 +1758,28 @@ struct Solver::Impl {
     void apply_G(const double* v, double* out) {
         const int NVV = P.quad ? 2 * NV : NV;
         if (P.trig) {
-            hipLaunchKernelGGL(k_trig_eval<NV>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, v, UU);
-            hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
+            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
+            hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
             return;
         }
         const double* xx = v;
         if (P.quad) {
-            hipLaunchKernelGGL(k_make_xx<NV>, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, v, XX);
+            hipLaunchKernelGGL(k_make_xx<NV>, lane_grid(dim3(cdiv(P.Nt, 256)), nlanes), dim3(256), 0, st, P, v, XX);
             xx = XX;
         }
         dim3 g(cdiv(P.Mf, 4));
-        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
-        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
-        else hipLaunchKernelGGL(k_amulti<4>, g, dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
-        hipLaunchKernelGGL(k_rows_G<NV>, dim3(cdiv(P.R, 256)), dim3(256), 0, st, P, UU, v, out);
+        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        else hipLaunchKernelGGL(k_amulti<4>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
     }
     // gout = G v and wout = W^-2 gout - sub; one kernel less than apply_G + winv2 on the lattice path
     // without a big cone
     template <int NV>
     void apply_G_winv2(const double* v, double* gout, const double* sub, double* wout) {
         if (P.trig && !P.big) {
-            hipLaunchKernelGGL(k_trig_eval<NV>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, v, UU);
-            hipLaunchKernelGGL(k_rows_winv2<NV>, dim3(cdiv(P.l + P.nq3, 256)), dim3(256), 0, st, P, UU, v, dl, w3, sub, gout, wout);
+            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
+            hipLaunchKernelGGL(k_rows_winv2<NV>, lane_grid(dim3(cdiv(P.l + P.nq3, 256)), nlanes), dim3(256), 0, st, P, UU, v, dl, w3, sub, gout, wout);
             return;
         }
         apply_G<NV>(v, gout);
@@ -1690,23 +1790,23 @@ struct Solver::Impl {
     void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
         dim3 g(cdiv(na + nb, 64), cdiv(P.nchunk, CGRP)), b(256);
         switch (nv) {
-            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), g, b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
+            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
             default: throw HipError("moments: unsupported vector count");
         }
-        hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.LDM, 64), 2 * nv), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, CGRP), 2 * nv, P.LDM, P.LDM, out);
+        hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.LDM, 64), 2 * nv), nlanes), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, CGRP), 2 * nv, P.LDM, P.LDM, out, lane_bytes, P.mask);
     }
     void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
         switch (nvv) {
-            case 1: hipLaunchKernelGGL((k_atmulti<1, false>), g, b, 0, st, P, A1, pp, partial); break;
-            case 2: hipLaunchKernelGGL((k_atmulti<2, false>), g, b, 0, st, P, A1, pp, partial); break;
-            case 3: hipLaunchKernelGGL((k_atmulti<3, false>), g, b, 0, st, P, A1, pp, partial); break;
-            case 4: hipLaunchKernelGGL((k_atmulti<4, false>), g, b, 0, st, P, A1, pp, partial); break;
-            case 6: hipLaunchKernelGGL((k_atmulti<6, false>), g, b, 0, st, P, A1, pp, partial); break;
+            case 1: hipLaunchKernelGGL((k_atmulti<1, false>), lane_grid(g, nlanes), b, 0, st, P, A1, pp, partial); break;
+            case 2: hipLaunchKernelGGL((k_atmulti<2, false>), lane_grid(g, nlanes), b, 0, st, P, A1, pp, partial); break;
+            case 3: hipLaunchKernelGGL((k_atmulti<3, false>), lane_grid(g, nlanes), b, 0, st, P, A1, pp, partial); break;
+            case 4: hipLaunchKernelGGL((k_atmulti<4, false>), lane_grid(g, nlanes), b, 0, st, P, A1, pp, partial); break;
+            case 6: hipLaunchKernelGGL((k_atmulti<6, false>), lane_grid(g, nlanes), b, 0, st, P, A1, pp, partial); break;
             default: throw HipError("atmulti: unsupported vector count");
         }
     }
@@ -1714,20 +1814,20 @@ struct Solver::Impl {
     void apply_GT(const double* val, double* out) {
         if (P.trig) {
             dim3 g(cdiv(P.D1, 64), cdiv(P.nchunk, CGRP)), b(256);
-            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
-            else hipLaunchKernelGGL((k_trig_moments<NV, true>), g, b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
+            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
+            else hipLaunchKernelGGL((k_trig_moments<NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
         } else {
             dim3 g(P.ld / 128, nsplit_at), b(64, 4);
-            if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), g, b, 0, st, P, A1, val, partial);
-            else hipLaunchKernelGGL((k_atmulti<NV, true>), g, b, 0, st, P, A1, val, partial);
+            if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
+            else hipLaunchKernelGGL((k_atmulti<NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
         }
-        hipLaunchKernelGGL(k_gt_finish<NV>, dim3(cdiv(P.Nt, GTC) + 1), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, CGRP) : nsplit_at, val, out);
+        hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, CGRP) : nsplit_at, val, out);
         allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
     void winv2(const double* in, const double* sub, double* out, int mode) {
-        hipLaunchKernelGGL(k_winv2<NV>, dim3(cdiv(P.l + P.nq3, 256)), dim3(256), 0, st, P, dl, w3, in, sub, out, mode);
-        if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, in, sub, out, mode);
+        hipLaunchKernelGGL(k_winv2<NV>, lane_grid(dim3(cdiv(P.l + P.nq3, 256)), nlanes), dim3(256), 0, st, P, dl, w3, in, sub, out, mode);
+        if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, in, sub, out, mode);
     }
     // Row-sharded solves on the lattice path: the normal matrix is a linear function of ~100 KB of trigonometric
     // moments, so the ranks all-reduce the MOMENTS, rank 0 alone assembles and factorises H (it also owns every
@@ -1738,8 +1838,8 @@ struct Solver::Impl {
     template <int NV>
     void hsolve(const double* rhs, double* out, const double* rhs2 = nullptr) {
         if (!lead_factor() || shard_rank == 0) {
-            trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2);
-            trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st);
+            trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2, nlanes, lane_bytes, P.mask);
+            trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st, nullptr, nlanes, lane_bytes, P.mask);
         }
         if (lead_factor()) {
             if (shard_rank != 0) hipMemsetAsync(out, 0, sizeof(double) * NV * P.LDV, st);
@@ -1754,44 +1854,50 @@ struct Solver::Impl {
     template <int NV>
     void kkt_solve(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int nsweep, int slot,
                    bool wbz_ready = false) {
-        const dim3 gN(nbN), gR(cdiv(P.R, 256)), b256(256);
+        // lock-step batch: nsweep is the largest count over the live lanes; mask row q switches off the lanes that
+        // need fewer than q sweeps
+        const dim3 gR = lane_grid(dim3(cdiv(P.R, 256)), nlanes), g1 = lane_grid(dim3(1), nlanes), b256(256);
         if (!wbz_ready) winv2<NV>(bz, nullptr, wbz, 0);
-        else if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, dim3(1), dim3(1024), 0, st, P, wbb, Sc, bz, nullptr, wbz, 0);
+        else if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, g1, dim3(1024), 0, st, P, wbb, Sc, bz, nullptr, wbz, 0);
         apply_GT<NV>(wbz, tmpN);
         hsolve<NV>(bx, dx, tmpN);                                                           // M'M (bx + G' W^-2 bz)
         apply_G_winv2<NV>(dx, gdx, wbz, dz);
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
-        hipLaunchKernelGGL(k_resid_norm<NV>, dim3(1), dim3(1024), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
+        hipLaunchKernelGGL(k_resid_norm<NV>, g1, dim3(1024), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
         if (nsweep <= 0) return;
+        const int* live = P.mask;
+        P.mask = mask_row(1);
         hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
-            hipLaunchKernelGGL(k_cg_start<NV>, dim3(1), dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
+            P.mask = mask_row(it + 1);
+            hipLaunchKernelGGL(k_cg_start<NV>, g1, dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
             apply_G_winv2<NV>(pN, tmpR, nullptr, wpR);                                      // G p, W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
             if (shard_size == 1) {
                 hipLaunchKernelGGL(k_cg_step_update<NV>, gR, b256, 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1, tmpR, wpR, gdx, dz);
             } else {
-                hipLaunchKernelGGL(k_cg_step<NV>, dim3(1), dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
+                hipLaunchKernelGGL(k_cg_step<NV>, g1, dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
                 hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
             }
-            if (it + 1 < nsweep) hsolve<NV>(r, tmpN2);
+            if (it + 1 < nsweep) { P.mask = mask_row(it + 2); hsolve<NV>(r, tmpN2); }
         }
+        P.mask = live;
     }
     // Extended-precision solve, step 1 (after the NT scaling): eigen data, cap, strong set.  Returns the number of
     // strong eigen-directions (0: nothing above the cap, the plain solve is exact enough).  One host
     // synchronisation (the count decides which solve runs).
     int dd_prepare(double theta) {
         const int nb = std::max(nbC, 1);
-        hipLaunchKernelGGL(k_dd_prep, dim3(nb), dim3(256), 0, st, P, dl, w3, D, partR);
+        hipLaunchKernelGGL(k_dd_prep, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, w3, D, partR);
         int nbp = nb;
         if (P.big) {
-            hipLaunchKernelGGL(k_dd_prep_big, dim3(1), dim3(1024), 0, st, P, wbb, Sc, D, partR + 2L * nb);
+            hipLaunchKernelGGL(k_dd_prep_big, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, D, partR + 2L * nb);
             nbp += 1;
         }
         for (int attempt = 0; attempt < 8; ++attempt) {
             hipMemsetAsync(D.kcnt, 0, sizeof(int), st);
-            hipLaunchKernelGGL(k_dd_select, dim3(nb), dim3(256), 0, st, P, dl, D, partR, nbp, theta);
+            hipLaunchKernelGGL(k_dd_select, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, D, partR, nbp, theta);
             MBFIR_HIP(hipMemcpyAsync(hostFlag + 1, D.kcnt, sizeof(int), hipMemcpyDeviceToHost, st));
             MBFIR_HIP(hipStreamSynchronize(st));
             if (hostFlag[1] <= DD_KMAX) return hostFlag[1];
@@ -1812,21 +1918,21 @@ struct Solver::Impl {
         hipMemsetAsync(gdx, 0, sizeof(double) * NV * P.Rp, st);
         for (int it = 0; it < 2; ++it) {
             apply_GT<NV>(dz, tmpN);
-            hipLaunchKernelGGL(k_resid_norm<NV>, dim3(1), dim3(1024), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
-            hipLaunchKernelGGL(k_dd_r2<NV>, gC, b256, 0, st, P, D, dl, bz, gdx, dz, tmpR, ddtS);                  // r2, t
-            if (P.big) hipLaunchKernelGGL(k_dd_r2_big<NV>, dim3(1), dim3(1024), 0, st, P, D, bz, gdx, dz, tmpR, ddtS, scratch);
-            hipLaunchKernelGGL(k_dd_winv2c<NV>, gC, b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
-            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, dim3(1), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
+            hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
+            hipLaunchKernelGGL(k_dd_r2<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, dl, bz, gdx, dz, tmpR, ddtS);                  // r2, t
+            if (P.big) hipLaunchKernelGGL(k_dd_r2_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, bz, gdx, dz, tmpR, ddtS, scratch);
+            hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
+            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
             apply_GT<NV>(wbz, tmpN2);
-            hipLaunchKernelGGL(k_dd_rhs<NV>, dim3(cdiv(P.np, 256)), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
+            hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 256)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
             dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st);
             apply_G<NV>(Bh, wpR);
-            hipLaunchKernelGGL(k_dd_winv2c<NV>, gC, b256, 0, st, P, D, wpR, tmpR, wbz);
-            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, dim3(1), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
-            hipLaunchKernelGGL(k_dd_zeta<NV>, dim3(k), dim3(64), 0, st, P, D, Bh, Bl, ddtS, ddzeta);
-            hipLaunchKernelGGL(k_dd_accum<NV>, gC, b256, 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
-            if (P.big) hipLaunchKernelGGL(k_dd_accum_big<NV>, dim3(1), dim3(1024), 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
-            hipLaunchKernelGGL(k_dd_accum_x<NV>, dim3(nbN), b256, 0, st, P, Bh, dx);
+            hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wpR, tmpR, wbz);
+            if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
+            hipLaunchKernelGGL(k_dd_zeta<NV>, lane_grid(dim3(k), nlanes), dim3(64), 0, st, P, D, Bh, Bl, ddtS, ddzeta);
+            hipLaunchKernelGGL(k_dd_accum<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
+            if (P.big) hipLaunchKernelGGL(k_dd_accum_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
+            hipLaunchKernelGGL(k_dd_accum_x<NV>, lane_grid(dim3(nbN), nlanes), b256, 0, st, P, Bh, dx);
         }
     }
     // H = G' W^-2 G from the current scaling, then Cholesky + inverse.  Timing events are pooled
@@ -1847,7 +1953,7 @@ struct Solver::Impl {
     void build_H(int ddk = 0) {
         const double* dlw = ddk > 0 ? D.dlc : dl;
         const double* m3c = ddk > 0 ? D.m3c : nullptr;
-        hipLaunchKernelGGL(k_freq_blocks, dim3(cdiv(P.Mf, 256)), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
+        hipLaunchKernelGGL(k_freq_blocks, lane_grid(dim3(cdiv(P.Mf, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
         hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
         if (P.trig) {
             if (g0) hipEventRecord(g0, st);
@@ -1871,37 +1977,37 @@ struct Solver::Impl {
                 }
             }
             if (!lead_factor() || shard_rank == 0)
-                hipLaunchKernelGGL(k_assemble_H_lat, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
+                hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
         } else {
         gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti_array(nvv, BB);
-            hipLaunchKernelGGL(k_fold_partials, dim3(cdiv(P.ld, 64), nvv), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT);
+            hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask);
         }
-        hipLaunchKernelGGL(k_assemble_H, dim3(cdiv(P.np, 256), P.np), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
+        hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         }
         const bool mine = !lead_factor() || shard_rank == 0;     // lead mode: only rank 0 holds H
         if (lead_factor() && P.Ne > 0) {
             // the y-y block also gets terms from frequency rows (rho, delta columns), which live on every rank
             hipMemsetAsync(RB, 0, sizeof(double) * 9, st);
-            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dlw, w3, RB, 3L, 0L, m3c);
+            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, RB, 3L, 0L, m3c);
             allreduce(RB, 9, 0);
-            if (mine) hipLaunchKernelGGL(k_H_yy_add, dim3(1), dim3(16), 0, st, P, RB, H);
+            if (mine) hipLaunchKernelGGL(k_H_yy_add, lane_grid(dim3(1), nlanes), dim3(16), 0, st, P, RB, H);
         }
         if (mine) {
-            hipLaunchKernelGGL(k_H_identity, dim3(cdiv(P.Nt, 256)), dim3(256), 0, st, P, dlw, w3, H, m3c);
+            hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c);
             if (!lead_factor() && P.Ne > 0 && P.nyrows > 0)
-                hipLaunchKernelGGL(k_H_yy, dim3(1), dim3(256), 0, st, P, dlw, w3, H, (long)P.np, (long)P.Nt, m3c);
+                hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, H, (long)P.np, (long)P.Nt, m3c);
             if (P.big) {
-                hipMemsetAsync(qv, 0, sizeof(double) * 3 * P.LDV, st);
+                memset_lanes(qv, sizeof(double) * 3 * P.LDV);
                 if (ddk > 0) {
-                    hipLaunchKernelGGL(k_big_q_dd, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV);
-                    hipLaunchKernelGGL(k_H_big_dd, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV, H);
+                    hipLaunchKernelGGL(k_big_q_dd, lane_grid(dim3(cdiv(P.big, 256)), nlanes), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV);
+                    hipLaunchKernelGGL(k_H_big_dd, lane_grid(dim3(cdiv(P.N, 256), P.N), nlanes), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV, H);
                 } else {
-                    hipLaunchKernelGGL(k_big_q, dim3(cdiv(P.big, 256)), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
-                    hipLaunchKernelGGL(k_H_big, dim3(cdiv(P.N, 256), P.N), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
+                    hipLaunchKernelGGL(k_big_q, lane_grid(dim3(cdiv(P.big, 256)), nlanes), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
+                    hipLaunchKernelGGL(k_H_big, lane_grid(dim3(cdiv(P.N, 256), P.N), nlanes), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
                 }
             }
         }
@@ -1909,20 +2015,20 @@ struct Solver::Impl {
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
         if (ddk > 0) {
             if (c0) hipEventRecord(c0, st);
-            hipLaunchKernelGGL(k_dd_rows, dim3(ddk), dim3(256), 0, st, P, D, P.np);
+            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
             dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
             dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st);
             if (c1) hipEventRecord(c1, st);
         } else if (mine) {
-            chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1);
+            chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
         } else {
             if (c0) hipEventRecord(c0, st);
             if (c1) hipEventRecord(c1, st);
         }
         if (lead_factor()) {                                      // everybody needs the pivot-replacement count (wall exit)
-            hipLaunchKernelGGL(k_flag_share, dim3(1), dim3(1), 0, st, flag, RB + 9, shard_rank == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_flag_share, lane_grid(dim3(1), nlanes), dim3(1), 0, st, flag, RB + 9, shard_rank == 0 ? 1 : 0);
             allreduce(RB + 9, 1, 0);
-            hipLaunchKernelGGL(k_flag_share, dim3(1), dim3(1), 0, st, flag, RB + 9, 2);
+            hipLaunchKernelGGL(k_flag_share, lane_grid(dim3(1), nlanes), dim3(1), 0, st, flag, RB + 9, 2);
         }
     }
     // events are recorded as (gram begin, gram end, chol begin, chol end) per build_H
@@ -1946,8 +2052,11 @@ Solver::Solver(int device) : impl(new Impl()) {
     MBFIR_HIP(hipStreamCreate(&impl->st));
     MBFIR_HIP(hipEventCreate(&impl->ev0));
     MBFIR_HIP(hipEventCreate(&impl->ev1));
-    MBFIR_HIP(hipHostMalloc(&impl->hostSc, sizeof(double) * S_COUNT));
-    MBFIR_HIP(hipHostMalloc(&impl->hostFlag, sizeof(int) * 4));
+    MBFIR_HIP(hipHostMalloc(&impl->hostSc, sizeof(double) * S_COUNT * MAX_LANES));
+    MBFIR_HIP(hipHostMalloc(&impl->hostFlag, sizeof(int) * 4 * MAX_LANES));
+    MBFIR_HIP(hipHostMalloc(&impl->hostMask, sizeof(int) * MASK_ROWS * MAX_LANES));
+    MBFIR_HIP(hipMalloc(&impl->maskT, sizeof(int) * MASK_ROWS * MAX_LANES));
+    std::memset(impl->hostMask, 0, sizeof(int) * MASK_ROWS * MAX_LANES);
 }
 Solver::~Solver() {
     if (!impl) return;
@@ -1955,6 +2064,8 @@ Solver::~Solver() {
     if (impl->ar.base) hipFree(impl->ar.base);
     if (impl->hostSc) hipHostFree(impl->hostSc);
     if (impl->hostFlag) hipHostFree(impl->hostFlag);
+    if (impl->hostMask) hipHostFree(impl->hostMask);
+    if (impl->maskT) hipFree(impl->maskT);
     for (hipEvent_t e : impl->evpool) hipEventDestroy(e);
     if (impl->ev0) hipEventDestroy(impl->ev0);
     if (impl->ev1) hipEventDestroy(impl->ev1);
@@ -1969,52 +2080,118 @@ static double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {
-    Impl& S = *impl;
-    MBFIR_HIP(hipSetDevice(S.device));
-    hipStream_t st = S.st;
-    const double t_begin = now_ms();
-    // ---- row sharding: this process keeps the frequencies i % size == rank (program.h) ----------
-    S.shard_rank = o.shard_size > 1 ? o.shard_rank : 0;
-    S.shard_size = o.shard_size > 1 ? o.shard_size : 1;
-    if (S.shard_size > 1 && !S.ar_fn) throw HipError("row-sharded solve without an all-reduce hook");
-    const TrigProgram Qlocal = shard_program(Qfull, S.shard_rank, S.shard_size);
-    const TrigProgram& Q = Qlocal;
-    // constants of the WHOLE program (identical on every shard)
-    double nrm_h = 0, nrm_c = 0;
-    for (double v : Qfull.h) nrm_h += v * v;
-    for (double v : Qfull.c) nrm_c += v * v;
-    nrm_h = std::max(1.0, std::sqrt(nrm_h)); nrm_c = std::max(1.0, std::sqrt(nrm_c));
-    const double degree = double(Qfull.l + Qfull.nq3 + (Qfull.big ? 1 : 0));
-    // ---- host-side index structures --------------------------------------------------------
-    const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;
-    std::vector<int> f_ptr(Mf + 1, 0), f_rows, c_ptr(Nt + 1, 0), c_rows, yrows;
+// Host-side description of one lane (one design of a lock-step batch)
+struct LaneHost {
+    const TrigProgram* Q = nullptr;
+    TrigProgram local;                       // the row shard (sharded solves have one lane)
+    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows;
+    LatticeInfo Lt;
+    double nrm_h = 1, nrm_c = 1, degree = 0;
+    // IPM state
+    int status = ST_MAXIT, nsweep = 0, wall = 0, iters = 0;
+    bool live = true, have_best = false;
+    double best_merit = 1e300;
+    SolveInfo info, best_info;
+};
+
+static void index_structures(const TrigProgram& Q, LaneHost& L) {
+    const int R = Q.R, Nt = Q.Nt, Mf = Q.Mf;
+    L.f_ptr.assign(Mf + 1, 0); L.c_ptr.assign(Nt + 1, 0); L.f_rows.clear(); L.c_rows.clear(); L.yrows.clear();
     for (int r = 0; r < R; ++r) {
-        if (Q.freq[r] >= 0) f_ptr[Q.freq[r] + 1]++;
-        if (Q.col[r] >= 0) c_ptr[Q.col[r] + 1]++;
-        if (Q.ey[3 * r] != 0 || Q.ey[3 * r + 1] != 0 || Q.ey[3 * r + 2] != 0) yrows.push_back(r);
+        if (Q.freq[r] >= 0) L.f_ptr[Q.freq[r] + 1]++;
+        if (Q.col[r] >= 0) L.c_ptr[Q.col[r] + 1]++;
+        if (Q.ey[3 * r] != 0 || Q.ey[3 * r + 1] != 0 || Q.ey[3 * r + 2] != 0) L.yrows.push_back(r);
         if (Q.freq[r] >= 0 && r >= Q.l) {
             int a = (r - Q.l) % 3;
             if (r >= Q.l + 3 * Q.nq3 || a == 0) throw HipError("unsupported cone layout (trig row at cone position 0 / in big cone)");
         }
     }
-    for (int i = 0; i < Mf; ++i) f_ptr[i + 1] += f_ptr[i];
-    for (int j = 0; j < Nt; ++j) c_ptr[j + 1] += c_ptr[j];
-    f_rows.resize(f_ptr[Mf]); c_rows.resize(c_ptr[Nt]);
-    {
-        std::vector<int> fp(f_ptr.begin(), f_ptr.end() - 1), cp(c_ptr.begin(), c_ptr.end() - 1);
-        for (int r = 0; r < R; ++r) {
-            if (Q.freq[r] >= 0) f_rows[fp[Q.freq[r]]++] = r;
-            if (Q.col[r] >= 0) c_rows[cp[Q.col[r]]++] = r;
-        }
+    for (int i = 0; i < Mf; ++i) L.f_ptr[i + 1] += L.f_ptr[i];
+    for (int j = 0; j < Nt; ++j) L.c_ptr[j + 1] += L.c_ptr[j];
+    L.f_rows.resize(L.f_ptr[Mf]); L.c_rows.resize(L.c_ptr[Nt]);
+    std::vector<int> fp(L.f_ptr.begin(), L.f_ptr.end() - 1), cp(L.c_ptr.begin(), L.c_ptr.end() - 1);
+    for (int r = 0; r < R; ++r) {
+        if (Q.freq[r] >= 0) L.f_rows[fp[Q.freq[r]]++] = r;
+        if (Q.col[r] >= 0) L.c_rows[cp[Q.col[r]]++] = r;
     }
-    // ---- sizes -----------------------------------------------------------------------------
-    const int nw = Q.quad ? 3 : 1;
-    S.gp = gram_plan(Mf, Nt, nw);
+}
+
+// Two programs can share a lock-step batch when every array the device holds for them has the same length and
+// the scalar structure the kernels are launched with is the same: dimensions, lattice extent and chunk count.
+std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
+    LaneHost L;
+    index_structures(Q, L);
     LatticeInfo Lt;
     if (!o.dense_trig) Lt = analyse_lattice(Q);
+    long tbits = 0;
+    std::memcpy(&tbits, &Lt.tmin, sizeof(double));
+    return {long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.Mf), long(Q.R), long(Q.l), long(Q.nq3), long(Q.big),
+            long(Q.quad), long(L.f_rows.size()), long(L.c_rows.size()), long(L.yrows.size()), long(Lt.ok), long(Lt.D1),
+            long(Lt.ch_start.size()), tbits};
+}
+// how many lanes of this shape one context runs in lock step (memory and occupancy)
+int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
+    if (o.shard_size > 1 || o.dense_trig || o.ddkkt_theta > 0) return 1;
+    const long np = round_up(Q.N(), 64);
+    return int(std::max<long>(1, std::min<long>(MAX_LANES, std::min<long>(32, 16384 / np))));
+}
+
+int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {
+    std::vector<const TrigProgram*> Qs{&Qfull};
+    std::vector<std::vector<double>> xs;
+    std::vector<SolveInfo> infos;
+    solve_lanes(Qs, o, xs, infos);
+    xout = xs[0]; info = infos[0];
+    return info.status;
+}
+
+void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveOpts& o, std::vector<std::vector<double>>& xouts,
+                         std::vector<SolveInfo>& infos) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    hipStream_t st = S.st;
+    const double t_begin = now_ms();
+    const int nlanes = int(Qs.size());
+    if (nlanes < 1 || nlanes > MAX_LANES) throw HipError("lock-step batch: bad lane count");
+    S.nlanes = nlanes;
+    // ---- row sharding: this process keeps the frequencies i % size == rank (program.h) ----------
+    S.shard_rank = o.shard_size > 1 ? o.shard_rank : 0;
+    S.shard_size = o.shard_size > 1 ? o.shard_size : 1;
+    if (S.shard_size > 1 && !S.ar_fn) throw HipError("row-sharded solve without an all-reduce hook");
+    if (S.shard_size > 1 && nlanes > 1) throw HipError("row-sharded solves run one design at a time");
+    std::vector<LaneHost> LH(nlanes);
+    for (int b = 0; b < nlanes; ++b) {
+        LaneHost& L = LH[b];
+        const TrigProgram& Qfull = *Qs[b];
+        if (S.shard_size > 1) { L.local = shard_program(Qfull, S.shard_rank, S.shard_size); L.Q = &L.local; }
+        else L.Q = &Qfull;
+        // constants of the WHOLE program (identical on every shard)
+        double nh = 0, nc = 0;
+        for (double v : Qfull.h) nh += v * v;
+        for (double v : Qfull.c) nc += v * v;
+        L.nrm_h = std::max(1.0, std::sqrt(nh)); L.nrm_c = std::max(1.0, std::sqrt(nc));
+        L.degree = double(Qfull.l + Qfull.nq3 + (Qfull.big ? 1 : 0));
+        index_structures(*L.Q, L);
+        if (!o.dense_trig) L.Lt = analyse_lattice(*L.Q);
+        L.nsweep = o.refine;
+    }
+    const TrigProgram& Q = *LH[0].Q;
+    const LatticeInfo& Lt = LH[0].Lt;
+    for (int b = 1; b < nlanes; ++b) {
+        const TrigProgram& Qb = *LH[b].Q;
+        const LatticeInfo& Lb = LH[b].Lt;
+        if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l ||
+            Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ok != Lt.ok ||
+            Lb.D1 != Lt.D1 || Lb.ch_start.size() != Lt.ch_start.size() || Lb.tmin != Lt.tmin)
+            throw HipError("lock-step batch: lanes differ in shape");
+    }
+    // ---- sizes -----------------------------------------------------------------------------
+    const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;
+    const int nw = Q.quad ? 3 : 1;
+    S.gp = gram_plan(Mf, Nt, nw);
     DProg& P = S.P;
     P.trig = Lt.ok ? 1 : 0;
+    if (nlanes > 1 && !P.trig) throw HipError("lock-step batch needs the lattice path");
     P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
     P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
@@ -2023,7 +2200,8 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
-    P.nyrows = int(yrows.size());
+    P.nyrows = int(LH[0].yrows.size());
+    P.mask = nullptr; P.lane_bytes = 0;
     S.nsplit_at = cdiv(P.Mpad, AT_ROWS);
     const int ncone = P.l + P.nq3;
     S.nbR = cdiv(R, 256); S.nbN = cdiv(N, 256); S.nbC = cdiv(ncone, 256);
@@ -2032,22 +2210,26 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     const int lp = Q.which == DES_AP ? specfact_lp(Q.n) : 0;
     std::vector<int> tiles(2 * S.gp.ntiles);
     gram_tiles_host(S.gp, tiles.data());
-    const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1;    // extended-precision KKT solve (ddkkt.inc)
+    const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
     Arena& ar = S.ar;
     char* zero_from = nullptr;
     size_t zero_bytes = 0;
     auto layout = [&]() {
-    // ---- upload the program ----------------------------------------------------------------
-    P.w = S.upload(Q.w); P.col_kind = S.upload(Q.col_kind); P.col_tau = S.upload(Q.col_tau);
-    P.col_scale = S.upload(Q.col_scale); P.pcol = S.upload(Q.pcol); P.psign = S.upload(Q.psign);
-    P.c = S.upload(Q.c); P.freq = S.upload(Q.freq); P.col = S.upload(Q.col); P.alpha = S.upload(Q.alpha);
-    P.beta = S.upload(Q.beta); P.ey = S.upload(Q.ey); P.h = S.upload(Q.h);
-    P.f_ptr = S.upload(f_ptr); P.f_rows = S.upload(f_rows); P.c_ptr = S.upload(c_ptr); P.c_rows = S.upload(c_rows);
-    P.yrows = S.upload(yrows);
-    S.tile_ij = S.upload(tiles);
-    P.lat = S.upload(Lt.lat); P.lat_col = S.upload(Lt.lat_col); P.lat_qcol = S.upload(Lt.lat_qcol);
-    P.lat_scale = S.upload(Lt.lat_scale); P.lat_qscale = S.upload(Lt.lat_qscale);
-    P.ch_start = S.upload(Lt.ch_start); P.ch_count = S.upload(Lt.ch_count); P.ch_w0 = S.upload(Lt.ch_w0); P.ch_dw = S.upload(Lt.ch_dw);
+    // ---- upload the program (one copy per lane) ----------------------------------------------
+#define UPQ(T, member) S.upload<T>([&](int b) -> const std::vector<T>& { return LH[b].Q->member; })
+#define UPL(T, member) S.upload<T>([&](int b) -> const std::vector<T>& { return LH[b].member; })
+    P.w = UPQ(double, w); P.col_kind = UPQ(int, col_kind); P.col_tau = UPQ(double, col_tau);
+    P.col_scale = UPQ(double, col_scale); P.pcol = UPQ(int, pcol); P.psign = UPQ(double, psign);
+    P.c = UPQ(double, c); P.freq = UPQ(int, freq); P.col = UPQ(int, col); P.alpha = UPQ(double, alpha);
+    P.beta = UPQ(double, beta); P.ey = UPQ(double, ey); P.h = UPQ(double, h);
+    P.f_ptr = UPL(int, f_ptr); P.f_rows = UPL(int, f_rows); P.c_ptr = UPL(int, c_ptr); P.c_rows = UPL(int, c_rows);
+    P.yrows = UPL(int, yrows);
+    S.tile_ij = S.upload<int>([&](int) -> const std::vector<int>& { return tiles; });
+    P.lat = UPL(int, Lt.lat); P.lat_col = UPL(int, Lt.lat_col); P.lat_qcol = UPL(int, Lt.lat_qcol);
+    P.lat_scale = UPL(double, Lt.lat_scale); P.lat_qscale = UPL(double, Lt.lat_qscale);
+    P.ch_start = UPL(int, Lt.ch_start); P.ch_count = UPL(int, Lt.ch_count); P.ch_w0 = UPL(double, Lt.ch_w0); P.ch_dw = UPL(double, Lt.ch_dw);
+#undef UPQ
+#undef UPL
     // ---- work buffers ----------------------------------------------------------------------
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
@@ -2091,26 +2273,40 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     zero_bytes = size_t(ar.base + ar.off - zero_from);
     S.slab = ar.get<double>(P.trig ? 0 : S.gp.slab_doubles);
     };
+    // first pass: only add up the sizes of ONE lane; the lanes then sit lane_bytes apart in one arena
     ar.measuring = true; ar.reset();
     { char* keep = ar.base; ar.base = nullptr; layout(); ar.base = keep; }
-    const size_t need = ar.off + 4096;
+    S.lane_bytes = (ar.off + 4095) & ~size_t(4095);
     ar.measuring = false;
-    S.ensure_arena(need);
+    S.ensure_arena(S.lane_bytes * nlanes + 4096);
     layout();
-    MBFIR_HIP(hipMemsetAsync(zero_from, 0, zero_bytes, st));
+    P.lane_bytes = S.lane_bytes;
+    S.memset_lanes(zero_from, zero_bytes);
+    // ---- lane masks ------------------------------------------------------------------------
+    auto push_masks = [&]() {                                 // row 0 = live lanes, rows q = 1..MAX_SWEEPS: lanes that run CG sweep q
+        if (nlanes == 1) return;
+        for (int b = 0; b < nlanes; ++b) {
+            S.hostMask[b] = LH[b].live ? 1 : 0;
+            for (int q = 1; q <= MAX_SWEEPS; ++q) S.hostMask[q * MAX_LANES + b] = (LH[b].live && LH[b].nsweep >= q) ? 1 : 0;
+        }
+        MBFIR_HIP(hipMemcpyAsync(S.maskT, S.hostMask, sizeof(int) * (MAX_SWEEPS + 1) * MAX_LANES, hipMemcpyHostToDevice, st));
+    };
+    push_masks();
+    P.mask = S.mask_row(0);
     // ---- build A1, norms -------------------------------------------------------------------
     if (!P.trig) hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
     else {
-        hipLaunchKernelGGL(k_build_seeds_m, dim3(cdiv(P.D1, 256), P.nchunk), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), nlanes), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
                            const_cast<double4*>(P.seed_tau));
-        hipLaunchKernelGGL(k_build_seeds_m, dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), nlanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
                            2 * P.D1 - 1, const_cast<double4*>(P.seed_h));
-        hipLaunchKernelGGL(k_build_seeds_e, dim3(cdiv(Mf, 256), P.useg), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
+        hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
     }
-    {
-        std::vector<double> sc0(S_COUNT, 0.0);
-        sc0[S_NRMH] = nrm_h; sc0[S_NRMC] = nrm_c; sc0[S_DEG] = degree; sc0[S_TAU] = 1.0; sc0[S_KAPPA] = 1.0;
-        MBFIR_HIP(hipMemcpyAsync(S.Sc, sc0.data(), sizeof(double) * S_COUNT, hipMemcpyHostToDevice, st));
+    std::vector<double> sc0((size_t)S_COUNT * nlanes, 0.0);
+    for (int b = 0; b < nlanes; ++b) {
+        double* q = sc0.data() + (size_t)b * S_COUNT;
+        q[S_NRMH] = LH[b].nrm_h; q[S_NRMC] = LH[b].nrm_c; q[S_DEG] = LH[b].degree; q[S_TAU] = 1.0; q[S_KAPPA] = 1.0;
+        MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(S.Sc) + (size_t)b * S.lane_bytes, q, sizeof(double) * S_COUNT, hipMemcpyHostToDevice, st));
     }
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_assembled = now_ms();
@@ -2121,116 +2317,137 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
     S.dd_iters = 0; S.dd_kmax_seen = 0;
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
-        hipLaunchKernelGGL(k_cone_resid, dim3(nb), dim3(256), 0, st, P, v, S.partR);
-        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, dim3(1), dim3(1024), 0, st, P, v, S.partR + 2L * nb);
-        hipLaunchKernelGGL(k_cone_fold, dim3(1), dim3(256), 0, st, S.partR, nb + (P.big ? 1 : 0), S.RB);
+        hipLaunchKernelGGL(k_cone_resid, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, v, S.partR);
+        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, v, S.partR + 2L * nb);
+        hipLaunchKernelGGL(k_cone_fold, lane_grid(dim3(1), nlanes), dim3(256), 0, st, S.partR, nb + (P.big ? 1 : 0), S.RB, S.lane_bytes, P.mask);
         S.allreduce(S.RB, 1, 1);                          // max of the cone distances
         S.allreduce(S.RB + 1, 1, 0);                      // sum of squares
-        hipLaunchKernelGGL(k_cone_shift, dim3(64), dim3(256), 0, st, P, v, S.RB);
+        hipLaunchKernelGGL(k_cone_shift, lane_grid(dim3(64), nlanes), dim3(256), 0, st, P, v, S.RB);
     };
     // ---- initial point (W = I) -------------------------------------------------------------
-    hipLaunchKernelGGL(k_unit_scaling, dim3(cdiv(std::max(std::max(P.l, P.nq3), std::max(P.big, 1)), 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_unit_scaling, lane_grid(dim3(cdiv(std::max(std::max(P.l, P.nq3), std::max(P.big, 1)), 256)), nlanes), dim3(256), 0, st,
                        P, S.dl, S.wl, S.w3, S.wbb, S.Sc);
     S.build_H();
-    hipLaunchKernelGGL(k_init_rhs, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.bx2, S.bz2);
-    int nsweep = o.refine;
-    S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA);
-    MBFIR_HIP(hipMemcpyAsync(S.x, S.dx2, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2, S.s, -1.0);
+    hipLaunchKernelGGL(k_init_rhs, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.bx2, S.bz2);
+    int nsweep_max = o.refine;
+    S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep_max, S_RNA);
+    S.copy_lanes(S.x, S.dx2, sizeof(double) * LDV);
+    hipLaunchKernelGGL(k_neg_copy_r, lane_grid(dim3(cdiv(R, 256)), nlanes), dim3(256), 0, st, P, S.dz2, S.s, -1.0);
     cone_shift(S.s);
-    hipLaunchKernelGGL(k_neg_copy_r, dim3(cdiv(R, 256)), dim3(256), 0, st, P, S.dz2 + Rp, S.z, 1.0);
+    hipLaunchKernelGGL(k_neg_copy_r, lane_grid(dim3(cdiv(R, 256)), nlanes), dim3(256), 0, st, P, S.dz2 + Rp, S.z, 1.0);
     cone_shift(S.z);
 
-    int status = ST_MAXIT, it = 0;
-    double* hs = S.hostSc;
-    double best_merit = 1e300;
-    SolveInfo best_info;
-    bool have_best = false;
-    int wall = 0;
-    bool dd_now = false, dd_prev = false;
-    (void)dd_prev;
+    int it = 0;
+    bool dd_now = false;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
-            hipLaunchKernelGGL(k_trig_eval<1>, dim3(cdiv(P.Mf, 256), P.useg), dim3(256), 0, st, P, S.x, S.UU);
+            hipLaunchKernelGGL(k_trig_eval<1>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, S.x, S.UU);
             S.apply_GT<1>(S.z, S.GTz);
-            hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
+            hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
         } else {
             S.apply_G<1>(S.x, S.Gx);
             S.apply_GT<1>(S.z, S.GTz);
-            hipLaunchKernelGGL(k_resid_rows, dim3(S.nbR), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
+            hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
         }
         if (sharded) {
             hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
             S.allreduce(S.RB, 4, 0);
         }
-        hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
-        MBFIR_HIP(hipMemcpyAsync(hs, S.Sc, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, st));
-        MBFIR_HIP(hipMemcpyAsync(S.hostFlag, S.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
+        MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
+        MBFIR_HIP(hipMemcpy2DAsync(S.hostFlag, sizeof(int) * 4, S.flag, S.lane_bytes, sizeof(int), nlanes, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
-        if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
-            // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
-            // measured before each sweep of the two KKT solves of the previous iteration
-            const double tol = REFTOL * hs[S_NRMC];
-            int need = 0;
-            bool unconverged = false;
-            for (int slot : {int(S_RNA), int(S_RNB)}) {
-                int k = -1;
-                for (int q = 0; q <= std::min(nsweep, MAX_SWEEPS); ++q)      // n_0 .. n_nsweep
-                    if (hs[slot + q] <= tol) { k = q; break; }
-                if (k < 0) unconverged = true;
-                else need = std::max(need, k);
+        bool any_live = false, any_best = false;
+        for (int b = 0; b < nlanes; ++b) {
+            LaneHost& L = LH[b];
+            if (!L.live) continue;
+            const double* hs = S.hostSc + (size_t)b * S_COUNT;
+            const int chol_fixes = S.hostFlag[4 * b];
+            SolveInfo& info = L.info;
+            if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
+                // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
+                // measured before each sweep of the two KKT solves of the previous iteration
+                const double tol = REFTOL * hs[S_NRMC];
+                int need = 0;
+                bool unconverged = false;
+                for (int slot : {int(S_RNA), int(S_RNB)}) {
+                    int k = -1;
+                    for (int q = 0; q <= std::min(L.nsweep, MAX_SWEEPS); ++q)      // n_0 .. n_nsweep
+                        if (hs[slot + q] <= tol) { k = q; break; }
+                    if (k < 0) unconverged = true;
+                    else need = std::max(need, k);
+                }
+                L.nsweep = unconverged ? std::min(MAX_SWEEPS, L.nsweep + 1) : need;
             }
-            nsweep = unconverged ? std::min(MAX_SWEEPS, nsweep + 1) : need;
-        }
-        info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
-        info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
-        if (o.verbose)
-            fprintf(stderr, "%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d\n",
-                    it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES], hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU],
-                    hs[S_ALPHA], hs[S_SIGMA], nsweep, S.hostFlag[0]);
-        if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) {
-            status = ST_NUMERICAL; break;
-        }
-        if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) {
-            status = ST_OPTIMAL; break;
-        }
-        const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
-        if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { status = ST_PRIMAL_INFEASIBLE; break; }
-        if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { status = ST_DUAL_INFEASIBLE; break; }
-        if (hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
-            // best iterate for the reduced-accuracy exit: residuals within the reduced tolerance,
-            // smallest gap measure (mirrors oracle/conic_ipm.py)
-            double merit = std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol);
-            if (merit < best_merit) {
-                best_merit = merit; best_info = info; have_best = true;
-                hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
+            info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
+            info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
+            if (o.verbose)
+                fprintf(stderr, "%s%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d\n",
+                        nlanes > 1 ? ("[" + std::to_string(b) + "] ").c_str() : "", it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES],
+                        hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU], hs[S_ALPHA], hs[S_SIGMA], L.nsweep, chol_fixes);
+            auto finish = [&](int status) { L.status = status; L.live = false; };
+            if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) { finish(ST_NUMERICAL); continue; }
+            if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) { finish(ST_OPTIMAL); continue; }
+            const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
+            if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { finish(ST_PRIMAL_INFEASIBLE); continue; }
+            if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { finish(ST_DUAL_INFEASIBLE); continue; }
+            S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;
+            if (hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
+                // best iterate for the reduced-accuracy exit: residuals within the reduced tolerance,
+                // smallest gap measure (mirrors oracle/conic_ipm.py)
+                double merit = std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol);
+                if (merit < L.best_merit) {
+                    L.best_merit = merit; L.best_info = info; L.have_best = true;
+                    S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 1;
+                    any_best = true;
+                }
             }
+            if (it == o.max_iter) { finish(ST_MAXIT); continue; }
+            // numerical wall (mirrors oracle/conic_ipm.py): the last factorisation replaced pivots and the
+            // residuals are out of the reduced-accuracy range, three iterations in a row
+            L.wall = (chol_fixes > 0 && (hs[S_PRES] > INACC_FEAS || hs[S_DRES] > INACC_FEAS)) ? L.wall + 1 : 0;
+            if (L.wall >= WALL_ITERS) { finish(ST_NUMERICAL); continue; }
+            any_live = true;
         }
-        if (it == o.max_iter) break;
-        // numerical wall (mirrors oracle/conic_ipm.py): the last factorisation replaced pivots and the
-        // residuals are out of the reduced-accuracy range, three iterations in a row
-        wall = (S.hostFlag[0] > 0 && (hs[S_PRES] > INACC_FEAS || hs[S_DRES] > INACC_FEAS)) ? wall + 1 : 0;
-        if (wall >= WALL_ITERS) { status = ST_NUMERICAL; break; }
+        if (any_best) {                                       // xbest = x / tau on the lanes with a new best iterate
+            if (nlanes > 1) {
+                for (int b = 0; b < nlanes; ++b)
+                    if (!LH[b].live) S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;
+                MBFIR_HIP(hipMemcpyAsync(S.maskT + (MAX_SWEEPS + 1) * MAX_LANES, S.hostMask + (MAX_SWEEPS + 1) * MAX_LANES, sizeof(int) * MAX_LANES,
+                                         hipMemcpyHostToDevice, st));
+                P.mask = S.mask_row(MAX_SWEEPS + 1);
+            }
+            bool want = nlanes > 1;
+            for (int b = 0; b < nlanes && !want; ++b) want = LH[b].live && S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b];
+            if (want) hipLaunchKernelGGL(k_finish_x, lane_grid(dim3(S.nbN), nlanes), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
+            P.mask = S.mask_row(0);
+        }
+        if (!any_live) break;
+        nsweep_max = 0;
+        for (int b = 0; b < nlanes; ++b)
+            if (LH[b].live) nsweep_max = std::max(nsweep_max, LH[b].nsweep);
+        push_masks();
         // scaling + H
-        hipLaunchKernelGGL(k_scaling, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
+        hipLaunchKernelGGL(k_scaling, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
         if (P.big) {
             const long ob = P.l + 3L * P.nq3;
-            hipLaunchKernelGGL(k_big_scaling, dim3(1), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc);
+            hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc,
+                               S.lane_bytes, P.mask);
         }
         S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
         if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
-        dd_prev = dd_now; dd_now = S.dd_k > 0;
+        dd_now = S.dd_k > 0;
         S.build_H(S.dd_k);
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
         if (S.dd_k > 0) S.kkt_solve_dd<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, S_RNA);
-        else S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep, S_RNA, true);  // W^-2 bz2 came with k_scaling
+        else S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep_max, S_RNA, true);  // W^-2 bz2 came with k_scaling
         double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
         auto dots = [&](const double* xx2, const double* zz2, int mode) -> int {
-            hipLaunchKernelGGL(k_dots_r, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
+            hipLaunchKernelGGL(k_dots_r, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
             int nb = std::max(S.nbC, 1);
             if (P.big) {
-                hipLaunchKernelGGL(k_big_dots, dim3(1), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
+                hipLaunchKernelGGL(k_big_dots, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
                 nb += 1;
             }
             if (sharded) {
@@ -2244,10 +2461,10 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
         // returns the number of partial rows; step_mode0_fused: the affine step length is left to k_comb_rhs
         auto dir_post = [&](const double* xx2, const double* zz2, const double* gg2, double* outA, double* outB, int mode, int ndots) -> int {
             int nb = std::max(S.nbC, 1);
-            hipLaunchKernelGGL(k_dir_post, dim3(nb), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+            hipLaunchKernelGGL(k_dir_post, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
                                S.partR2, mode, sharded ? nullptr : S.partR, ndots, xx2);
             if (P.big) {
-                hipLaunchKernelGGL(k_big_dir_post, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+                hipLaunchKernelGGL(k_big_dir_post, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
                                    S.scratch, S.partR2 + 2L * nb, mode);
                 nb += 1;
             }
@@ -2256,51 +2473,65 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
                 S.allreduce(S.RB, 2, 1);
                 hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
             } else if (mode == 1) {
-                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
+                hipLaunchKernelGGL(k_scal_step, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
             }
             return nb;
         };
         const int nd0 = dots(x2a, z2a, 0);
         const int ns0 = dir_post(x2a, z2a, g2a, S.dssa, S.wdza, 0, nd0);
         // combined direction (unsharded: sigma and bx are formed inside k_comb_rhs, and W^-2 bz comes with it)
-        hipLaunchKernelGGL(k_comb_rhs, dim3(std::max(S.nbC, 1)), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.dssa, S.wdza, S.rz, S.Sc,
+        hipLaunchKernelGGL(k_comb_rhs, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.wl, S.w3, S.lam, S.dssa, S.wdza, S.rz, S.Sc,
                            S.lds, S.bzc, sharded ? nullptr : S.partR2, ns0, S.rx, S.bxc, S.dl, S.wbz);
         if (P.big)
-            hipLaunchKernelGGL(k_big_comb_rhs, dim3(1), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
+            hipLaunchKernelGGL(k_big_comb_rhs, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
         if (S.dd_k > 0) S.kkt_solve_dd<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
-        else S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep, S_RNB, true);
+        else S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep_max, S_RNB, true);
         const int nd1 = dots(S.dxc, S.dzc, 1);
         dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
-        hipLaunchKernelGGL(k_update, dim3(cdiv(std::max(N, R), 256)), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
+        hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
     }
-    const double* xsrc = S.xout;
-    hipLaunchKernelGGL(k_finish_x, dim3(S.nbN), dim3(256), 0, st, P, S.x, S.Sc, S.xout);
-    if ((status == ST_MAXIT || status == ST_NUMERICAL) && have_best && best_info.pres <= INACC_FEAS &&
-        best_info.dres <= INACC_FEAS && (best_info.relgap <= INACC_GAP || best_info.gap <= o.abstol)) {
-        // the reference accepts CVX's 'Inaccurate/Solved' (fir_ap_cvx.m:176): reduced tolerances
-        int keep_it = info.iters;
-        info = best_info; info.iters = keep_it;
-        status = ST_OPTIMAL_INACCURATE;
-        MBFIR_HIP(hipMemcpyAsync(S.xout, S.xbest, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
+    P.mask = nullptr;                                         // the final x / tau of every lane, finished or not
+    hipLaunchKernelGGL(k_finish_x, lane_grid(dim3(S.nbN), nlanes), dim3(256), 0, st, P, S.x, S.Sc, S.xout);
+    xouts.assign(nlanes, std::vector<double>());
+    infos.assign(nlanes, SolveInfo());
+    for (int b = 0; b < nlanes; ++b) {
+        LaneHost& L = LH[b];
+        if (L.live) L.status = ST_MAXIT;
+        char* xo = reinterpret_cast<char*>(S.xout) + (size_t)b * S.lane_bytes;
+        if ((L.status == ST_MAXIT || L.status == ST_NUMERICAL) && L.have_best && L.best_info.pres <= INACC_FEAS &&
+            L.best_info.dres <= INACC_FEAS && (L.best_info.relgap <= INACC_GAP || L.best_info.gap <= o.abstol)) {
+            // the reference accepts CVX's 'Inaccurate/Solved' (fir_ap_cvx.m:176): reduced tolerances
+            const int keep_it = L.info.iters;
+            L.info = L.best_info; L.info.iters = keep_it;
+            L.status = ST_OPTIMAL_INACCURATE;
+            MBFIR_HIP(hipMemcpyAsync(xo, reinterpret_cast<char*>(S.xbest) + (size_t)b * S.lane_bytes, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
+        }
+        xouts[b].assign(N, 0.0);
+        MBFIR_HIP(hipMemcpyAsync(xouts[b].data(), xo, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     }
-    (void)xsrc;
-    (void)t_begin;
-    info.status = status;
-    info.ms_assemble = t_assembled - t_begin;
-    xout.assign(N, 0.0);
-    MBFIR_HIP(hipMemcpyAsync(xout.data(), S.xout, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     MBFIR_HIP(hipStreamSynchronize(st));
-    info.ms_solve = now_ms() - t_assembled;
-    S.collect_times(info.ms_gram, info.ms_chol, info.h_builds);
-    info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
-    info.lattice = P.trig;
-    info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
-    info.chol_launches = info.h_builds * (P.np / 64 + 1);
-    info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
-    info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
-                            : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
-    return status;
+    const double t_end = now_ms();
+    double ms_gram = 0, ms_chol = 0;
+    int builds = 0;
+    S.collect_times(ms_gram, ms_chol, builds);
+    for (int b = 0; b < nlanes; ++b) {
+        SolveInfo& info = infos[b];
+        info = LH[b].info;
+        info.status = LH[b].status;
+        info.ms_assemble = t_assembled - t_begin;
+        info.ms_solve = t_end - t_assembled;                  // of the whole lock-step batch
+        info.ms_gram = ms_gram; info.ms_chol = ms_chol; info.h_builds = builds;
+        info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
+        info.lattice = P.trig;
+        info.lanes = nlanes;
+        info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
+        info.chol_launches = builds * (P.np / 64 + 1);
+        info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
+        info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
+                                : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
+    }
+    S.nlanes_last = nlanes;
 }
 
 }  // namespace mbfir
@@ -2310,12 +2541,14 @@ int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<doub
 // ================================================================================================
 namespace mbfir {
 
-void Solver::specfact_last(int n, double* h_re, double* h_im) {
+void Solver::specfact_last(int n, double* h_re, double* h_im, int lane) {
     Impl& S = *impl;
     MBFIR_HIP(hipSetDevice(S.device));
-    specfact_launch(S.xout, n, S.sfwork, S.hout, S.st);
+    if (lane < 0 || lane >= S.nlanes_last) throw HipError("specfact: no such lane");
+    const size_t off = (size_t)lane * S.lane_bytes / sizeof(double);
+    specfact_launch(S.xout + off, n, S.sfwork + off, S.hout + off, S.st);
     std::vector<double> h(2 * (size_t)n);
-    MBFIR_HIP(hipMemcpyAsync(h.data(), S.hout, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(h.data(), S.hout + off, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));
     for (int i = 0; i < n; ++i) { h_re[i] = h[2 * i]; h_im[i] = h[2 * i + 1]; }
 }
