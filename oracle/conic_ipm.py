@@ -347,7 +347,7 @@ def next_sweeps(norm_lists, nsweep, tol):
 
 
 def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
-          reltol=1e-8, refine=2, verbose=False, history=None, ddkkt=None):
+          reltol=1e-8, refine=2, verbose=False, history=None, ddkkt=None, _exp=None):
     """Returns dict(status, x, s, z, iters, pcost, dcost, gap, pres, dres).
 
     Stopping rule (all quantities of the de-homogenised point x/tau ...):
@@ -677,7 +677,21 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             status = STATUS_NUMERICAL
             break
         dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, dk_c, x2, z2, Gx2)
-        alpha = step_of(dss, wdz, dtau, dkap, STEP)
+        alpha = step_of(dss, wdz, dtau, dkap, (_exp or {}).get("step", STEP))
+        if _exp and _exp.get("nbhd"):
+            gam = _exp["nbhd"]
+            for _bt in range(30):
+                sn, zn = s + alpha * ds, z + alpha * dz
+                tn, kn = tau + alpha * dtau, kappa + alpha * dkap
+                mun = (sn @ zn + tn * kn) / (cone.degree + 1)
+                prods = [sn[:cone.l] * zn[:cone.l]] if cone.l else []
+                if cone.nq3:
+                    sq, zq = sn[cone.o3:cone.ob].reshape(-1, 3), zn[cone.o3:cone.ob].reshape(-1, 3)
+                    prods.append((sq[:, 0] - np.hypot(sq[:, 1], sq[:, 2])) * (zq[:, 0] - np.hypot(zq[:, 1], zq[:, 2])))
+                prods.append(np.array([tn * kn]))
+                if np.concatenate(prods).min() >= gam * mun:
+                    break
+                alpha *= 0.9
         if sweep_log:                                         # (iterations on the extended-precision path keep the count)
             nsweep[0] = next_sweeps(sweep_log, nsweep[0], REFTOL * nrm_c)
         if history is not None:

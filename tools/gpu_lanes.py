@@ -29,7 +29,7 @@ def run(n, m, count, lanes, streams, ref=None):
         n, m, count, lanes, streams, dt, count / dt, ok, min(its), max(its), res[0][2]["lanes"], dev), flush=True)
     return pc
 
-which = sys.argv[1] if len(sys.argv) > 1 else "c4"
+which = (sys.argv[1] if len(sys.argv) > 1 else "c4") if __name__ == "__main__" else "none"
 if which == "c4":
     ref = run(200, 4096, 64, 1, 4)
     for lanes, streams in ((4, 4), (8, 4), (16, 4), (16, 2), (32, 2), (32, 1), (64, 1)):
@@ -37,7 +37,7 @@ if which == "c4":
     run(200, 4096, 256, 32, 4)
     run(200, 4096, 256, 32, 2)
     run(200, 4096, 256, 16, 4)
-else:
+elif which == "head":
     ref = run(512, 16384, 16, 1, 4)
     for lanes, streams in ((2, 4), (4, 4), (4, 2), (8, 2), (8, 1), (16, 1)):
         run(512, 16384, 16, lanes, streams, ref)
