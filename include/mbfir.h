@@ -95,6 +95,7 @@ typedef struct mbfir_info {
     int builds;          /* normal-matrix builds (= iterations + 1)                                       */
     int dd_iters;        /* iterations that ran the extended-precision KKT solve (opts.ddkkt)              */
     int dd_kmax;         /* largest number of strong eigen-directions it carried                          */
+    int collectives;     /* all-reduces a row-sharded solve issued (0 otherwise)                                   */
     int lanes;           /* designs that shared this design's lock-step batch (ms_solve, ms_gram, ms_chol are then
                             those of the whole batch)                                                      */
 } mbfir_info;
@@ -107,6 +108,17 @@ typedef struct mbfir_info {
  * every G'v and preconditioner application (N doubles each) and a few scalars -- all ranks make the
  * same sequence of calls. */
 typedef int (*mbfir_allreduce_fn)(void* buf, long count, int op, void* user);
+
+/* RCCL communicator for row-sharded solves (one process per GPU): rank 0 calls mbfir_comm_unique_id and
+ * hands the 128 bytes to the other ranks (the host language's own channel: torch.distributed, MPI, a file), every rank
+ * then calls mbfir_comm_init with its rank.  With a communicator the per-iteration reductions are ncclAllReduce calls
+ * (ncclDouble, sum / max) enqueued on the solver's stream: no host synchronisation and no callback per collective.
+ * Without one, mbfir_set_allreduce's hook is used (the CPU/gloo rehearsal path).  RCCL is bound at run time.      */
+int  mbfir_comm_unique_id(mbfir_ctx* ctx, char* id128);
+int  mbfir_comm_init(mbfir_ctx* ctx, int nranks, int rank, const char* id128);
+void mbfir_comm_destroy(mbfir_ctx* ctx);
+/* test hook: all-reduce the host array v (n doubles; op 0 sum, 1 max) through the context's communicator, on its stream */
+int  mbfir_test_comm_allreduce(mbfir_ctx* ctx, double* v, long n, int op);
 
 mbfir_ctx*  mbfir_create(int device_id);
 void        mbfir_destroy(mbfir_ctx* ctx);

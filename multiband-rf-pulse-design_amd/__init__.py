@@ -51,7 +51,7 @@ class Info(C.Structure):
                 ("ms_total", C.c_double), ("ms_gram", C.c_double), ("ms_chol", C.c_double),
                 ("gram_flop", C.c_double), ("gram_launches", C.c_int), ("lattice", C.c_int),
                 ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int),
-                ("dd_iters", C.c_int), ("dd_kmax", C.c_int), ("lanes", C.c_int)]
+                ("dd_iters", C.c_int), ("dd_kmax", C.c_int), ("collectives", C.c_int), ("lanes", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -79,6 +79,10 @@ SYMBOLS = {
     "mbfir_default_opts": (None, [C.POINTER(Opts)]),
     "mbfir_set_allreduce": (None, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "mbfir_version": (C.c_char_p, []),
+    "mbfir_comm_unique_id": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mbfir_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "mbfir_comm_destroy": (None, [C.c_void_p]),
+    "mbfir_test_comm_allreduce": (C.c_int, [C.c_void_p, _dp, C.c_long, C.c_int]),
     "mbfir_last_solution": (C.c_int, [C.c_void_p, _dp, C.c_int]),
     "mbfir_ap_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double,
                                  C.POINTER(Opts), _dp, _dp, C.POINTER(Info)]),
@@ -180,9 +184,43 @@ class Context:
         return z[:k]
 
     def set_allreduce(self, fn):
-        """fn(ptr:int, count:int, op:int) -> int ; op 0 = sum, 1 = max (device pointer)."""
-        self._cb = ALLREDUCE_FN(lambda buf, count, op, user: int(fn(buf, count, op)))
+        """fn(ptr:int, count:int, op:int) -> int ; op 0 = sum, 1 = max (device pointer).  An exception inside the
+        hook is logged and reported as a failed collective (the solve then raises) instead of being swallowed by
+        ctypes with an undefined return value."""
+        def cb(buf, count, op, user):
+            try:
+                return int(fn(buf, count, op))
+            except BaseException:                          # noqa: BLE001 -- must not propagate into C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLREDUCE_FN(cb)
         load_library().mbfir_set_allreduce(self._h, self._cb, None)
+
+    def init_comm(self, rank=None, size=None, group=None):
+        """Native RCCL communicator for row-sharded solves: rank 0 makes the unique id, torch.distributed (any
+        backend) carries its 128 bytes to the other ranks, every rank joins (mbfir_comm_init).  From then on the
+        solver issues its all-reduces itself, on its own stream."""
+        import torch.distributed as dist
+        lib = load_library()
+        rank = dist.get_rank(group) if rank is None else rank
+        size = dist.get_world_size(group) if size is None else size
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _check(self, lib.mbfir_comm_unique_id(self._h, buf))
+        box = [bytes(buf.raw)]
+        if size > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        _check(self, lib.mbfir_comm_init(self._h, int(size), int(rank), box[0]))
+
+    def comm_allreduce(self, v, op=0):
+        """test hook: all-reduce a host array through the context's RCCL communicator (in place)."""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        _check(self, load_library().mbfir_test_comm_allreduce(self._h, _ptr(v), v.size, int(op)))
+        return v
+
+    def destroy_comm(self):
+        load_library().mbfir_comm_destroy(self._h)
 
 
 class _DevArray:

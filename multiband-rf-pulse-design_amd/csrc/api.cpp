@@ -21,6 +21,7 @@ struct mbfir_ctx {
     std::string err;
     mbfir_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    bool has_comm = false;
 };
 
 namespace {
@@ -78,7 +79,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->gram_launches = si.lattice ? 0 : si.h_builds * (P.quad ? 3 : 1);
     info->lattice = si.lattice;
     info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
-    info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes;
+    info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes; info->collectives = si.collectives;
 }
 
 // Solution vector -> taps, per designer.  lane: which design of the solver's last lock-step batch (fir_ap_cvx runs
@@ -127,8 +128,8 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         if (info) info->status = asm_rc;
         return asm_rc;
     }
-    if (opts && opts->shard_size > 1 && !ctx->allreduce) {
-        ctx->err = "row-sharded solve requested without an all-reduce hook";
+    if (opts && opts->shard_size > 1 && !ctx->allreduce && !ctx->has_comm) {
+        ctx->err = "row-sharded solve requested without a communicator (mbfir_comm_init) or an all-reduce hook";
         return MBFIR_E_ARG;
     }
     try {
@@ -195,6 +196,27 @@ void mbfir_set_allreduce(mbfir_ctx* ctx, mbfir_allreduce_fn fn, void* user) {
     ctx->allreduce = fn;
     ctx->allreduce_user = user;
     ctx->solver->set_allreduce(fn, user);
+}
+
+int mbfir_comm_unique_id(mbfir_ctx* ctx, char* id128) {
+    if (!ctx || !id128) return MBFIR_E_ARG;
+    try { ctx->solver->comm_unique_id(id128); return 0; }
+    catch (const std::exception& e) { ctx->err = e.what(); return MBFIR_E_HIP; }
+}
+int mbfir_comm_init(mbfir_ctx* ctx, int nranks, int rank, const char* id128) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return MBFIR_E_ARG;
+    try { ctx->solver->comm_init(nranks, rank, id128); ctx->has_comm = true; return 0; }
+    catch (const std::exception& e) { ctx->err = e.what(); return MBFIR_E_HIP; }
+}
+int mbfir_test_comm_allreduce(mbfir_ctx* ctx, double* v, long n, int op) {
+    if (!ctx || !v || n < 0) return MBFIR_E_ARG;
+    try { ctx->solver->test_comm_allreduce(v, n, op); return 0; }
+    catch (const std::exception& e) { ctx->err = e.what(); return MBFIR_E_HIP; }
+}
+void mbfir_comm_destroy(mbfir_ctx* ctx) {
+    if (!ctx) return;
+    ctx->solver->comm_destroy();
+    ctx->has_comm = false;
 }
 
 int mbfir_last_solution(mbfir_ctx* ctx, double* z, int capacity) {

@@ -27,6 +27,7 @@ struct SolveInfo {
     int chol_launches = 0;  // k_chol_step launches timed in ms_chol
     double chol_flop = 0;   // factorisation + triangular inverse, per build
     int dd_iters = 0, dd_kmax = 0;   // iterations that ran the extended-precision solve; largest strong set
+    int collectives = 0;    // all-reduces the (row-sharded) solve issued
     int lanes = 1;          // designs that shared the lock-step batch (ms_* are those of the whole batch)
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
 };
@@ -68,6 +69,11 @@ public:
     void test_mfma_peak(double* tf_mfma, double* tf_valu);
     void test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, double* ms_gram);
     void* stream() const;
+    // RCCL communicator for row-sharded solves (one process per GPU): rank 0 makes the id, everybody joins
+    void comm_unique_id(char* id128);
+    void comm_init(int nranks, int rank, const char* id128);
+    void comm_destroy();
+    void test_comm_allreduce(double* v, long n, int op);
     void set_allreduce(int (*fn)(void*, long, int, void*), void* user);
 
 private:

@@ -32,7 +32,43 @@
 #include <cstring>
 #include <vector>
 
+// RCCL is bound at run time (dlopen): a process that has torch loaded shares torch's librccl, and the library
+// still loads on a machine without RCCL (the CPU-side tests bind every symbol of include/mbfir.h).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 namespace mbfir {
+
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string err;
+};
+static RcclApi& rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api;
+    tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // already in the process (torch's copy)?
+        if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { api.err = "librccl not found"; return api; }
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
+    if (!api.ok) api.err = "librccl lacks the expected symbols";
+    return api;
+}
 
 enum {
     S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
@@ -1683,8 +1719,19 @@ struct Solver::Impl {
     int (*ar_fn)(void*, long, int, void*) = nullptr;
     void* ar_user = nullptr;
     double* RB = nullptr;        // 16 doubles: reduction mailbox
+    // RCCL communicator of this context (mbfir_comm_init): the sharded solve's reductions are ncclAllReduce calls
+    // enqueued on the solver stream -- no host synchronisation, no callback.  Without one the hook is used.
+    ncclComm_t comm = nullptr;
+    int comm_size = 0, comm_rank = 0;
+    long n_collectives = 0;      // issued by the current solve
     void allreduce(double* buf, long count, int op) {
         if (shard_size <= 1) return;
+        ++n_collectives;
+        if (comm) {
+            ncclResult_t r = rccl().AllReduce(buf, buf, size_t(count), ncclDouble, op == 1 ? ncclMax : ncclSum, comm, st);
+            if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "failed"));
+            return;
+        }
         MBFIR_HIP(hipStreamSynchronize(st));
         if (!ar_fn || ar_fn(buf, count, op, ar_user) != 0) throw HipError("all-reduce hook failed");
     }
@@ -2061,6 +2108,7 @@ Solver::Solver(int device) : impl(new Impl()) {
 Solver::~Solver() {
     if (!impl) return;
     hipSetDevice(impl->device);
+    comm_destroy();
     if (impl->ar.base) hipFree(impl->ar.base);
     if (impl->hostSc) hipHostFree(impl->hostSc);
     if (impl->hostFlag) hipHostFree(impl->hostFlag);
@@ -2073,6 +2121,42 @@ Solver::~Solver() {
     delete impl;
 }
 void* Solver::stream() const { return impl->st; }
+void Solver::comm_unique_id(char* id128) {
+    RcclApi& R = rccl();
+    if (!R.ok) throw HipError("RCCL unavailable: " + R.err);
+    ncclUniqueId id;
+    ncclResult_t r = R.GetUniqueId(&id);
+    if (r != ncclSuccess) throw HipError("ncclGetUniqueId failed");
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+}
+void Solver::comm_init(int nranks, int rank, const char* id128) {
+    RcclApi& R = rccl();
+    if (!R.ok) throw HipError("RCCL unavailable: " + R.err);
+    MBFIR_HIP(hipSetDevice(impl->device));
+    comm_destroy();
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = R.CommInitRank(&impl->comm, nranks, id, rank);
+    if (r != ncclSuccess) { impl->comm = nullptr; throw HipError(std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "failed")); }
+    impl->comm_size = nranks; impl->comm_rank = rank;
+}
+// test hook: all-reduce a host array through the context's communicator on the solver stream
+void Solver::test_comm_allreduce(double* v, long n, int op) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    if (!S.comm) throw HipError("no communicator (mbfir_comm_init)");
+    void* d = nullptr;
+    MBFIR_HIP(hipMalloc(&d, size_t(std::max<long>(n, 1)) * 8));
+    MBFIR_HIP(hipMemcpyAsync(d, v, size_t(n) * 8, hipMemcpyHostToDevice, S.st));
+    ncclResult_t r = rccl().AllReduce(d, d, size_t(n), ncclDouble, op == 1 ? ncclMax : ncclSum, S.comm, S.st);
+    MBFIR_HIP(hipMemcpyAsync(v, d, size_t(n) * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+    hipFree(d);
+    if (r != ncclSuccess) throw HipError("ncclAllReduce failed");
+}
+void Solver::comm_destroy() {
+    if (impl->comm) { hipStreamSynchronize(impl->st); rccl().CommDestroy(impl->comm); impl->comm = nullptr; }
+}
 void Solver::set_allreduce(int (*fn)(void*, long, int, void*), void* user) { impl->ar_fn = fn; impl->ar_user = user; }
 
 static double now_ms() {
@@ -2157,7 +2241,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     // ---- row sharding: this process keeps the frequencies i % size == rank (program.h) ----------
     S.shard_rank = o.shard_size > 1 ? o.shard_rank : 0;
     S.shard_size = o.shard_size > 1 ? o.shard_size : 1;
-    if (S.shard_size > 1 && !S.ar_fn) throw HipError("row-sharded solve without an all-reduce hook");
+    if (S.shard_size > 1 && !S.ar_fn && !S.comm) throw HipError("row-sharded solve without a communicator or an all-reduce hook");
+    if (S.comm && S.shard_size > 1 && (S.comm_size != S.shard_size || S.comm_rank != S.shard_rank))
+        throw HipError("row-sharded solve: shard_rank / shard_size differ from the RCCL communicator's");
+    S.n_collectives = 0;
     if (S.shard_size > 1 && nlanes > 1) throw HipError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
@@ -2177,6 +2264,18 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     }
     const TrigProgram& Q = *LH[0].Q;
     const LatticeInfo& Lt = LH[0].Lt;
+    if (S.shard_size > 1 && !o.dense_trig) {
+        // every rank must take the same path (it selects the sequence and the sizes of the collectives): the
+        // lattice path only if EVERY shard has the structure -- a min all-reduce of the local verdicts
+        S.ensure_arena(4096);
+        double* dv = reinterpret_cast<double*>(S.ar.base);
+        S.hostSc[0] = LH[0].Lt.ok ? -1.0 : 0.0;                // min(v) = -max(-v); the collective knows sum and max
+        MBFIR_HIP(hipMemcpyAsync(dv, S.hostSc, sizeof(double), hipMemcpyHostToDevice, st));
+        S.allreduce(dv, 1, 1);
+        MBFIR_HIP(hipMemcpyAsync(S.hostSc, dv, sizeof(double), hipMemcpyDeviceToHost, st));
+        MBFIR_HIP(hipStreamSynchronize(st));
+        if (S.hostSc[0] > -0.5) LH[0].Lt = LatticeInfo();      // somebody lacks it: dense path everywhere
+    }
     for (int b = 1; b < nlanes; ++b) {
         const TrigProgram& Qb = *LH[b].Q;
         const LatticeInfo& Lb = LH[b].Lt;
@@ -2525,6 +2624,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
         info.lattice = P.trig;
         info.lanes = nlanes;
+        info.collectives = int(S.n_collectives);
         info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
         info.chol_launches = builds * (P.np / 64 + 1);
         info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);

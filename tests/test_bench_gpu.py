@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--n", "128", "--grid-m", "4096",
-                        "--cpu-iters", "1"], capture_output=True, text=True, timeout=600)
+                        "--designs", "8", "--lanes", "4", "--cpu-iters", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -32,3 +32,41 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_full_convergence_cpu_leg_and_distinct_designs():
+    """The cpu_baseline leg runs the oracle to convergence (no extrapolation) when asked to, and the timed batch holds
+    distinct designs (iteration counts differ)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--n", "100", "--grid-m", "2048",
+                        "--designs", "16", "--lanes", "4", "--streams", "2", "--cpu-iters", "-1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    cb = d["cpu_baseline"]
+    assert cb["extrapolated"] is False and "to convergence" in cb["sample"]
+    g, c = cb["pcost_gpu_vs_cpu"]
+    assert abs(g - c) <= 1e-8 * abs(c)                      # the two legs solved the same design to the same optimum
+    assert d["config"]["designs_per_step_per_rank"] == 16 and d["config"]["lanes"] == 4
+    assert d["ms_breakdown_lockstep_unit"]["lanes"] == 4 and d["roofline"]["frac"] > 0
+
+
+def test_row_sharded_bench_as_two_processes_over_gloo():
+    """`bench.py --gpus 2 --mode shard --backend gloo`: two ranks launched as child processes (before this process's
+    children touch the GPU), sharing the one GPU, the solver's reductions going through the host hook.  Exercises the
+    multi-process path end to end: rendezvous, partition, every collective of the sharded iteration, rank-0 output.
+    The taps of the sharded solve equal the unsharded solve's (checked through the objective and the iteration count
+    in the JSON; tests/test_shard_gpu.py compares taps)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "shard", "--backend", "gloo",
+                        "--steps", "1", "--warmup", "0", "--taps", "64", "--grid-m", "1024"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["shard"]["collectives_per_iteration"] > 0 and "hook" in d["shard"]["reductions"]

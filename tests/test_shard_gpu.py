@@ -93,3 +93,19 @@ def test_row_sharded_dense_path_all_reduces_the_normal_matrix(name):
         assert s == s0 == "Solved" and info["lattice"] == 0 and relinf(h, h0) <= 1e-6
         assert np.array_equal(h, res[0][0])
     assert sum(i["n_rows"] for _, _, i in res) == i0["n_rows"]
+
+
+def test_native_rccl_communicator_single_rank():
+    """mbfir_comm_unique_id / mbfir_comm_init / ncclAllReduce on the solver stream: with the one GPU of this box the
+    communicator has a single rank (RCCL refuses two ranks on one device), which still exercises the run-time binding
+    of librccl, the communicator life cycle and the on-stream collective; the multi-rank exchange itself is exercised
+    over gloo (tests/test_bench_gpu.py) and by the driver's 8-GPU run."""
+    ctx = mbfir.Context(0)
+    ctx.init_comm(rank=0, size=1)
+    v = np.arange(1000, dtype=np.float64) * 0.5
+    assert np.array_equal(ctx.comm_allreduce(v.copy(), 0), v)
+    assert np.array_equal(ctx.comm_allreduce(v.copy(), 1), v)
+    with pytest.raises(mbfir.MbfirError, match="communicator"):
+        mbfir.fir_linprog(*CASES["lin_real33"][1], opts=mbfir.make_opts(shard_rank=0, shard_size=2), ctx=ctx)   # sizes differ
+    ctx.destroy_comm()
+    ctx.close()
