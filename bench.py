@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--n", "--taps", dest="n", type=int, default=512)
     ap.add_argument("--grid-m", type=int, default=16384)
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch")
-    ap.add_argument("--designs", type=int, default=32, help="distinct designs per step and rank")
+    ap.add_argument("--designs", type=int, default=64, help="distinct designs per step and rank")
     ap.add_argument("--lanes", type=int, default=8, help="designs per lock-step unit (mbfir_opts.lanes; 1 = one design per stream)")
     ap.add_argument("--streams", type=int, default=4, help="contexts / HIP streams the units are spread over")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="cpu_baseline leg: -1 the oracle to convergence on one design "

@@ -696,6 +696,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             nsweep[0] = next_sweeps(sweep_log, nsweep[0], REFTOL * nrm_c)
         if history is not None:
             sl_, zl_ = s[:cone.l], z[:cone.l]
+            _ts, _tz = _max_step(cone, lam, dss), _max_step(cone, lam, wdz)
+            history[-1].update(alpha_s=min(1.0, 0.99 / _ts) if _ts > 0 else 1.0, alpha_z=min(1.0, 0.99 / _tz) if _tz > 0 else 1.0)
             history[-1].update(alpha=alpha, alpha_a=alpha_a, sigma=sigma,
                                cmin=(sl_ * zl_).min() / mu if cone.l else 1.0,
                                cmax=(sl_ * zl_).max() / mu if cone.l else 1.0)

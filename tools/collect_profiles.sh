@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-2 profile collection on the GPU box (run through gpurun from the repo root).  Every rocprofv3 call puts the
+# program itself after `--` (python3 ...), counters go in their own passes with --kernel-trace only.
+#   bash tools/collect_profiles.sh            -> gpurun_out/r02/*  (then: python tools/rocprof_summary.py)
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r02
+mkdir -p $OUT
+UNIT="tools/gpu_lanes_one.py 512 16384 8 8 1 1"          # one lock-step unit of 8 headline designs, one stream
+# 1. the bench line itself, then the same command under the kernel trace
+python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench_trace.log 2>&1 || exit 1
+# 2. one lock-step unit alone: kernel trace and the counter passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unit_trace -o unit -- python3 $UNIT > $OUT/unit_trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/unit_pmc_busy -o unit -- python3 $UNIT > $OUT/unit_pmc_busy.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/unit_pmc_insts -o unit -- python3 $UNIT > $OUT/unit_pmc_insts.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/unit_pmc_fetch -o unit -- python3 $UNIT > $OUT/unit_pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/unit_pmc_write -o unit -- python3 $UNIT > $OUT/unit_pmc_write.log 2>&1 || exit 1
+# 3. the dense path (k_gram on the matrix cores): one design, one stream
+DENSE="tools/gpu_dense_one.py 512 16384"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense_trace -o dense -- python3 $DENSE > $OUT/dense_trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/dense_pmc_busy -o dense -- python3 $DENSE > $OUT/dense_pmc_busy.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/dense_pmc_insts -o dense -- python3 $DENSE > $OUT/dense_pmc_insts.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/dense_pmc_fetch -o dense -- python3 $DENSE > $OUT/dense_pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/dense_pmc_write -o dense -- python3 $DENSE > $OUT/dense_pmc_write.log 2>&1 || exit 1
+find $OUT -name "*.csv" | head -40
