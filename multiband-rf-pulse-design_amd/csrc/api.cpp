@@ -138,19 +138,22 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         std::vector<double> x;
         SolveOpts so = to_opts(opts, P.which);
         int st = ctx->solver->solve(P, so, x, si);
-        // The lattice path forms the normal matrix from trigonometric moments; its rounding noise (recurrences,
-        // ~1e-14 relative) is above that of the dense Gram products, so on programs that end near cond(H) ~ 1e14
-        // it can hit the numerical wall a few iterations before the dense path does.
-        // A numerical failure there -- not an infeasibility certificate -- is retried once on the dense path.
-        if (status_to_rc(st) == MBFIR_NUMERICAL && si.lattice && !so.dense_trig && so.shard_size <= 1 &&
-            (double)P.Mf * P.N() <= 6e8) {
+        // A numerical failure (never an infeasibility certificate) is a precision limit of the double-precision normal
+        // equations: near cond(H) ~ 1e14 the Cholesky factor starts replacing pivots -- a few iterations earlier on the
+        // lattice path, whose moments carry 1e-14 of recurrence noise, than on the dense one.  The
+        // remedy is precision, not the path: retry once with the extended-precision KKT solve (same path), and only if
+        // that fails too once more on the dense path.
+        auto retry = [&](bool dense) {
             const SolveInfo first = si;
-            so.dense_trig = true;
+            so.ddkkt_theta = DDKKT_THETA;
+            so.dense_trig = so.dense_trig || dense;
             st = ctx->solver->solve(P, so, x, si);
             si.ms_assemble += first.ms_assemble; si.ms_solve += first.ms_solve; si.ms_chol += first.ms_chol;
             si.ms_gram += first.ms_gram; si.h_builds += first.h_builds; si.chol_launches += first.chol_launches;
             si.chol_flop += first.chol_flop; si.iters += first.iters; si.dd_iters += first.dd_iters;
-        }
+        };
+        if (status_to_rc(st) == MBFIR_NUMERICAL && so.shard_size <= 1 && !(so.ddkkt_theta > 0) && !(opts && opts->ddkkt < 0)) retry(false);
+        if (status_to_rc(st) == MBFIR_NUMERICAL && si.lattice && !so.dense_trig && so.shard_size <= 1 && (double)P.Mf * P.N() <= 6e8) retry(true);
         ctx->last_x = x;
         double t_solved = now_ms();
         int rc = status_to_rc(st);

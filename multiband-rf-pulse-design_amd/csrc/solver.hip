@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1644,8 +1645,10 @@ struct LatticeInfo {
     std::vector<int> lat, lat_col, lat_qcol, ch_start, ch_count;
     std::vector<double> lat_scale, lat_qscale, ch_w0, ch_dw;
 };
-static LatticeInfo analyse_lattice(const TrigProgram& Q) {
+// chunk_len: longest run of frequencies one recurrence covers between two exact sincos seeds (<= CHK)
+static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = CHK) {
     LatticeInfo L;
+    if (const char* ev = std::getenv("MBFIR_CHUNK")) chunk_len = std::max(4, std::min(CHK, std::atoi(ev)));
     const int Nt = Q.Nt, Mf = Q.Mf;
     if (Nt <= 0 || Mf <= 0) return L;
     double tmin = Q.col_tau[0];
@@ -1682,7 +1685,7 @@ static LatticeInfo analyse_lattice(const TrigProgram& Q) {
         int k = i + 1;
         if (k < Mf) {
             const double dw = Q.w[k] - Q.w[i];
-            while (k < Mf && k - i < CHK && std::fabs(Q.w[k] - (Q.w[i] + (k - i) * dw)) <= tol) ++k;
+            while (k < Mf && k - i < chunk_len && std::fabs(Q.w[k] - (Q.w[i] + (k - i) * dw)) <= tol) ++k;
         }
         int cnt = k - i;
         double dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0;
@@ -1691,7 +1694,7 @@ static LatticeInfo analyse_lattice(const TrigProgram& Q) {
         L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(Q.w[i]); L.ch_dw.push_back(dwf);
         i += cnt;
     }
-    if ((long)L.ch_start.size() > Mf / 8 + 64) return L;       // grid too irregular: the dense path is the better one
+    if ((long)L.ch_start.size() > (long)Mf * 16 / chunk_len / 8 + 64) return L;       // grid too irregular: the dense path is the better one
     L.tmin = tmin; L.D1 = D1; L.ok = true;
     return L;
 }
@@ -2293,6 +2296,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (nlanes > 1 && !P.trig) throw HipError("lock-step batch needs the lattice path");
     P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
     P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
+    if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
     P.nchunk = int(Lt.ch_start.size());
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));

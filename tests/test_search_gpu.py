@@ -103,18 +103,25 @@ def test_fir_qp_search_matches_the_oracle():
     assert relinf(hg, ho) <= 1e-6
 
 
-def test_lattice_numerical_failure_is_retried_on_the_dense_path():
-    """fir_ap_cvx(20, ..., 1e5): the moment-based normal matrix hits the numerical wall at iteration 19, the dense
-    Gram path follows the oracle to a clean solve (25 iterations); the entry point retries by itself."""
+def test_numerical_failure_is_retried_in_extended_precision_on_the_same_path():
+    """fir_ap_cvx(20, ..., 1e5) (fir_qp.m's lambda): the double-precision normal equations hit the numerical wall at
+    iteration 19 on the lattice path (cond(H) ~ 1e14; the dense Gram products last a few iterations longer).  The entry
+    point retries by itself with the extended-precision KKT solve -- on the SAME lattice path -- and follows the oracle to
+    a clean full-accuracy solve in the oracle's 25 iterations; forcing ddkkt from the start gives the same without the
+    first attempt."""
     from oracle import designers
     f, a, d = [-0.25, 0.25, 0.45, 1.0], [0.15, 0.15, 0, 0], [0.004, 0.002]
     h, s, i = mbfir.fir_ap_cvx(20, f, a, d, 1e5, info=True)
-    ho, so = designers.fir_ap_cvx(20, f, a, d, 1e5)
-    assert s == so == "Solved" and i["lattice"] == 0 and i["relgap"] <= 1e-8
+    ho, so, io = designers.fir_ap_cvx(20, f, a, d, 1e5, info=True)
+    assert s == so == "Solved" and i["lattice"] == 1 and i["dd_iters"] > 0 and i["relgap"] <= 1e-8 and i["dres"] <= 1e-8
     assert relinf(h, ho) <= 1e-6
+    h2, s2, i2 = mbfir.fir_ap_cvx(20, f, a, d, 1e5, info=True, opts=mbfir.make_opts(ddkkt=1))
+    assert s2 == "Solved" and i2["lattice"] == 1 and i2["iters"] == io["iters"] and relinf(h2, ho) <= 1e-6
+    h3, s3, i3 = mbfir.fir_ap_cvx(20, f, a, d, 1e5, info=True, opts=mbfir.make_opts(ddkkt=-1))     # extended precision forbidden:
+    assert s3 == "Solved" and i3["lattice"] == 0 and relinf(h3, ho) <= 1e-6                      # the dense path is the last resort
 
 
-def test_dense_retry_inside_a_batch():
+def test_retry_inside_a_batch():
     """The retry runs per job inside mbfir_solve_batch's worker threads (own context, own arena)."""
     from oracle import designers
     f, a, d = [-0.25, 0.25, 0.45, 1.0], [0.15, 0.15, 0, 0], [0.004, 0.002]
@@ -124,5 +131,5 @@ def test_dense_retry_inside_a_batch():
     ho, so = designers.fir_ap_cvx(20, f, a, d, 1e5, 1e-3)
     for k in (0, 2, 4):
         h, s, i = res[k]
-        assert s == so == "Solved" and i["lattice"] == 0 and relinf(h, ho) <= 1e-6
+        assert s == so == "Solved" and i["lattice"] == 1 and i["dd_iters"] > 0 and relinf(h, ho) <= 1e-6
     assert res[1][1] == "Solved" and res[1][2]["lattice"] == 1 and res[3][1] == "Solved"
