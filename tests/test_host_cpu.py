@@ -145,3 +145,25 @@ def test_mex_gateway_compiles_against_a_stub_header():
             r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", stub, "-I", os.path.join(ROOT, "include")] + flags + [src],
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
+
+
+def test_h1qp_fixture_is_a_certified_optimum():
+    """tests/golden/h1qp_golden.json (BASELINE config 3 read literally, made by make_golden_h1qp.py): the stored oracle
+    results carry their own primal-dual certificates, re-evaluated in plain NumPy when the fixture was generated."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "h1qp_golden.json")) as fh:
+        g = json.load(fh)
+    assert set(g) == {"h1qp_384_6144", "h1qp_512_16384"}
+    for rec in g.values():
+        c = rec["certificate"]
+        assert rec["status"] == 0 and rec["chol_fixes"] == 0
+        assert c["pres"] <= 1e-8 and c["dres"] <= 1e-8 and c["s_outside"] <= 1e-12 and c["z_outside"] <= 1e-7
+        assert abs(c["pcost"] - c["dcost"]) <= 1e-8 * abs(c["pcost"]) and abs(c["sz"]) <= 1e-8 * abs(c["pcost"])
+        assert len(rec["h_re"]) == rec["n"] and abs(rec["pcost"] - c["pcost"]) <= 1e-12 * abs(c["pcost"])
+
+
+def test_refine_is_clamped_and_new_options_exist():
+    o = mbfir.make_opts(refine=20, ddkkt=1, lanes=8)
+    assert o.refine == 20 and o.ddkkt == 1 and o.lanes == 8           # the clamp to 8 sweeps happens inside the library
+    with pytest.raises(TypeError):
+        mbfir.make_opts(no_such_option=1)
