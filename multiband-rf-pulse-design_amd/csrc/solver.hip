@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
     double acc[NVVMAX];
 #pragma unroll
     for (int v = 0; v < NVVMAX; ++v) acc[v] = 0;
+#pragma unroll 8
     for (int m = 0; m < m1 - m0; ++m) {
 #pragma unroll
         for (int v = 0; v < NVVMAX; ++v)
@@ -522,13 +523,17 @@ __global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
 // aggregates of a row vector (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency),
 // otherwise they are read from the per-frequency array src[v][Mpad].
 constexpr int CGRP = 4;
+constexpr int MPTS = 256;     // moment points per block
 template <int NV, bool AGG>
 __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, const double4* __restrict__ seeds,
                                                       int na, int nb, double* __restrict__ partial) {
     LANES(P, src, seeds, partial);
+    // Block = 256 moment points x one group of CGRP chunks: every thread runs the recurrence of its point through
+    // the group's chunks one after the other (fixed order), so the per-frequency operands of a chunk group are
+    // staged -- with AGG: aggregated from the row vector through the CSR map -- once per 256 points, and the fold
+    // kernels see nchunk / CGRP partials.
     __shared__ double pp[NV][CGRP][CHK];
-    __shared__ double red[CGRP - 1][2 * NV][64];
-    const int tid = threadIdx.x, pt = tid & 63, cl = tid >> 6;
+    const int tid = threadIdx.x;
     const int ch0 = blockIdx.y * CGRP;
     for (int e = tid; e < CGRP * CHK; e += 256) {         // stage the operands of the group's chunks
         const int cc = e / CHK, q = e - cc * CHK, ch = ch0 + cc;
@@ -563,16 +568,19 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __r
         }
     }
     __syncthreads();
-    const int m = blockIdx.x * 64 + pt, ch = ch0 + cl;
-    const bool work = m < na + nb && ch < P.nchunk;
+    const int m = blockIdx.x * MPTS + tid;
+    if (m >= na + nb) return;
     double ag[NV], as[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) ag[v] = as[v] = 0;
-    if (work) {
+    for (int cl = 0; cl < CGRP; ++cl) {
+        const int ch = ch0 + cl;
+        if (ch >= P.nchunk) break;
         const double4 sd4 = seeds[(long)ch * (na + nb) + m];
         double c = sd4.x, s = sd4.y;
         const double cd = sd4.z, sd = sd4.w;
         const int cnt = P.ch_count[ch];
+#pragma unroll 4
         for (int q = 0; q < cnt; ++q) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -585,20 +593,10 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __r
             c = cn;
         }
     }
-    if (cl > 0) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { red[cl - 1][2 * v][pt] = ag[v]; red[cl - 1][2 * v + 1][pt] = as[v]; }
-    }
-    __syncthreads();
-    if (cl == 0 && m < na + nb) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            double g = ag[v], h = as[v];
-#pragma unroll
-            for (int k = 0; k < CGRP - 1; ++k) { g += red[k][2 * v][pt]; h += red[k][2 * v + 1][pt]; }
-            partial[(((long)blockIdx.y * NV + v) * 2) * P.LDM + m] = g;
-            partial[(((long)blockIdx.y * NV + v) * 2 + 1) * P.LDM + m] = h;
-        }
+    for (int v = 0; v < NV; ++v) {
+        partial[(((long)blockIdx.y * NV + v) * 2) * P.LDM + m] = ag[v];
+        partial[(((long)blockIdx.y * NV + v) * 2 + 1) * P.LDM + m] = as[v];
     }
 }
 
@@ -1694,7 +1692,7 @@ static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = CHK) {
         L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(Q.w[i]); L.ch_dw.push_back(dwf);
         i += cnt;
     }
-    if ((long)L.ch_start.size() > (long)Mf * 16 / chunk_len / 8 + 64) return L;       // grid too irregular: the dense path is the better one
+    if ((long)L.ch_start.size() > Mf / 8 + 64) return L;       // grid too irregular: the dense path is the better one
     L.tmin = tmin; L.D1 = D1; L.ok = true;
     return L;
 }
@@ -1838,7 +1836,7 @@ struct Solver::Impl {
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
     void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
-        dim3 g(cdiv(na + nb, 64), cdiv(P.nchunk, CGRP)), b(256);
+        dim3 g(cdiv(na + nb, MPTS), cdiv(P.nchunk, CGRP)), b(256);
         switch (nv) {
             case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
             case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
@@ -1863,7 +1861,7 @@ struct Solver::Impl {
     template <int NV>
     void apply_GT(const double* val, double* out) {
         if (P.trig) {
-            dim3 g(cdiv(P.D1, 64), cdiv(P.nchunk, CGRP)), b(256);
+            dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, CGRP)), b(256);
             if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
             else hipLaunchKernelGGL((k_trig_moments<NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
         } else {

@@ -667,7 +667,11 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         # affine direction: lam \ (-lam o lam) = -lam, W lam = s  ->  bz = s - rz (in the batch above)
         dxa, dsa, dza, dta, dka, dssa, wdza = direction(0.0, -kappa * tau, XB[:, 1], ZB[:, 1], GB[:, 1])
         alpha_a = step_of(dssa, wdza, dta, dka, 1.0)
-        sigma = (1.0 - alpha_a) ** 3
+        sigma = (1.0 - alpha_a) ** (_exp or {}).get("sig_pow", 3)
+        if _exp and "sig_max" in _exp:
+            sigma = min(sigma, _exp["sig_max"])
+        if _exp and "sig_min" in _exp:
+            sigma = max(sigma, _exp["sig_min"])
         ds_c = sigma * mu * e - ll - _cone_prod(cone, dssa, wdza)
         dk_c = sigma * mu - kappa * tau - dka * dta
         lds = _cone_div(cone, lam, ds_c)

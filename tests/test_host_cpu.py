@@ -139,7 +139,7 @@ def test_mex_gateway_compiles_against_a_stub_header():
     """matlab/mbfir_mex.c cannot be built for real (no MATLAB); check it is valid C against a
     minimal stand-in for mex.h that declares only the API calls the gateway uses."""
     stub = os.path.join(ROOT, "tests", "stubs")
-    for name in ("mbfir_mex.c", "mbfir_slr_mex.c"):
+    for name in ("mbfir_mex.c", "mbfir_slr_mex.c", "mbfir_bloch_mex.c"):
         src = os.path.join(ROOT, "matlab", name)
         for flags in ([], ["-DMX_HAS_INTERLEAVED_COMPLEX=1"]):
             r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", stub, "-I", os.path.join(ROOT, "include")] + flags + [src],
