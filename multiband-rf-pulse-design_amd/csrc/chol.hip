@@ -4,6 +4,7 @@
 // All fp64; tile products on v_mfma_f64_16x16x4_f64.
 #include "dev_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mbfir {
@@ -298,12 +299,17 @@ struct CholStep {
     int nP, nMS, nT;
     size_t lane_bytes;       // lock-step batch: blockIdx.y = lane, every pointer moves by lane * lane_bytes
     const int* mask;         // nlanes ints (or null): lanes switched off
+    int phase;               // 0: one launch per panel step, every row block factorises L_kk itself (lowest latency,
+                             //    one design); 1 / 2: split step for lock-step batches -- launch 1 = the diagonal
+                             //    block (one per lane) with the MS / T / RU blocks, launch 2 = the row blocks, which
+                             //    read the image of L_kk that launch 1 left in Dfac instead of repeating its 64 pivots
 };
 
 constexpr int YLD = 65;                                  // staging tiles that are read one row per lane
 constexpr int R0 = 0, R1 = CB * CLD, R2 = 2 * CB * CLD, R3 = R2 + 1152;
 constexpr int STEP_LDS = R3 + 336;                       // 79.4 KB
 
+template <bool FROM_IMAGE>
 __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k = a.k, np = a.np;
@@ -327,7 +333,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     for (int q = 0; q < 3; ++q) {
         const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[q][r] = q < nt ? H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] : 0.0;
+        for (int r = 0; r < 4; ++r) hv[q][r] = (!FROM_IMAGE && q < nt) ? H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] : 0.0;
     }
     if (rows) {
 #pragma unroll
@@ -348,7 +354,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
-            if (q < nt) {
+            if (!FROM_IMAGE && q < nt) {
 #pragma unroll 4
                 for (int k0 = 0; k0 < CB; k0 += 4) {
                     const int kx = k0 + g4;
@@ -378,7 +384,19 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     __syncthreads();                                      // also: everybody is done with X and AR
     TRACE(3)
     double* Lz = smem + R0;
-    potf2_slabs(acc, tiles, LB, LS, dsh, dsh + 2 * CB, Lz, dinv, a.pivtol, a.flag, b == 0);
+    if (FROM_IMAGE) {                                     // the image of L_kk and 1 / diag(L_kk) as launch 1 left them
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const double2*>(a.Dfac + kk * CB + 2 * (tid + 256 * u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+        }
+        if (tid < CB) dinv[tid] = a.dinvG[kk + tid];
+    } else {
+        potf2_slabs(acc, tiles, LB, LS, dsh, dsh + 2 * CB, Lz, dinv, a.pivtol, a.flag, b == 0);
+    }
     TRACE(4)
     __syncthreads();                                      // image complete; LB is free again (Y aliases it)
     if (rows) {                                           // updated rows of A_ik (MFMA layout -> one row per DPP row)
@@ -481,7 +499,8 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
         a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
     }
     int b = blockIdx.x;
-    if (b < a.nP) { panel_block(a, b, smem); return; }
+    if (a.phase == 2) { panel_block<true>(a, b + 1, smem); return; }      // launch 2 of a split step: row blocks only
+    if (b < a.nP) { panel_block<false>(a, b, smem); return; }
     b -= a.nP;
     if (b < a.nMS) { minv_block(a, b, smem); return; }
     b -= a.nMS;
@@ -549,8 +568,9 @@ __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ M
     for (int r = threadIdx.y; r < 32; r += blockDim.y) Mt[(long)(bx + r) * np + by + threadIdx.x] = tile[threadIdx.x][r];
 }
 
-void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy, hipEvent_t e0, hipEvent_t e1, int nlanes, size_t lane_bytes, const int* mask) {
+int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
+                    double* Lcopy, hipEvent_t e0, hipEvent_t e1, int nlanes, size_t lane_bytes, const int* mask) {
+    int launches = 0;
     const int nblk = np / CB;
     // W1 layout: np doubles: original diagonal | 64 np doubles: images of the L_kk blocks | np: 1 / diag(L)
     CholStep a;
@@ -560,18 +580,31 @@ void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* 
     a.lane_bytes = lane_bytes; a.mask = mask;
     hipLaunchKernelGGL(k_chol_init, dim3(std::min(1024, cdiv((long)np * np / 2, 256)), nlanes), dim3(256), 0, st, H, np, W1, M, flag, lane_bytes, mask);
     if (e0) hipEventRecord(e0, st);
+    // lock-step batches split every step in two launches (see CholStep::phase): with several designs in flight the
+    // chip is no longer empty, and the 4 * nrem row blocks of a step each repeating the 64-pivot factorisation of
+    // L_kk is what fills it
+    bool split = nlanes >= 3;
+    if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev) != 0;
     for (int k = 0; k <= nblk; ++k) {
         const int nrem = nblk - k - 1;
         a.k = k;
-        a.nP = k < nblk ? 1 + 4 * nrem : 0;
+        a.nP = k < nblk ? (split ? 1 : 1 + 4 * nrem) : 0;
         a.nMS = k >= 1 ? 4 * k : 0;
         a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
         const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
+        a.phase = split ? 1 : 0;
         hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU, nlanes), dim3(256), 0, st, a);
+        ++launches;
+        if (split && k < nblk && nrem > 0) {
+            a.phase = 2;
+            hipLaunchKernelGGL(k_chol_step, dim3(4 * nrem, nlanes), dim3(256), 0, st, a);
+            ++launches;
+        }
     }
     if (e1) hipEventRecord(e1, st);
     if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
     hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32, nlanes), dim3(32, 8), 0, st, M, Mt, np, lane_bytes, mask);
+    return launches;                                      // k_chol_step launches issued
 }
 
 // y[v][i] = sum_j T[i][j] b[v][j] over the stored triangle; one wave per row, 16-byte loads.

@@ -86,9 +86,10 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // fills 2*ntiles ints
 // W1 is a workspace of 66*np doubles.  flag[0] counts replaced (noise-level) pivots.
 // e0 / e1 (optional) are recorded right before / after the np/64 + 1 k_chol_step launches.
 // Lock-step batch: nlanes designs, the buffers of lane b at + b * lane_bytes, mask (nlanes ints or null) = lanes to do.
-void chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
-                     double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int nlanes = 1,
-                     size_t lane_bytes = 0, const int* mask = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
+// Returns the number of k_chol_step launches it issued (one per panel step, two for lock-step batches).
+int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* flag, hipStream_t st,
+                    double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int nlanes = 1,
+                    size_t lane_bytes = 0, const int* mask = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
 // y[v] = Lo * (b[v] + b2[v]) for a row-major lower (upper=0) or upper (upper=1) triangular np x np
 // matrix; b2 may be null.

@@ -1742,6 +1742,7 @@ struct Solver::Impl {
     int* hostFlag = nullptr;     // pinned, 4 per lane
     // lock-step batch: nlanes designs of identical shape in one arena, lane b at + b * lane_bytes (see DProg)
     int nlanes = 1, nlanes_last = 1;
+    long chol_launch_count = 0;  // k_chol_step launches of the current solve
     size_t lane_bytes = 0;
     int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
                                  // still need CG sweep q, row MAX_SWEEPS + 1 = scratch (lanes with a new best iterate)
@@ -2068,7 +2069,7 @@ struct Solver::Impl {
             dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st);
             if (c1) hipEventRecord(c1, st);
         } else if (mine) {
-            chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
+            chol_launch_count += chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
         } else {
             if (c0) hipEventRecord(c0, st);
             if (c1) hipEventRecord(c1, st);
@@ -2415,7 +2416,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.timing = o.timing;
 
     const bool sharded = S.shard_size > 1;
-    S.dd_iters = 0; S.dd_kmax_seen = 0;
+    S.dd_iters = 0; S.dd_kmax_seen = 0; S.chol_launch_count = 0;
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
         hipLaunchKernelGGL(k_cone_resid, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, v, S.partR);
@@ -2628,7 +2629,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
         info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
-        info.chol_launches = builds * (P.np / 64 + 1);
+        info.chol_launches = int(S.chol_launch_count);
         info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
         info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
                                 : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);

@@ -94,6 +94,22 @@ def test_double_double_solve_matches_the_oracles_dd_kernels(n, k):
     assert np.abs(r).max() <= 1e-10 * (np.abs(b).max() + np.abs(Hw).max() * np.abs(Xh).max() * n)
 
 
+@pytest.mark.parametrize("n", [64, 200, 449, 1023])
+def test_cholesky_split_step_equals_the_fused_step(n, monkeypatch):
+    """Lock-step batches run every panel step as two launches (diagonal block + trailing work, then the row blocks
+    reading the stored image of L_kk); forced here on a single matrix: same factor and inverse as the fused step,
+    bit for bit (the row blocks do the same arithmetic on the same image)."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n + 20, n))
+    H = B.T @ B + 0.1 * np.eye(n)
+    monkeypatch.setenv("MBFIR_CHOL_SPLIT", "0")
+    L0, M0 = mbfir.test_chol(H)
+    monkeypatch.setenv("MBFIR_CHOL_SPLIT", "1")
+    L1, M1 = mbfir.test_chol(H)
+    assert np.array_equal(L0, L1) and np.array_equal(M0, M1)
+    assert relinf(L1, np.linalg.cholesky(H)) <= 1e-12
+
+
 def test_cholesky_ill_conditioned_scaling():
     """IPM-like matrix: A' D A with D spanning ten decades (cond ~1e9)."""
     rng = np.random.default_rng(11)

@@ -9,18 +9,22 @@ mkdir -p $OUT
 UNIT="tools/gpu_lanes_one.py 512 16384 8 8 1 1"          # one lock-step unit of 8 headline designs, one stream
 # 1. the bench line itself, then the same command under the kernel trace
 python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench_trace.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench_trace.log 2>&1 || exit 1
 # 2. one lock-step unit alone: kernel trace and the counter passes
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/unit_trace -o unit -- python3 $UNIT > $OUT/unit_trace.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/unit_pmc_busy -o unit -- python3 $UNIT > $OUT/unit_pmc_busy.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/unit_pmc_insts -o unit -- python3 $UNIT > $OUT/unit_pmc_insts.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/unit_pmc_fetch -o unit -- python3 $UNIT > $OUT/unit_pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/unit_pmc_write -o unit -- python3 $UNIT > $OUT/unit_pmc_write.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/unit_trace -o unit -- python3 $UNIT > $OUT/unit_trace.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/unit_pmc_busy -o unit -- python3 $UNIT > $OUT/unit_pmc_busy.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/unit_pmc_insts -o unit -- python3 $UNIT > $OUT/unit_pmc_insts.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/unit_pmc_fetch -o unit -- python3 $UNIT > $OUT/unit_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/unit_pmc_write -o unit -- python3 $UNIT > $OUT/unit_pmc_write.log 2>&1 || exit 1
 # 3. the dense path (k_gram on the matrix cores): one design, one stream
 DENSE="tools/gpu_dense_one.py 512 16384"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dense_trace -o dense -- python3 $DENSE > $OUT/dense_trace.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/dense_pmc_busy -o dense -- python3 $DENSE > $OUT/dense_pmc_busy.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/dense_pmc_insts -o dense -- python3 $DENSE > $OUT/dense_pmc_insts.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/dense_pmc_fetch -o dense -- python3 $DENSE > $OUT/dense_pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/dense_pmc_write -o dense -- python3 $DENSE > $OUT/dense_pmc_write.log 2>&1 || exit 1
-find $OUT -name "*.csv" | head -40
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/dense_trace -o dense -- python3 $DENSE > $OUT/dense_trace.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/dense_pmc_busy -o dense -- python3 $DENSE > $OUT/dense_pmc_busy.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/dense_pmc_insts -o dense -- python3 $DENSE > $OUT/dense_pmc_insts.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/dense_pmc_fetch -o dense -- python3 $DENSE > $OUT/dense_pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dense_pmc_write -o dense -- python3 $DENSE > $OUT/dense_pmc_write.log 2>&1 || exit 1
+# the traces are hundreds of MB: condense them here, keep only the summaries (gpurun copies back <= 64 MiB)
+MBFIR_PROFILE_DST=gpurun_out/r02_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
+cp $OUT/bench.json $OUT/summary.log gpurun_out/r02_profiles/ 2>/dev/null
+rm -rf $OUT
+ls -la gpurun_out/r02_profiles

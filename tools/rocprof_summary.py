@@ -11,11 +11,11 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r02")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("MBFIR_PROFILE_DST", os.path.join(ROOT, "profiles"))
 
 
-def find(d, pat):
-    hits = glob.glob(os.path.join(SRC, d, "**", pat), recursive=True)
+def find_db(d):
+    hits = glob.glob(os.path.join(SRC, d, "**", "*_results.db"), recursive=True)
     return hits[0] if hits else None
 
 
@@ -25,15 +25,17 @@ def short(name):
 
 
 def kernel_stats(d, out):
-    path = find(d, "*kernel_trace.csv")
+    """rocprofv3's default output is an SQLite database; `kernels` is its view of the kernel dispatches."""
+    path = find_db(d)
     if not path:
         return None
+    import sqlite3
+    cur = sqlite3.connect(path).cursor()
     agg = defaultdict(lambda: [0, 0.0])
-    with open(path) as fh:
-        for r in csv.DictReader(fh):
-            k = short(r["Kernel_Name"])
-            agg[k][0] += 1
-            agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    for name, start, end in cur.execute("select name, start, end from kernels"):
+        k = short(name)
+        agg[k][0] += 1
+        agg[k][1] += (end - start) / 1e3
     tot = sum(v[1] for v in agg.values())
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     with open(os.path.join(DST, out), "w") as fh:
@@ -44,16 +46,17 @@ def kernel_stats(d, out):
 
 
 def counter_sums(d):
-    path = find(d, "*counter_collection.csv")
+    path = find_db(d)
     if not path:
         return {}
+    import sqlite3
+    cur = sqlite3.connect(path).cursor()
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(set)
-    with open(path) as fh:
-        for r in csv.DictReader(fh):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            calls[k].add(r["Dispatch_Id"])
+    for name, cname, val, disp in cur.execute("select name, counter_name, counter_value, dispatch_id from pmc_events"):
+        k = short(name)
+        agg[k][cname] += float(val)
+        calls[k].add(disp)
     return {k: dict(v, calls=len(calls[k])) for k, v in agg.items()}
 
 
