@@ -61,3 +61,28 @@ def test_random_spec_matches_the_oracle(seed):
         if clean:
             # absolute floor: a spec whose optimum is h ~ 1e-10 has nothing to compare relatively
             assert np.max(np.abs(hg - ho)) <= 1e-6 * max(np.max(np.abs(ho)), 1e-3), (which, args[0], ig["iters"], io["iters"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_quadratic_phase_specs_with_large_peak_weights(seed):
+    """fir_qp_cvx the way dzrf_mb calls it (k ~ 100, obj ~ 1e6: dzrf_mb.m:210-213) on random band specs: the regime in
+    which the error and tap-peak cones become nearly active with NT weights far above the rest and the extended-precision
+    KKT solve takes over.  Device and oracle must agree on the verdict, the objective and -- when both solves
+    are clean -- the taps."""
+    warnings.filterwarnings("ignore", category=RuntimeWarning)
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(40, 120))
+    f, k = random_bands(rng, -1.0, 1.0, 3)
+    f = f * rng.uniform(0.15, 0.5)                               # narrow bands around DC, as the spectral pulses have
+    amp = np.where(rng.random(k) < 0.4, 0.0, rng.uniform(0.5, 0.9, k))
+    amp[int(rng.integers(0, k))] = 0.8
+    a, d = np.repeat(amp, 2), rng.uniform(0.01, 0.05, k)
+    kq, obj = float(rng.uniform(40, 140)), float(10 ** rng.uniform(4, 6.5))
+    grid = int(rng.choice([0, 4 * n, 8 * n]))
+    hg, sg, ig = mbfir.fir_qp_cvx(n, f, a, d, kq, obj, opts=mbfir.make_opts(grid_m=grid), info=True)
+    ho, so, io = designers.fir_qp_cvx(n, f, a, d, kq, obj, grid_m=grid, info=True)
+    assert sg == so, (n, grid, ig["rc"], io["status"], ig["relgap"], io.get("relgap"))
+    if sg == "Solved":
+        assert abs(ig["pcost"] - io["pcost"]) <= 1e-6 * max(1.0, abs(io["pcost"]))
+        if io["status"] == conic_ipm.STATUS_OPTIMAL and ig["relgap"] <= 1e-8:
+            assert np.max(np.abs(hg - ho)) <= 1e-4 * max(np.max(np.abs(ho)), 1e-3)      # E + obj Peak is flat around its minimiser

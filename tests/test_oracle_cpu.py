@@ -166,3 +166,26 @@ def test_reference_grid_rules():
     # lower bound floor epsilon^2 = 1e-20 and squared upper bound (fir_ap_cvx.m:105-116)
     P = assemble.assemble_fir_ap_cvx(10, [0, 0.2, 0.4, 1], [1, 1, 0, 0], [0.1, 0.1], 0.1, 1)
     assert P["meta"]["L_b"].min() == 1e-10 ** 2 and abs(P["meta"]["U_b"].max() - 1.21) < 1e-12
+
+
+def test_linprog_degenerate_optimal_face_objective_and_feasibility():
+    """ss/fir_linprog.m:244-252 hands the LP to linprog's active-set method, which returns a VERTEX (which one depends on
+    its path from the warm start x0); an interior-point method returns the analytic centre of the optimal face.  On the
+    golden cases the optimiser is unique and the two coincide.  Here the optimal face is made degenerate on purpose --
+    adjacent bands leave no transition samples, so fmin = sum_tran A(i,:) = 0 (ss/fir_linprog.m:240) and the whole
+    feasible polytope is optimal -- and what CAN be asserted is asserted: the oracle's point is feasible for every row
+    (it is the analytic centre: strictly inside), its objective equals HiGHS's (an independent solver, itself returning
+    a vertex), and the two optimisers differ (the face is not a point)."""
+    from scipy.optimize import linprog
+    n, f, a, d = 21, [0, 0.5, 0.5, 1.0], [1, 1, 0, 0], [0.6, 0.6]
+    P = assemble.assemble_fir_linprog(n, f, a, d)
+    r = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"])
+    assert r["status"] == conic_ipm.STATUS_OPTIMAL
+    x = r["x"]
+    assert np.abs(P["c"]).max() == 0.0
+    assert (P["h"] - P["G"] @ x).min() >= 1e-3                 # analytic centre of the face: strictly interior
+    hi = linprog(P["c"], A_ub=P["G"], b_ub=P["h"], bounds=[(None, None)] * len(P["c"]), method="highs",
+                 options=dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10))
+    assert hi.status == 0
+    assert abs(P["c"] @ x - hi.fun) <= 1e-9 * max(1.0, abs(hi.fun))
+    assert np.abs(x - hi.x).max() >= 1e-3                     # same optimal value, different points of the face

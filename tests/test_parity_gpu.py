@@ -306,3 +306,14 @@ def test_config4_peak_ripple_sweep_as_one_batch():
         cost[(j, pk)] = info["pcost"]
     for j in (0, 8, 15):
         assert cost[(j, 1e-4)] >= cost[(j, 1e-3)] - 1e-9 >= cost[(j, 1e-2)] - 2e-9
+
+
+def test_linprog_degenerate_optimal_face_device_returns_the_oracles_analytic_centre():
+    """Adjacent bands leave no transition samples: fmin = 0 (ss/fir_linprog.m:240), every feasible point is optimal.
+    linprog's active-set method would return some vertex; device and oracle both return the analytic centre of the
+    face -- the same point (tests/test_oracle_cpu.py checks it against HiGHS's objective)."""
+    args = (21, [0, 0.5, 0.5, 1.0], [1, 1, 0, 0], [0.6, 0.6])
+    ho, so = designers.fir_linprog(*args)
+    hg, sg, info = mbfir.fir_linprog(*args, info=True)
+    assert so == sg == "Solved" and abs(info["pcost"]) <= 1e-12
+    assert relinf(hg, ho) <= TAP_TOL
