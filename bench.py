@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--shard-n", type=int, default=2048)
     ap.add_argument("--shard-grid-m", type=int, default=131072)
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the row-sharded config-5 leg")
+    ap.add_argument("--shard-timeout", type=int, default=240, help="N > 1: seconds the row-sharded leg may take before the line "
+                    "is printed without it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks: ranks then share devices and the solver's "
                     "reductions go through the host hook instead of its own RCCL communicator)")
@@ -182,9 +184,8 @@ def main():
                 "reductions": "ncclAllReduce on the solver stream (mbfir_comm_init)" if args.backend == "nccl" else "host hook (gloo rehearsal)"}
 
     shard_primary = args.mode == "shard" and world > 1
-    if world > 1 and (shard_primary or not args.no_shard):
-        wire_shard(ctx)
     if shard_primary:
+        wire_shard(ctx)
         res = shard_leg(args.n, args.grid_m, args.steps, args.warmup)
         if rank == 0:
             out = {"metric": res["metric"], "value": res["value"], "unit": "designs/s", "n_gpus": world, "steps": args.steps,
@@ -239,10 +240,7 @@ def main():
         _, st_d, dense_info = mbfir.fir_ap_cvx(*jobs[0][1], ctx=ctx, info=True, opts=mbfir.make_opts(grid_m=args.grid_m, dense_trig=1))
         if st_d != "Solved":
             dense_info = None
-    shard_res = None
-    if world > 1 and not args.no_shard:
-        shard_res = shard_leg(args.shard_n, args.shard_grid_m, 1, 1)
-
+    out = None
     if rank == 0:
         iters = sum(i["iters"] for i in infos)
         lattice = bool(infos[0]["lattice"])
@@ -322,8 +320,6 @@ def main():
             "roofline": dominant,
             "roofline_other": others,
         }
-        if shard_res is not None:
-            out["shard"] = shard_res
         if world == 1 and args.cpu_iters != 0:
             cb = cpu_baseline(jobs[0], args.grid_m, infos[0]["iters"], args.cpu_iters)
             out["cpu_baseline"] = cb
@@ -334,6 +330,29 @@ def main():
                 out["cpu_baseline"]["gpu_dense_path_over_cpu"] = 1e3 / dense_info["ms_total"] / cb["value"]
                 if cb["pcost"] is not None:
                     out["cpu_baseline"]["pcost_gpu_vs_cpu"] = [infos[0]["pcost"], cb["pcost"]]
+    if world > 1 and not args.no_shard:
+        # The row-sharded leg (config 5) runs LAST and under a watchdog: it is the one part of this file that needs every
+        # rank to issue the same collectives, so a failure or a stall there must not cost the batch figure -- the line
+        # is then printed without "shard" and the processes leave.
+        import threading
+
+        def bail():
+            if rank == 0 and out is not None:
+                out["shard"] = {"error": "row-sharded leg did not finish within %d s" % args.shard_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.shard_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            wire_shard(ctx)
+            shard_res = shard_leg(args.shard_n, args.shard_grid_m, 1, 1)
+        except Exception as e:                              # noqa: BLE001
+            shard_res = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+        if rank == 0:
+            out["shard"] = shard_res
+    if rank == 0:
         print(json.dumps(out), flush=True)
     for c in ctxs:
         c.close()

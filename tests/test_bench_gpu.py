@@ -70,3 +70,25 @@ def test_row_sharded_bench_as_two_processes_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["shard"]["collectives_per_iteration"] > 0 and "hook" in d["shard"]["reductions"]
+
+
+def test_two_rank_batch_bench_carries_the_shard_leg():
+    """`bench.py --gpus 2` in its default (batch, weak-scaling) mode as the driver launches it, over gloo on one GPU: the
+    line carries the whole-job designs/s of both ranks and, under "shard", the row-sharded strong-scaling leg."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "1", "--taps", "64", "--grid-m", "1024", "--designs", "8", "--lanes", "4", "--streams", "2",
+                        "--shard-n", "64", "--shard-grid-m", "1024", "--cpu-iters", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * 8) < 1e-6 * d["value"] * d["ms_per_step"]      # both ranks' designs
+    assert "error" not in d["shard"] and d["shard"]["scaling"] == "strong" and d["shard"]["value"] > 0
