@@ -3,7 +3,7 @@
 //
 // Algorithm (identical, step for step, to the test oracle oracle/conic_ipm.py so the two agree to
 // rounding): homogeneous self-dual embedding, Nesterov-Todd scaling, Mehrotra predictor-corrector
-// (step fraction 0.99, sigma = (1-alpha_aff)^3), KKT systems reduced to the normal equations
+// (step fraction 0.99, sigma = min((1-alpha_aff)^3, 0.25)), KKT systems reduced to the normal equations
 //   (G' W^-2 G) dx = bx + G' W^-2 bz ,  dz = W^-2 (G dx - bz)
 // with dz kept explicit and corrected incrementally (`refine` sweeps) so the dual equation
 // G'dz = bx holds to rounding.
@@ -79,6 +79,7 @@ enum {
     S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */, S_COUNT = 64
 };
 constexpr double STEP = 0.99;
+constexpr double SIGMA_MAX = 0.25;   // cap of Mehrotra's centring parameter (oracle/conic_ipm.py SIGMA_MAX)
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int MAX_SWEEPS = 8;
 constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
@@ -1222,7 +1223,7 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
         if (mode == 0) {
             double a = t == 0.0 ? 1.0 : fmin(1.0, 1.0 / t);
             Sc[S_ALPHA_A] = a;
-            Sc[S_SIGMA] = (1 - a) * (1 - a) * (1 - a);
+            Sc[S_SIGMA] = fmin((1 - a) * (1 - a) * (1 - a), SIGMA_MAX);
             sh[16] = Sc[S_SIGMA];
         } else {
             double a = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
@@ -1259,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_comb_rhs(DProg P, const double* __restr
         const double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         const double tt = fmax(0.0, fmax(fmax(ts, tz), fmax(-Sc[S_DTAU_A] / tau, -Sc[S_DKAP_A] / kap)));
         const double a = tt == 0.0 ? 1.0 : fmin(1.0, 1.0 / tt);
-        sigma = (1 - a) * (1 - a) * (1 - a);
+        sigma = fmin((1 - a) * (1 - a) * (1 - a), SIGMA_MAX);
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0) { Sc[S_TMAX] = tt; Sc[S_ALPHA_A] = a; Sc[S_SIGMA] = sigma; }
             for (int j = threadIdx.x; j < P.N; j += blockDim.x) bxc[j] = -(1.0 - sigma) * rx[j];
