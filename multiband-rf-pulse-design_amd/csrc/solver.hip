@@ -1645,7 +1645,7 @@ struct LatticeInfo {
     std::vector<double> lat_scale, lat_qscale, ch_w0, ch_dw;
 };
 // chunk_len: longest run of frequencies one recurrence covers between two exact sincos seeds (<= CHK)
-static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = CHK) {
+static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = 64) {
     LatticeInfo L;
     if (const char* ev = std::getenv("MBFIR_CHUNK")) chunk_len = std::max(4, std::min(CHK, std::atoi(ev)));
     const int Nt = Q.Nt, Mf = Q.Mf;
@@ -1679,17 +1679,24 @@ static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = CHK) {
         }
     double wmax = 1.0;
     for (double w : Q.w) wmax = std::max(wmax, std::fabs(w));
-    const double tol = 8 * 2.2204460492503131e-16 * wmax;
+    const double tol = 2 * 2.2204460492503131e-16 * wmax;
+    // Longest run from i (at most chunk_len points) that lies on the straight line through its END POINTS to within
+    // `tol`: a linspace run passes at full length (every point is within half an ulp of the exact line), where a step
+    // estimated from the first two points drifts out of tolerance after ~30 points.  Shrink by halves on failure.
     for (int i = 0; i < Mf;) {
-        int k = i + 1;
-        if (k < Mf) {
-            const double dw = Q.w[k] - Q.w[i];
-            while (k < Mf && k - i < chunk_len && std::fabs(Q.w[k] - (Q.w[i] + (k - i) * dw)) <= tol) ++k;
+        int cnt = std::min(chunk_len, Mf - i);
+        double dwf = 0.0;
+        for (;;) {
+            dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0;
+            bool ok = true;
+            for (int q = 1; q + 1 < cnt && ok; ++q) ok = std::fabs(Q.w[i + q] - (Q.w[i] + q * dwf)) <= tol;
+            if (ok || cnt <= 2) break;
+            cnt = std::max(2, cnt / 2);
         }
-        int cnt = k - i;
-        double dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0;
-        for (int q = 1; q < cnt; ++q)
-            if (std::fabs(Q.w[i + q] - (Q.w[i] + q * dwf)) > 2 * tol) { cnt = q; dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0; break; }
+        if (cnt == 2 && i + 2 < Mf && std::fabs(Q.w[i + 2] - (Q.w[i] + 2 * dwf)) > tol && std::fabs(dwf) > 0 &&
+            (i + 3 >= Mf || std::fabs((Q.w[i + 2] - Q.w[i + 1]) - (Q.w[i + 3] - Q.w[i + 2])) <= tol))
+            cnt = 1;                                       // an isolated point (a band edge) ahead of the next run
+        if (cnt <= 1) { cnt = 1; dwf = 0.0; }
         L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(Q.w[i]); L.ch_dw.push_back(dwf);
         i += cnt;
     }

@@ -317,3 +317,26 @@ def test_linprog_degenerate_optimal_face_device_returns_the_oracles_analytic_cen
     hg, sg, info = mbfir.fir_linprog(*args, info=True)
     assert so == sg == "Solved" and abs(info["pcost"]) <= 1e-12
     assert relinf(hg, ho) <= TAP_TOL
+
+
+def test_lock_step_unit_with_mixed_verdicts_equals_the_single_solves():
+    """One lock-step unit (same shape: n, band edges, ripples; only the spike bound differs) in which some lanes end
+    with a Farkas certificate after a few iterations, others solve after many: finished lanes are masked out, the
+    live ones must not notice.  Every lane's verdict, iteration count, objective and taps equal the single-design
+    solve's bit for bit."""
+    f, a, d = c13(64)
+    peaks = [1e-3, 1e-7, 3e-3, 1e-8, 1e-2, 2e-7, 5e-4, 1e-6]
+    jobs = [("fir_ap_cvx", (64, f, a, d, 0.1, pk)) for pk in peaks]
+    ctx = mbfir.Context(0)
+    res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=8))
+    verdicts = [r[1] for r in res]
+    assert "Solved" in verdicts and "Failed" in verdicts
+    assert all(r[2]["lanes"] == 8 for r in res if r[1] == "Solved")
+    for job, (h, status, info) in zip(jobs, res):
+        h1, s1, i1 = mbfir.fir_ap_cvx(*job[1], ctx=ctx, info=True)
+        assert s1 == status and i1["iters"] == info["iters"], job[1][-1]
+        if status == "Solved":
+            assert np.array_equal(h, h1) and info["pcost"] == i1["pcost"]
+        else:
+            assert len(h) == 0 and info["rc"] == i1["rc"] == mbfir.INFEASIBLE
+    ctx.close()
