@@ -138,22 +138,37 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         std::vector<double> x;
         SolveOpts so = to_opts(opts, P.which);
         int st = ctx->solver->solve(P, so, x, si);
-        // A numerical failure (never an infeasibility certificate) is a precision limit of the double-precision normal
-        // equations: near cond(H) ~ 1e14 the Cholesky factor starts replacing pivots -- a few iterations earlier on the
-        // lattice path, whose moments carry 1e-14 of recurrence noise, than on the dense one.  The
-        // remedy is precision, not the path: retry once with the extended-precision KKT solve (same path), and only if
-        // that fails too once more on the dense path.
+        // A numerical failure (never an infeasibility certificate) -- or a solve that only met the reduced tolerances
+        // ('Inaccurate/Solved') -- is a precision limit of the double-precision normal equations: near cond(H) ~ 1e14 the
+        // Cholesky factor starts replacing pivots, a few iterations earlier on the lattice path, whose moments carry
+        // 1e-14 of recurrence noise, than on the dense one.  The remedy is precision, not the
+        // path: retry once with the extended-precision KKT solve (same path), and only if that does not give a full-
+        // accuracy solve either once more on the dense path.  The best of the attempts is returned.
+        bool ran_retry = false;
+        auto rank_of = [](int status) { return status == ST_OPTIMAL ? 2 : status == ST_OPTIMAL_INACCURATE ? 1 : 0; };
         auto retry = [&](bool dense) {
             const SolveInfo first = si;
+            const std::vector<double> x_first = x;
+            const int st_first = st;
             so.ddkkt_theta = DDKKT_THETA;
             so.dense_trig = so.dense_trig || dense;
             st = ctx->solver->solve(P, so, x, si);
-            si.ms_assemble += first.ms_assemble; si.ms_solve += first.ms_solve; si.ms_chol += first.ms_chol;
-            si.ms_gram += first.ms_gram; si.h_builds += first.h_builds; si.chol_launches += first.chol_launches;
-            si.chol_flop += first.chol_flop; si.iters += first.iters; si.dd_iters += first.dd_iters;
+            const bool keep_first = rank_of(st_first) > rank_of(st);
+            const SolveInfo second = si;
+            if (keep_first) { si = first; x = x_first; st = st_first; }
+            const SolveInfo& other = keep_first ? second : first;
+            si.ms_assemble += other.ms_assemble; si.ms_solve += other.ms_solve; si.ms_chol += other.ms_chol;
+            si.ms_gram += other.ms_gram; si.h_builds += other.h_builds; si.chol_launches += other.chol_launches;
+            si.iters += other.iters; si.dd_iters += other.dd_iters;
+            ran_retry = true;
+            return !keep_first;
         };
-        if (status_to_rc(st) == MBFIR_NUMERICAL && so.shard_size <= 1 && !(so.ddkkt_theta > 0) && !(opts && opts->ddkkt < 0)) retry(false);
-        if (status_to_rc(st) == MBFIR_NUMERICAL && si.lattice && !so.dense_trig && so.shard_size <= 1 && (double)P.Mf * P.N() <= 6e8) retry(true);
+        auto wants_retry = [&]() { return status_to_rc(st) == MBFIR_NUMERICAL || st == ST_OPTIMAL_INACCURATE; };
+        if (wants_retry() && so.shard_size <= 1 && !(so.ddkkt_theta > 0) && !(opts && opts->ddkkt < 0)) retry(false);
+        if (wants_retry() && si.lattice && !so.dense_trig && so.shard_size <= 1 && (double)P.Mf * P.N() <= 6e8) retry(true);
+        // fir_ap_cvx extracts its taps on the device from the solution the LAST solve left there; after a retry the
+        // winner may be an earlier attempt: put the returned solution there
+        if (ran_retry && status_to_rc(st) == MBFIR_SOLVED) ctx->solver->set_solution(x);
         ctx->last_x = x;
         double t_solved = now_ms();
         int rc = status_to_rc(st);
@@ -391,7 +406,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 for (size_t b = 0; b < U.size(); ++b) {
                     mbfir_job& J = jobs[U[b]];
                     const int rc = status_to_rc(sis[b].status);
-                    if (rc == MBFIR_NUMERICAL) { redo.push_back(U[b]); continue; }   // single path: retries on the dense path
+                    if (rc == MBFIR_NUMERICAL || sis[b].status == ST_OPTIMAL_INACCURATE) { redo.push_back(U[b]); continue; }   // single path: retries in extended precision
                     if (rc == MBFIR_SOLVED) taps_from_solution(*ctx->solver, progs[U[b]], xs[b], int(b), J.h_re, J.h_im);
                     fill_info(&J.info, progs[U[b]], sis[b], rc, t0, t_asm, t_solved, now_ms());
                     J.rc = rc;

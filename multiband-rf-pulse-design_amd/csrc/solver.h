@@ -48,6 +48,7 @@ public:
     static int max_lanes(const TrigProgram& P, const SolveOpts& o);
     // fir_ap_cvx tap extraction on the device from the solution left by the last solve() / lane of solve_lanes().
     void specfact_last(int n, double* h_re, double* h_im, int lane = 0);
+    void set_solution(const std::vector<double>& x);
     // Inverse SLR on the device (slr.hip).  b: n complex taps.  a_in null: a = b2a(b) (b2a.m:15-32), else a = a_in.
     // a_out (optional) receives a; rf (optional) receives ab2rf(a, b) (ab2rf.m:14-29).
     void slr(int n, const double* b_re, const double* b_im, const double* a_in_re, const double* a_in_im,

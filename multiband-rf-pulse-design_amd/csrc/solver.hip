@@ -2652,6 +2652,13 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
 // ================================================================================================
 namespace mbfir {
 
+// the solution vector the tap extraction of lane 0 starts from (api.cpp: the best of several attempts)
+void Solver::set_solution(const std::vector<double>& x) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    MBFIR_HIP(hipMemcpyAsync(S.xout, x.data(), sizeof(double) * x.size(), hipMemcpyHostToDevice, S.st));
+    MBFIR_HIP(hipStreamSynchronize(S.st));
+}
 void Solver::specfact_last(int n, double* h_re, double* h_im, int lane) {
     Impl& S = *impl;
     MBFIR_HIP(hipSetDevice(S.device));
