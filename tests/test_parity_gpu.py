@@ -340,3 +340,44 @@ def test_lock_step_unit_with_mixed_verdicts_equals_the_single_solves():
         else:
             assert len(h) == 0 and info["rc"] == i1["rc"] == mbfir.INFEASIBLE
     ctx.close()
+
+
+@pytest.mark.parametrize("which", ["fir_linprog", "fir_qprog_phs", "fir_qp_cvx"])
+def test_lock_step_units_of_every_designer_equal_the_single_solves(which):
+    """Lock-step units for the other three designers (LP rows only; LP rows + the big cone; Q3 cones + the big cone --
+    the single-workgroup big-cone kernels run with the lane as a grid dimension too).  Same shape, different bounds /
+    weights per lane; every lane equals its single-design solve bit for bit."""
+    if which == "fir_linprog":
+        base = CASES["lin_cplx32"][1]
+        jobs = [(which, (base[0], base[1], base[2], [v * s for v in base[3]])) for s in (1.0, 1.3, 0.8, 2.0, 1.1)]
+        opts = mbfir.make_opts(lanes=8)
+    elif which == "fir_qprog_phs":
+        base = CASES["qphs21"][1]
+        # the number of half-planes per frequency follows from the ripples (ss/fir_qprog_phs.m:100-128), so the ripples
+        # stay and the pass-band amplitude varies
+        jobs = [(which, (base[0], base[1], [v * s for v in base[2]], base[3])) for s in (1.0, 0.97, 1.03, 0.94)]
+        opts = mbfir.make_opts(lanes=8)
+    else:
+        base = CASES["qp_modelA48"][1]
+        jobs = [(which, (base[0], base[1], base[2], base[3], base[4], obj)) for obj in (10.0, 3.0, 30.0, 100.0)]
+        opts = mbfir.make_opts(lanes=8, ddkkt=-1)             # the extended-precision solve runs one design at a time
+    ctx = mbfir.Context(0)
+    res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=opts)
+    assert all(r[1] == "Solved" for r in res) and all(r[2]["lanes"] == len(jobs) for r in res)
+    single = mbfir.make_opts(ddkkt=-1) if which == "fir_qp_cvx" else None
+    for job, (h, status, info) in zip(jobs, res):
+        h1, s1, i1 = getattr(mbfir, which)(*job[1], ctx=ctx, info=True, opts=single)
+        assert s1 == "Solved" and i1["iters"] == info["iters"] and info["pcost"] == i1["pcost"] and np.array_equal(h, h1)
+    ctx.close()
+
+
+def test_refine_option_is_clamped_to_the_sweep_limit():
+    """opts.refine beyond MAX_SWEEPS = 8 used to overrun the residual-norm slots of the device's scalar block (ADVICE
+    r1); it is clamped now: refine = 20 behaves exactly like refine = 8, and both reach the default's optimum."""
+    fn, args = CASES["ap_c13_64"]
+    h2, s2, i2 = mbfir.fir_ap_cvx(*args, info=True)
+    h8, s8, i8 = mbfir.fir_ap_cvx(*args, info=True, opts=mbfir.make_opts(refine=8))
+    h20, s20, i20 = mbfir.fir_ap_cvx(*args, info=True, opts=mbfir.make_opts(refine=20))
+    assert s2 == s8 == s20 == "Solved"
+    assert np.array_equal(h8, h20) and i8["iters"] == i20["iters"]
+    assert relinf(h20, h2) <= TAP_TOL

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 warnings.filterwarnings("ignore", category=RuntimeWarning)
 
 
-def _run_sharded(fn, args, size, dense=0):
+def _run_sharded(fn, args, size, dense=0, grid_m=0):
     import torch
     torch.zeros(1, device="cuda")                   # initialise torch's HIP context on the main thread
     ctxs = [mbfir.Context(0) for _ in range(size)]
@@ -46,7 +46,7 @@ def _run_sharded(fn, args, size, dense=0):
 
     def work(rank):
         ctxs[rank].set_allreduce(make_hook(rank))
-        opts = mbfir.make_opts(shard_rank=rank, shard_size=size, dense_trig=dense)
+        opts = mbfir.make_opts(shard_rank=rank, shard_size=size, dense_trig=dense, grid_m=grid_m)
         try:
             results[rank] = getattr(mbfir, fn)(*args, opts=opts, ctx=ctxs[rank], info=True)
         except Exception as e:                      # noqa: BLE001
@@ -109,3 +109,20 @@ def test_native_rccl_communicator_single_rank():
         mbfir.fir_linprog(*CASES["lin_real33"][1], opts=mbfir.make_opts(shard_rank=0, shard_size=2), ctx=ctx)   # sizes differ
     ctx.destroy_comm()
     ctx.close()
+
+
+@pytest.mark.parametrize("name,size,grid_m", [("lin_real33", 3, 40), ("ap_lowpass20", 3, 48), ("lin_cplx31", 2, 36)])
+def test_row_sharded_solve_on_a_tiny_grid_where_shards_disagree_about_the_lattice(name, size, grid_m):
+    """A grid so small that a rank's strided sub-grid has only a few (or irregularly spaced) frequencies: the ranks'
+    own lattice analyses can disagree.  They settle it with a min all-reduce before the first build (every rank takes the
+    dense path unless all have the structure), so the collective sequences match and the taps equal the unsharded solve."""
+    fn, args = CASES[name]
+    h0, s0, i0 = getattr(mbfir, fn)(*args, info=True, opts=mbfir.make_opts(grid_m=grid_m))
+    res = _run_sharded(fn, args, size, grid_m=grid_m)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    assert len({i["lattice"] for _, _, i in res}) == 1            # one verdict for all ranks
+    for h, s, info in res:
+        assert s == s0
+        if s0 == "Solved":
+            assert relinf(h, h0) <= 1e-6 and np.array_equal(h, res[0][0])
