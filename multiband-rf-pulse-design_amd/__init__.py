@@ -201,8 +201,13 @@ class Context:
         """Native RCCL communicator for row-sharded solves: rank 0 makes the unique id, torch.distributed (any
         backend) carries its 128 bytes to the other ranks, every rank joins (mbfir_comm_init).  From then on the
         solver issues its all-reduces itself, on its own stream."""
+        import torch
         import torch.distributed as dist
         lib = load_library()
+        # one RCCL per process: point the library at the copy torch has loaded
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ.setdefault("MBFIR_RCCL_PATH", cand)
         rank = dist.get_rank(group) if rank is None else rank
         size = dist.get_world_size(group) if size is None else size
         buf = C.create_string_buffer(128)

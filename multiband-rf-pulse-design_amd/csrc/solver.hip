@@ -55,10 +55,20 @@ static RcclApi& rccl() {
     if (tried) return api;
     tried = true;
     void* h = nullptr;
+    // one RCCL per process: a copy that is already loaded (torch's, when the host is Python) is preferred -- by the
+    // path the host names in MBFIR_RCCL_PATH, then by the usual names -- before a fresh one is opened
+    const char* hinted = std::getenv("MBFIR_RCCL_PATH");
+    if (hinted && *hinted) {
+        h = dlopen(hinted, RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen(hinted, RTLD_NOW | RTLD_GLOBAL);
+    }
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // already in the process (torch's copy)?
-        if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // already in the process?
+    }
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+        if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!h) { api.err = "librccl not found"; return api; }
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
