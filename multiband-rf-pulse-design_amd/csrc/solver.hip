@@ -20,7 +20,14 @@
 //   K4  Cholesky + triangular inverse (chol.hip); every solve = two triangular GEMVs, refined by
 //       preconditioned CG on the exact operator
 //   K5  step length: closed form per cone, block max-reductions, scalars stay on the device
-// One host synchronisation per iteration (termination test on 24 doubles).
+// One host synchronisation per iteration (termination test on 24 doubles per design).
+//
+// Lock-step batches ("lanes", solve_lanes): B designs of one shape share every launch -- blockIdx.z (Cholesky:
+// .y) is the design, all device buffers of lane b sit b * lane_bytes after lane 0's, every kernel starts with the
+// LANES(...) prologue (mask test + pointer shift); per-lane status, sweep counts and masks live on the host.
+// Extended-precision KKT solve (ddkkt.inc + ddlin.hip): double-double accumulation / factorisation of the strongly
+// weighted part of the normal matrix for nearly active cones (fir_qp_cvx, and the retry of any numerical failure).
+// Row-sharded solves: reductions are ncclAllReduce calls on the solver stream (run-time bound RCCL) or a host hook.
 #include "dev_common.h"
 #include "cone_dev.h"
 #include "dd_dev.h"
