@@ -101,6 +101,33 @@ def cpu_baseline(job, grid_m, gpu_iters, iters_cpu):
             "pcost": float(r["pcost"]) if full else None}
 
 
+def s_lp_baseline(mbfir, ctx):
+    """BASELINE config 1 (S-LP: n=64 linear-phase low-pass, fir_linprog form, 512 grid points): the GPU design beside
+    scipy.optimize.linprog(method="highs") and the oracle's C++ solver on the identical program (SURVEY.md 8(d));
+    None when SciPy is missing on the box."""
+    try:
+        from scipy.optimize import linprog
+    except Exception:
+        return None
+    from oracle import assemble, cpu_ipm
+    import numpy as np
+    args = (64, [0, 0.2, 0.3, 1], [1, 1, 0, 0], [0.01, 0.01])
+    opts = mbfir.make_opts(grid_m=512)
+    mbfir.fir_linprog(*args, opts=opts, ctx=ctx)                     # warm (allocations of this shape)
+    t0 = time.perf_counter()
+    h, status, info = mbfir.fir_linprog(*args, opts=opts, ctx=ctx, info=True)
+    t_gpu = time.perf_counter() - t0
+    P = assemble.assemble_fir_linprog(*args, 512)
+    t0 = time.perf_counter()
+    rh = linprog(P["c"], A_ub=P["G"], b_ub=P["h"], bounds=[(None, None)] * len(P["c"]), method="highs")
+    t_highs = time.perf_counter() - t0
+    rc = cpu_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"], threads=1)
+    return {"workload": "S-LP: fir_linprog(64, [0 .2 .3 1], [1 1 0 0], [.01 .01]), grid_m=512: %d rows x %d unknowns" % P["G"].shape,
+            "gpu_ms": t_gpu * 1e3, "gpu_status": status, "gpu_iters": info["iters"], "highs_ms": t_highs * 1e3,
+            "cpp_1thread_ms": rc["seconds_total"] * 1e3, "objective_gpu_highs_cpp": [info["pcost"], float(rh.fun), rc["pcost"]],
+            "note": "a 1028 x 32 LP is launch-latency bound on the GPU; this leg is the reference's CPU-runnable case, not a throughput claim"}
+
+
 def pmc_traffic():
     """HBM-side bytes per k_chol_step launch from this round's PMC passes (tools/rocprof_summary.py writes
     profiles/r02_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
@@ -353,6 +380,7 @@ def main():
                 out["cpu_baseline"]["gpu_dense_path_over_cpu"] = 1e3 / dense_info["ms_total"] / cb["value"]
                 if cb["pcost"] is not None:
                     out["cpu_baseline"]["pcost_gpu_vs_cpu"] = [infos[0]["pcost"], cb["pcost"]]
+            out["cpu_baseline"]["s_lp_config1"] = s_lp_baseline(mbfir, ctx)
     if world > 1 and not args.no_shard:
         # The row-sharded leg (config 5) runs LAST and under a watchdog: it is the one part of this file that needs every
         # rank to issue the same collectives, so a failure or a stall there must not cost the batch figure -- the line

@@ -124,12 +124,15 @@ struct DProg {
     const int *lat;                   // Nt: lattice index of column j
     const int *lat_col, *lat_qcol;    // 2*D1 [kind][m]: column there (or -1); source column of P'v there
     const double *lat_scale, *lat_qscale;
-    const int *ch_start, *ch_count;   // nchunk
+    const int *ch_start, *ch_count;   // nchunk: runs of the FOLDED frequency list (analyse_lattice)
+    const int *fold_pos, *fold_neg;   // nfold: frequency index at +wf[k] / -wf[k], or -1
+    const double* wf; int nfold;
+    int cgrp;                         // chunks per block of k_trig_moments (<= CGRP): many when lanes fill the chip, few for one design
     const double *ch_w0, *ch_dw;
     // rotation seeds, tabulated once per design (a sincos costs as much as ~40 recurrence steps):
     const double4* seed_tau;          // [nchunk][D1]   (cos, sin)(w0 t), (cos, sin)(dw t), t = tmin + m
     const double4* seed_h;            // [nchunk][3 D1 - 1]  same for the difference | sum progressions of the H moments
-    const double4* seed_eval;         // [useg][Mpad]   (cos, sin)(w_i (tmin + sg seg)), (cos, sin)(w_i)
+    const double4* seed_eval;         // [useg][Mpad]   (cos, sin)(wf_k (tmin + sg seg)), (cos, sin)(wf_k), k < nfold
     // Lock-step batch ("lanes"): B designs of identical shape advance together, blockIdx.z = lane.  Every device
     // buffer of lane b -- program arrays and work vectors alike -- sits lane_bytes after the same buffer of lane
     // b-1 (one arena, identical layout per lane), so a kernel shifts all its pointers by blockIdx.z * lane_bytes.
@@ -143,7 +146,7 @@ struct DProg {
         sh(freq, off); sh(col, off); sh(alpha, off); sh(beta, off); sh(ey, off); sh(h, off);
         sh(f_ptr, off); sh(f_rows, off); sh(c_ptr, off); sh(c_rows, off); sh(yrows, off);
         sh(lat, off); sh(lat_col, off); sh(lat_qcol, off); sh(lat_scale, off); sh(lat_qscale, off);
-        sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off);
+        sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off); sh(fold_pos, off); sh(fold_neg, off); sh(wf, off);
         sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off);
     }
 };
@@ -461,18 +464,19 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
 //  * Gram matrices: sum_i d_i trig(w_i ta) trig(w_i tb) = 1/2 [mom(ta - tb) +- mom(ta + tb)] with
 //    the moments g(t) = sum_i d_i cos(w_i t), s(t) = sum_i d_i sin(w_i t) on two unit-step
 //    progressions (differences, sums): O(Mf N) instead of the O(Mf N^2) of a dense A1' D A1.
-constexpr int CHK = 128;      // frequencies per chunk
+constexpr int CHK = 64;       // (folded) frequencies per chunk at most
 
 // K1 (lattice): UU[sg][vv][i] = sum_{m in segment sg} XL[vv][cos][m] cos(w_i t_m) + XL[vv][sin][m] sin(w_i t_m),
 // XL = the lattice coefficients of A1 * [v ; P'v] (column scale * entry of v, or of P'v), formed here in
-// LDS for the block's segment; one thread per (frequency, segment), the coefficient reads are wave-uniform.
+// LDS for the block's segment; one thread per (FOLDED frequency, segment): the cosine and the sine sums are kept
+// apart, C + S is the response at +wf and C - S the one at -wf; the coefficient reads are wave-uniform.
 constexpr int SEGMAX = 128;
 template <int NV>
 __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __restrict__ vin, double* __restrict__ UU) {
     LANES(P, vin, UU);
     constexpr int NVVMAX = 2 * NV;
     __shared__ double2 cf[NVVMAX][SEGMAX];                // (cos, sin) coefficient pairs
-    const int i = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x, sg = blockIdx.y;
     const int m0 = sg * P.seg, m1 = min(m0 + P.seg, P.D1);
     const int NVV = P.quad ? 2 * NV : NV;
     for (int e = threadIdx.x; e < 2 * (m1 - m0); e += 256) {
@@ -490,25 +494,30 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
         }
     }
     __syncthreads();
-    if (i >= P.Mf) return;
-    const double4 sd4 = P.seed_eval[(long)sg * P.Mpad + i];
+    if (k >= P.nfold) return;
+    const double4 sd4 = P.seed_eval[(long)sg * P.Mpad + k];
     double c = sd4.x, s = sd4.y;
     const double cw = sd4.z, sw = sd4.w;
-    double acc[NVVMAX];
+    double ac[NVVMAX], as[NVVMAX];
 #pragma unroll
-    for (int v = 0; v < NVVMAX; ++v) acc[v] = 0;
+    for (int v = 0; v < NVVMAX; ++v) ac[v] = as[v] = 0;
 #pragma unroll 8
     for (int m = 0; m < m1 - m0; ++m) {
 #pragma unroll
         for (int v = 0; v < NVVMAX; ++v)
-            if (v < NVV) { const double2 x = cf[v][m]; acc[v] += x.x * c + x.y * s; }
+            if (v < NVV) { const double2 x = cf[v][m]; ac[v] += x.x * c; as[v] += x.y * s; }
         const double cn = c * cw - s * sw;
         s = s * cw + c * sw;
         c = cn;
     }
+    const int ip = P.fold_pos[k], in = P.fold_neg[k];
 #pragma unroll
     for (int v = 0; v < NVVMAX; ++v)
-        if (v < NVV) UU[((long)sg * NVV + v) * P.Mpad + i] = acc[v];
+        if (v < NVV) {
+            double* u = UU + ((long)sg * NVV + v) * P.Mpad;
+            if (ip >= 0) u[ip] = ac[v] + as[v];
+            if (in >= 0) u[in] = ac[v] - as[v];
+        }
 }
 
 // seed tables for the recurrences below (once per design)
@@ -525,65 +534,73 @@ __global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb,
 __global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
     LANES(P, seeds);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
-    if (i >= P.Mf) return;
-    const double w = P.w[i];
+    if (i >= P.nfold) return;
+    const double w = P.wf[i];
     double s, c, sw, cw;
     sincos(w * (P.tmin + sg * P.seg), &s, &c);
     sincos(w, &sw, &cw);
     seeds[(long)sg * P.Mpad + i] = make_double4(c, s, cw, sw);
 }
 
-// K3 / K2 (lattice): partial[group][v][0|1][m] = sum over the CGRP chunks of the group, sum_{i in chunk}
-// p_v[i] cos|sin(w_i t_m), t_m on up to two unit-step progressions (na points, then nb points; the seeds table
-// knows them).  Block = 64 points x CGRP chunks: one thread per (point, chunk) runs the recurrence over the
-// chunk's frequencies, the CGRP chunk sums of a point are added in LDS (fixed order), so the fold kernels
-// see nchunk / CGRP partials.  The chunks' operands sit in LDS: with AGG they are the per-frequency
-// aggregates of a row vector (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at that frequency),
-// otherwise they are read from the per-frequency array src[v][Mpad].
-constexpr int CGRP = 4;
+// K3 / K2 (lattice): partial[group][v][0|1][m] = sum over the CGRP chunks of the group, sum_{k in chunk}
+// pe_v[k] cos(wf_k t_m) | po_v[k] sin(wf_k t_m), t_m on up to two unit-step progressions (na points, then nb points;
+// the seeds table knows them), with pe = p(+wf) + p(-wf), po = p(+wf) - p(-wf) over the folded frequency list.
+// Block = 256 moment points x one group of CGRP chunks: every thread runs the recurrence of its point through the
+// group's chunks one after the other (fixed order), so the operands of a chunk group are staged -- with AGG:
+// aggregated from the row vector through the CSR map (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at
+// that frequency); otherwise read from the per-frequency array src[v][Mpad] -- once per 256 points, and the fold
+// kernels see nchunk / CGRP partials.
+constexpr int CGRP = 8;
 constexpr int MPTS = 256;     // moment points per block
 template <int NV, bool AGG>
-__global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __restrict__ src, const double4* __restrict__ seeds,
-                                                      int na, int nb, double* __restrict__ partial) {
-    LANES(P, src, seeds, partial);
-    // Block = 256 moment points x one group of CGRP chunks: every thread runs the recurrence of its point through
-    // the group's chunks one after the other (fixed order), so the per-frequency operands of a chunk group are
-    // staged -- with AGG: aggregated from the row vector through the CSR map -- once per 256 points, and the fold
-    // kernels see nchunk / CGRP partials.
-    __shared__ double pp[NV][CGRP][CHK];
-    const int tid = threadIdx.x;
-    const int ch0 = blockIdx.y * CGRP;
-    for (int e = tid; e < CGRP * CHK; e += 256) {         // stage the operands of the group's chunks
-        const int cc = e / CHK, q = e - cc * CHK, ch = ch0 + cc;
-        const bool live = ch < P.nchunk && q < P.ch_count[ch < P.nchunk ? ch : 0];
-        const int i = live ? P.ch_start[ch] + q : 0;
-        if (AGG) {
-            const int nv = P.quad ? NV / 2 : NV;
-            double p1[NV], p2[NV];
+__device__ __forceinline__ void freq_operands(const DProg& P, const double* __restrict__ src, int i, double (&out)[NV]) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) p1[v] = p2[v] = 0;
-            if (live)
-                for (int qq = P.f_ptr[i]; qq < P.f_ptr[i + 1]; ++qq) {
-                    const int r = P.f_rows[qq];
-                    const double al = P.alpha[r], be = P.beta[r];
-#pragma unroll
-                    for (int v = 0; v < NV; ++v)
-                        if (v < nv) {
-                            const double x = src[(long)v * P.Rp + r];
-                            p1[v] += al * x;
-                            p2[v] += be * x;
-                        }
-                }
+    for (int v = 0; v < NV; ++v) out[v] = 0;
+    if (i < 0) return;
+    if (AGG) {
+        const int nv = P.quad ? NV / 2 : NV;
+        for (int qq = P.f_ptr[i]; qq < P.f_ptr[i + 1]; ++qq) {
+            const int r = P.f_rows[qq];
+            const double al = P.alpha[r], be = P.beta[r];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 if (v < nv) {
-                    pp[v][cc][q] = p1[v];
-                    if (P.quad) pp[nv + v][cc][q] = p2[v];
+                    const double x = src[(long)v * P.Rp + r];
+                    out[v] += al * x;
+                    if (P.quad) out[nv + v] += be * x;
                 }
-        } else {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) pp[v][cc][q] = live ? src[(long)v * P.Mpad + i] : 0.0;
         }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) out[v] = src[(long)v * P.Mpad + i];
+    }
+}
+// (pe, po) of every folded frequency, one thread each: the serial gathers through the CSR map happen once here, not
+// once per block of the moment kernel
+template <int NV, bool AGG>
+__global__ __launch_bounds__(256) void k_freq_fold(DProg P, const double* __restrict__ src, double2* __restrict__ out) {
+    LANES(P, src, out);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= P.nfold) return;
+    double a[NV], b[NV];
+    freq_operands<NV, AGG>(P, src, P.fold_pos[k], a);
+    freq_operands<NV, AGG>(P, src, P.fold_neg[k], b);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[(long)v * P.Mpad + k] = make_double2(a[v] + b[v], a[v] - b[v]);
+}
+template <int NV>
+__global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double2* __restrict__ src, const double4* __restrict__ seeds,
+                                                      int na, int nb, double* __restrict__ partial) {
+    LANES(P, src, seeds, partial);
+    __shared__ double2 pp[NV][CGRP][CHK];                 // (pe, po)
+    const int tid = threadIdx.x;
+    const int ch0 = blockIdx.y * P.cgrp;
+    for (int e = tid; e < P.cgrp * CHK; e += 256) {       // stage the operands of the group's chunks
+        const int cc = e / CHK, q = e - cc * CHK, ch = ch0 + cc;
+        const bool live = ch < P.nchunk && q < P.ch_count[ch < P.nchunk ? ch : 0];
+        const int k = live ? P.ch_start[ch] + q : 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) pp[v][cc][q] = live ? src[(long)v * P.Mpad + k] : make_double2(0.0, 0.0);
     }
     __syncthreads();
     const int m = blockIdx.x * MPTS + tid;
@@ -591,24 +608,28 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double* __r
     double ag[NV], as[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) ag[v] = as[v] = 0;
-    for (int cl = 0; cl < CGRP; ++cl) {
-        const int ch = ch0 + cl;
-        if (ch >= P.nchunk) break;
-        const double4 sd4 = seeds[(long)ch * (na + nb) + m];
-        double c = sd4.x, s = sd4.y;
-        const double cd = sd4.z, sd = sd4.w;
-        const int cnt = P.ch_count[ch];
+    // two chunks at a time: their recurrences are independent chains, which is what keeps the fp64 pipe busy with the
+    // two or three waves per SIMD this grid has (operands past a chunk's end are staged as zeros)
+    for (int cl = 0; cl < P.cgrp; cl += 2) {
+        const int cha = ch0 + cl, chb = cha + 1;
+        if (cha >= P.nchunk) break;
+        const bool two = cl + 1 < P.cgrp && chb < P.nchunk;
+        const double4 sa = seeds[(long)cha * (na + nb) + m];
+        const double4 sb = two ? seeds[(long)chb * (na + nb) + m] : make_double4(0.0, 0.0, 0.0, 0.0);
+        double c0 = sa.x, s0 = sa.y, c1 = sb.x, s1 = sb.y;
+        const int cnt = max(P.ch_count[cha], two ? P.ch_count[chb] : 0);
+        const int clb = two ? cl + 1 : cl;                  // (a lone last chunk pairs with itself at zero weight: sb = 0)
 #pragma unroll 4
         for (int q = 0; q < cnt; ++q) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const double p = pp[v][cl][q];
-                ag[v] += p * c;
-                as[v] += p * s;
+                const double2 pa = pp[v][cl][q], pb = pp[v][clb][q];
+                ag[v] += pa.x * c0; as[v] += pa.y * s0;
+                ag[v] += pb.x * c1; as[v] += pb.y * s1;
             }
-            const double cn = c * cd - s * sd;
-            s = s * cd + c * sd;
-            c = cn;
+            const double n0 = c0 * sa.z - s0 * sa.w, n1 = c1 * sb.z - s1 * sb.w;
+            s0 = s0 * sa.z + c0 * sa.w; s1 = s1 * sb.z + c1 * sb.w;
+            c0 = n0; c1 = n1;
         }
     }
 #pragma unroll
@@ -1660,11 +1681,20 @@ struct LatticeInfo {
     int D1 = 0;
     std::vector<int> lat, lat_col, lat_qcol, ch_start, ch_count;
     std::vector<double> lat_scale, lat_qscale, ch_w0, ch_dw;
+    // folded frequency list (see analyse_lattice): entry k stands for +wf[k] (frequency index fold_pos[k], or -1) and
+    // -wf[k] (fold_neg[k], or -1); the chunks index this list
+    std::vector<int> fold_pos, fold_neg;
+    std::vector<double> wf;
 };
-// chunk_len: longest run of frequencies one recurrence covers between two exact sincos seeds (<= CHK)
-static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = 64) {
+// chunk_len: longest run of frequencies one recurrence covers between two exact sincos seeds (<= CHK).
+// fold: pair the frequencies +w / -w of a grid that is symmetric about 0 (linspace(-pi, pi, m) is, to 2 ulp): the two
+// share cos(w t) and differ in the sign of sin(w t), so every recurrence of the lattice kernels serves both -- the
+// moment sums take p(+w) + p(-w) on the cosine and p(+w) - p(-w) on the sine, a row response is C + S at +w and C - S
+// at -w.  A frequency without a partner (band edges, one-sided grids) is an entry with one side empty.
+static LatticeInfo analyse_lattice(const TrigProgram& Q, bool fold = true, int chunk_len = 64) {
     LatticeInfo L;
     if (const char* ev = std::getenv("MBFIR_CHUNK")) chunk_len = std::max(4, std::min(CHK, std::atoi(ev)));
+    if (const char* ev = std::getenv("MBFIR_FOLD")) fold = std::atoi(ev) != 0;
     const int Nt = Q.Nt, Mf = Q.Mf;
     if (Nt <= 0 || Mf <= 0) return L;
     double tmin = Q.col_tau[0];
@@ -1697,24 +1727,47 @@ static LatticeInfo analyse_lattice(const TrigProgram& Q, int chunk_len = 64) {
     double wmax = 1.0;
     for (double w : Q.w) wmax = std::max(wmax, std::fabs(w));
     const double tol = 2 * 2.2204460492503131e-16 * wmax;
+    // ---- the folded list ---------------------------------------------------------------------------------------
+    if (fold) {
+        std::vector<int> order(Mf);
+        for (int i = 0; i < Mf; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(Q.w[a]) < std::fabs(Q.w[b]); });
+        for (int q = 0; q < Mf; ++q) {
+            const int i = order[q];
+            const bool neg = Q.w[i] < 0.0;
+            const double aw = std::fabs(Q.w[i]);
+            if (!L.wf.empty() && aw - L.wf.back() <= tol && (neg ? L.fold_neg.back() < 0 : L.fold_pos.back() < 0)) {
+                (neg ? L.fold_neg : L.fold_pos).back() = i;
+                L.wf.back() = 0.5 * (L.wf.back() + aw);       // the pair's common |w|: each side within 1 ulp of its own
+            } else {
+                L.wf.push_back(aw); L.fold_pos.push_back(neg ? -1 : i); L.fold_neg.push_back(neg ? i : -1);
+            }
+        }
+    } else {                                                  // every frequency on its own, in the program's order, signs kept
+        L.wf = Q.w;
+        L.fold_pos.resize(Mf); L.fold_neg.assign(Mf, -1);
+        for (int i = 0; i < Mf; ++i) L.fold_pos[i] = i;
+    }
+    const int Nf = int(L.wf.size());
+    const std::vector<double>& W = L.wf;
     // Longest run from i (at most chunk_len points) that lies on the straight line through its END POINTS to within
     // `tol`: a linspace run passes at full length (every point is within half an ulp of the exact line), where a step
     // estimated from the first two points drifts out of tolerance after ~30 points.  Shrink by halves on failure.
-    for (int i = 0; i < Mf;) {
-        int cnt = std::min(chunk_len, Mf - i);
+    for (int i = 0; i < Nf;) {
+        int cnt = std::min(chunk_len, Nf - i);
         double dwf = 0.0;
         for (;;) {
-            dwf = cnt > 1 ? (Q.w[i + cnt - 1] - Q.w[i]) / (cnt - 1) : 0.0;
+            dwf = cnt > 1 ? (W[i + cnt - 1] - W[i]) / (cnt - 1) : 0.0;
             bool ok = true;
-            for (int q = 1; q + 1 < cnt && ok; ++q) ok = std::fabs(Q.w[i + q] - (Q.w[i] + q * dwf)) <= tol;
+            for (int q = 1; q + 1 < cnt && ok; ++q) ok = std::fabs(W[i + q] - (W[i] + q * dwf)) <= tol;
             if (ok || cnt <= 2) break;
             cnt = std::max(2, cnt / 2);
         }
-        if (cnt == 2 && i + 2 < Mf && std::fabs(Q.w[i + 2] - (Q.w[i] + 2 * dwf)) > tol && std::fabs(dwf) > 0 &&
-            (i + 3 >= Mf || std::fabs((Q.w[i + 2] - Q.w[i + 1]) - (Q.w[i + 3] - Q.w[i + 2])) <= tol))
+        if (cnt == 2 && i + 2 < Nf && std::fabs(W[i + 2] - (W[i] + 2 * dwf)) > tol && std::fabs(dwf) > 0 &&
+            (i + 3 >= Nf || std::fabs((W[i + 2] - W[i + 1]) - (W[i + 3] - W[i + 2])) <= tol))
             cnt = 1;                                       // an isolated point (a band edge) ahead of the next run
         if (cnt <= 1) { cnt = 1; dwf = 0.0; }
-        L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(Q.w[i]); L.ch_dw.push_back(dwf);
+        L.ch_start.push_back(i); L.ch_count.push_back(cnt); L.ch_w0.push_back(W[i]); L.ch_dw.push_back(dwf);
         i += cnt;
     }
     if ((long)L.ch_start.size() > Mf / 8 + 64) return L;       // grid too irregular: the dense path is the better one
@@ -1783,6 +1836,7 @@ struct Solver::Impl {
     int *tile_ij, *flag;
     double *x, *s, *z, *lam, *dl, *wl, *w3, *wbb;
     double *XX, *UU, *PP, *partial, *TT, *TT2, *Dw, *BB, *qv;
+    double2* PPf = nullptr;      // (pe, po) per folded frequency (k_freq_fold)
     double *Mom, *MomB;            // lattice mode: H moments, border moments
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
@@ -1832,7 +1886,7 @@ struct Solver::Impl {
     void apply_G(const double* v, double* out) {
         const int NVV = P.quad ? 2 * NV : NV;
         if (P.trig) {
-            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
+            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
             hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
             return;
         }
@@ -1852,7 +1906,7 @@ struct Solver::Impl {
     template <int NV>
     void apply_G_winv2(const double* v, double* gout, const double* sub, double* wout) {
         if (P.trig && !P.big) {
-            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
+            hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
             hipLaunchKernelGGL(k_rows_winv2<NV>, lane_grid(dim3(cdiv(P.l + P.nq3, 256)), nlanes), dim3(256), 0, st, P, UU, v, dl, w3, sub, gout, wout);
             return;
         }
@@ -1862,16 +1916,18 @@ struct Solver::Impl {
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
     void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
-        dim3 g(cdiv(na + nb, MPTS), cdiv(P.nchunk, CGRP)), b(256);
+        dim3 g(cdiv(na + nb, MPTS), cdiv(P.nchunk, P.cgrp)), b(256), gf(cdiv(P.nfold, 256));
         switch (nv) {
-            case 1: hipLaunchKernelGGL((k_trig_moments<1, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 2: hipLaunchKernelGGL((k_trig_moments<2, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 3: hipLaunchKernelGGL((k_trig_moments<3, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 4: hipLaunchKernelGGL((k_trig_moments<4, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
-            case 6: hipLaunchKernelGGL((k_trig_moments<6, false>), lane_grid(g, nlanes), b, 0, st, P, pp, seeds, na, nb, partial); break;
+#define MOM_CASE(NVX)                                                                                                          \
+            case NVX:                                                                                                          \
+                hipLaunchKernelGGL((k_freq_fold<NVX, false>), lane_grid(gf, nlanes), b, 0, st, P, pp, PPf);                    \
+                hipLaunchKernelGGL((k_trig_moments<NVX>), lane_grid(g, nlanes), b, 0, st, P, PPf, seeds, na, nb, partial);     \
+                break;
+            MOM_CASE(1) MOM_CASE(2) MOM_CASE(3) MOM_CASE(4) MOM_CASE(6)
+#undef MOM_CASE
             default: throw HipError("moments: unsupported vector count");
         }
-        hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.LDM, 64), 2 * nv), nlanes), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, CGRP), 2 * nv, P.LDM, P.LDM, out, lane_bytes, P.mask);
+        hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.LDM, 64), 2 * nv), nlanes), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, P.cgrp), 2 * nv, P.LDM, P.LDM, out, lane_bytes, P.mask);
     }
     void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
@@ -1887,15 +1943,21 @@ struct Solver::Impl {
     template <int NV>
     void apply_GT(const double* val, double* out) {
         if (P.trig) {
-            dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, CGRP)), b(256);
-            if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
-            else hipLaunchKernelGGL((k_trig_moments<NV, true>), lane_grid(g, nlanes), b, 0, st, P, val, P.seed_tau, P.D1, 0, partial);
+            dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, P.cgrp)), b(256);
+            const dim3 gf(cdiv(P.nfold, 256));
+            if (P.quad) {
+                hipLaunchKernelGGL((k_freq_fold<2 * NV, true>), lane_grid(gf, nlanes), b, 0, st, P, val, PPf);
+                hipLaunchKernelGGL((k_trig_moments<2 * NV>), lane_grid(g, nlanes), b, 0, st, P, PPf, P.seed_tau, P.D1, 0, partial);
+            } else {
+                hipLaunchKernelGGL((k_freq_fold<NV, true>), lane_grid(gf, nlanes), b, 0, st, P, val, PPf);
+                hipLaunchKernelGGL((k_trig_moments<NV>), lane_grid(g, nlanes), b, 0, st, P, PPf, P.seed_tau, P.D1, 0, partial);
+            }
         } else {
             dim3 g(P.ld / 128, nsplit_at), b(64, 4);
             if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
             else hipLaunchKernelGGL((k_atmulti<NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
         }
-        hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, CGRP) : nsplit_at, val, out);
+        hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, P.cgrp) : nsplit_at, val, out);
         allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
@@ -2233,12 +2295,12 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     LaneHost L;
     index_structures(Q, L);
     LatticeInfo Lt;
-    if (!o.dense_trig) Lt = analyse_lattice(Q);
+    if (!o.dense_trig) Lt = analyse_lattice(Q, o.ddkkt_theta <= 0);
     long tbits = 0;
     std::memcpy(&tbits, &Lt.tmin, sizeof(double));
     return {long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.Mf), long(Q.R), long(Q.l), long(Q.nq3), long(Q.big),
             long(Q.quad), long(L.f_rows.size()), long(L.c_rows.size()), long(L.yrows.size()), long(Lt.ok), long(Lt.D1),
-            long(Lt.ch_start.size()), tbits};
+            long(Lt.ch_start.size()), long(Lt.wf.size()), tbits};
 }
 // how many lanes of this shape one context runs in lock step (memory and occupancy)
 int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
@@ -2286,7 +2348,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         L.nrm_h = std::max(1.0, std::sqrt(nh)); L.nrm_c = std::max(1.0, std::sqrt(nc));
         L.degree = double(Qfull.l + Qfull.nq3 + (Qfull.big ? 1 : 0));
         index_structures(*L.Q, L);
-        if (!o.dense_trig) L.Lt = analyse_lattice(*L.Q);
+        // (the extended-precision KKT solve forms its strong rows from the exact w_i: its programs keep every frequency
+        // on its own so that the lattice operator and those rows see the same grid to the old 2 ulp)
+        if (!o.dense_trig) L.Lt = analyse_lattice(*L.Q, o.ddkkt_theta <= 0);
         L.nsweep = o.refine;
     }
     const TrigProgram& Q = *LH[0].Q;
@@ -2308,7 +2372,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         const LatticeInfo& Lb = LH[b].Lt;
         if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l ||
             Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ok != Lt.ok ||
-            Lb.D1 != Lt.D1 || Lb.ch_start.size() != Lt.ch_start.size() || Lb.tmin != Lt.tmin)
+            Lb.D1 != Lt.D1 || Lb.ch_start.size() != Lt.ch_start.size() || Lb.wf.size() != Lt.wf.size() || Lb.tmin != Lt.tmin)
             throw HipError("lock-step batch: lanes differ in shape");
     }
     // ---- sizes -----------------------------------------------------------------------------
@@ -2322,7 +2386,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
     if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
-    P.nchunk = int(Lt.ch_start.size());
+    P.nchunk = int(Lt.ch_start.size()); P.nfold = int(Lt.wf.size());
+    P.cgrp = nlanes >= 4 ? CGRP : 2;
+    if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
     P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
@@ -2355,6 +2421,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.lat = UPL(int, Lt.lat); P.lat_col = UPL(int, Lt.lat_col); P.lat_qcol = UPL(int, Lt.lat_qcol);
     P.lat_scale = UPL(double, Lt.lat_scale); P.lat_qscale = UPL(double, Lt.lat_qscale);
     P.ch_start = UPL(int, Lt.ch_start); P.ch_count = UPL(int, Lt.ch_count); P.ch_w0 = UPL(double, Lt.ch_w0); P.ch_dw = UPL(double, Lt.ch_dw);
+    P.fold_pos = UPL(int, Lt.fold_pos); P.fold_neg = UPL(int, Lt.fold_neg); P.wf = UPL(double, Lt.wf);
 #undef UPQ
 #undef UPL
     // ---- work buffers ----------------------------------------------------------------------
@@ -2382,7 +2449,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
-    S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
+    S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.PPf = ar.get<double2>(6 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(P.trig ? (size_t)P.nchunk * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     if (use_dd) {
@@ -2427,7 +2494,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                            const_cast<double4*>(P.seed_tau));
         hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), nlanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
                            2 * P.D1 - 1, const_cast<double4*>(P.seed_h));
-        hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
+        hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
     }
     std::vector<double> sc0((size_t)S_COUNT * nlanes, 0.0);
     for (int b = 0; b < nlanes; ++b) {
@@ -2469,7 +2536,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
-            hipLaunchKernelGGL(k_trig_eval<1>, lane_grid(dim3(cdiv(P.Mf, 256), P.useg), nlanes), dim3(256), 0, st, P, S.x, S.UU);
+            hipLaunchKernelGGL(k_trig_eval<1>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, S.x, S.UU);
             S.apply_GT<1>(S.z, S.GTz);
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
         } else {
