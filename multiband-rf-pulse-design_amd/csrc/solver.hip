@@ -127,7 +127,7 @@ struct DProg {
     const int *ch_start, *ch_count;   // nchunk: runs of the FOLDED frequency list (analyse_lattice)
     const int *fold_pos, *fold_neg;   // nfold: frequency index at +wf[k] / -wf[k], or -1
     const double* wf; int nfold;
-    int cgrp;                         // chunks per block of k_trig_moments (<= CGRP): many when lanes fill the chip, few for one design
+    int cgrp;                         // chunks per block of k_trig_moments (<= CGRP)
     const double *ch_w0, *ch_dw;
     // rotation seeds, tabulated once per design (a sincos costs as much as ~40 recurrence steps):
     const double4* seed_tau;          // [nchunk][D1]   (cos, sin)(w0 t), (cos, sin)(dw t), t = tmin + m
@@ -550,7 +550,7 @@ __global__ void k_build_seeds_e(DProg P, double4* __restrict__ seeds) {
 // aggregated from the row vector through the CSR map (p1 = sum alpha_r val_r, p2 = sum beta_r val_r over the rows at
 // that frequency); otherwise read from the per-frequency array src[v][Mpad] -- once per 256 points, and the fold
 // kernels see nchunk / CGRP partials.
-constexpr int CGRP = 8;
+constexpr int CGRP = 4;
 constexpr int MPTS = 256;     // moment points per block
 template <int NV, bool AGG>
 __device__ __forceinline__ void freq_operands(const DProg& P, const double* __restrict__ src, int i, double (&out)[NV]) {
@@ -2387,7 +2387,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
     P.nchunk = int(Lt.ch_start.size()); P.nfold = int(Lt.wf.size());
-    P.cgrp = nlanes >= 4 ? CGRP : 2;
+    P.cgrp = 2;          // one pair of interleaved chunks per block: measured best at 1 and at 8 lanes, and the same sums in both
     if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
     P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
