@@ -109,7 +109,7 @@ void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const
 // Spectral factorisation (fir_ap_cvx.m:185-186,264-304): x (2n-1) -> n taps (re, im interleaved
 // in hout[2n]).  work must hold 6*lp doubles, lp = 8*2^ceil(log2(2n-1)).
 int specfact_lp(int n);
-void specfact_launch(const double* x, int n, double* work, double* hout, hipStream_t st);
+void specfact_launch(const double* x, int n, double* work, double* hout, hipStream_t st, int nlanes = 1, size_t lane_bytes = 0);
 
 // Inverse SLR (slr.hip; b2a.m:15-32, ab2rf.m:14-29).  b2a: work holds 48 n doubles; a_il / b_il / rf_il are
 // interleaved (re, im) device arrays of 2 n doubles.  ab2rf: n <= 2048.

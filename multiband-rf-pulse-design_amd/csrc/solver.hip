@@ -128,6 +128,7 @@ struct DProg {
     const int *fold_pos, *fold_neg;   // nfold: frequency index at +wf[k] / -wf[k], or -1
     const double* wf; int nfold;
     int cgrp;                         // chunks per block of k_trig_moments (<= CGRP)
+    int seeds_shared;                 // all lanes of the unit have the same grid and lattice: they read lane 0's seed tables
     const double *ch_w0, *ch_dw;
     // rotation seeds, tabulated once per design (a sincos costs as much as ~40 recurrence steps):
     const double4* seed_tau;          // [nchunk][D1]   (cos, sin)(w0 t), (cos, sin)(dw t), t = tmin + m
@@ -147,7 +148,7 @@ struct DProg {
         sh(f_ptr, off); sh(f_rows, off); sh(c_ptr, off); sh(c_rows, off); sh(yrows, off);
         sh(lat, off); sh(lat_col, off); sh(lat_qcol, off); sh(lat_scale, off); sh(lat_qscale, off);
         sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off); sh(fold_pos, off); sh(fold_neg, off); sh(wf, off);
-        sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off);
+        if (!seeds_shared) { sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off); }
     }
 };
 // Kernel prologue: leave if the lane is masked off, then move the program and the listed pointer arguments to
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(256) void k_freq_fold(DProg P, const double* __rest
 template <int NV>
 __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double2* __restrict__ src, const double4* __restrict__ seeds,
                                                       int na, int nb, double* __restrict__ partial) {
-    LANES(P, src, seeds, partial);
+    if (!P.seeds_shared && blockIdx.z) seeds = reinterpret_cast<const double4*>(reinterpret_cast<const char*>(seeds) + (size_t)blockIdx.z * P.lane_bytes);
+    LANES(P, src, partial);
     __shared__ double2 pp[NV][CGRP][CHK];                 // (pe, po)
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.y * P.cgrp;
@@ -1820,6 +1822,7 @@ struct Solver::Impl {
     int* hostFlag = nullptr;     // pinned, 4 per lane
     // lock-step batch: nlanes designs of identical shape in one arena, lane b at + b * lane_bytes (see DProg)
     int nlanes = 1, nlanes_last = 1;
+    bool taps_valid = false;     // hout holds the taps of the last unit's solutions (specfact_last)
     long chol_launch_count = 0;  // k_chol_step launches of the current solve
     size_t lane_bytes = 0;
     int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
@@ -2387,6 +2390,16 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
     P.nchunk = int(Lt.ch_start.size()); P.nfold = int(Lt.wf.size());
+    P.seeds_shared = 0;
+    if (nlanes > 1 && Lt.ok) {                               // sweeps over Peak / ripple keep the grid: one seed table serves the unit
+        bool same = true;
+        for (int b = 1; b < nlanes && same; ++b) {
+            const LatticeInfo& Lb = LH[b].Lt;
+            same = Lb.wf == Lt.wf && Lb.ch_w0 == Lt.ch_w0 && Lb.ch_dw == Lt.ch_dw && Lb.ch_start == Lt.ch_start && Lb.ch_count == Lt.ch_count;
+        }
+        P.seeds_shared = same ? 1 : 0;
+    }
+    if (const char* ev = std::getenv("MBFIR_SHARE_SEEDS")) P.seeds_shared = P.seeds_shared && std::atoi(ev) != 0;
     P.cgrp = 2;          // one pair of interleaved chunks per block: measured best at 1 and at 8 lanes, and the same sums in both
     if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
@@ -2490,11 +2503,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     // ---- build A1, norms -------------------------------------------------------------------
     if (!P.trig) hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
     else {
-        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), nlanes), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
+        const int seed_lanes = P.seeds_shared ? 1 : nlanes;
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
                            const_cast<double4*>(P.seed_tau));
-        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), nlanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
                            2 * P.D1 - 1, const_cast<double4*>(P.seed_h));
-        hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
+        hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), seed_lanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
     }
     std::vector<double> sc0((size_t)S_COUNT * nlanes, 0.0);
     for (int b = 0; b < nlanes; ++b) {
@@ -2726,7 +2740,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
                                 : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
     }
-    S.nlanes_last = nlanes;
+    S.nlanes_last = nlanes; S.taps_valid = false;
 }
 
 }  // namespace mbfir
@@ -2742,13 +2756,17 @@ void Solver::set_solution(const std::vector<double>& x) {
     MBFIR_HIP(hipSetDevice(S.device));
     MBFIR_HIP(hipMemcpyAsync(S.xout, x.data(), sizeof(double) * x.size(), hipMemcpyHostToDevice, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));
+    S.taps_valid = false;
 }
 void Solver::specfact_last(int n, double* h_re, double* h_im, int lane) {
     Impl& S = *impl;
     MBFIR_HIP(hipSetDevice(S.device));
     if (lane < 0 || lane >= S.nlanes_last) throw HipError("specfact: no such lane");
     const size_t off = (size_t)lane * S.lane_bytes / sizeof(double);
-    specfact_launch(S.xout + off, n, S.sfwork + off, S.hout + off, S.st);
+    if (!S.taps_valid) {                                  // one launch factorises every lane of the last unit (a lane
+        specfact_launch(S.xout, n, S.sfwork, S.hout, S.st, S.nlanes_last, S.lane_bytes);    // without a solution yields
+        S.taps_valid = true;                              // numbers nobody asks for)
+    }
     std::vector<double> h(2 * (size_t)n);
     MBFIR_HIP(hipMemcpyAsync(h.data(), S.hout + off, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));

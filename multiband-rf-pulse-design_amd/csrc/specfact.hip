@@ -34,9 +34,17 @@ __device__ void fft_inplace(double2* a, int n, int logn, int sign) {
     }
 }
 
+// blockIdx.x = design of a lock-step unit: every pointer moves by blockIdx.x * lane_bytes
 __global__ __launch_bounds__(1024) void k_specfact(const double* __restrict__ x, int n, int lp, int loglp,
-                                                   double2* __restrict__ B0, double2* __restrict__ B1,
-                                                   double2* __restrict__ B2, double* __restrict__ hout) {
+                                                   double2* __restrict__ B0, double* __restrict__ hout, size_t lane_bytes) {
+    {
+        const size_t off = (size_t)blockIdx.x * lane_bytes;
+        x = reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + off);
+        B0 = reinterpret_cast<double2*>(reinterpret_cast<char*>(B0) + off);
+        hout = reinterpret_cast<double*>(reinterpret_cast<char*>(hout) + off);
+    }
+    double2* __restrict__ B1 = B0 + lp;
+    double2* __restrict__ B2 = B0 + 2 * lp;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int l = 2 * n - 1;
     const int pad_lo = (lp - l + 1) / 2;                 // ceil((lp-l)/2)            :273
@@ -98,11 +106,10 @@ int specfact_lp(int n) {
     return 8 * p;
 }
 
-void specfact_launch(const double* x, int n, double* work, double* hout, hipStream_t st) {
+void specfact_launch(const double* x, int n, double* work, double* hout, hipStream_t st, int nlanes, size_t lane_bytes) {
     int lp = specfact_lp(n), loglp = 0;
     while ((1 << loglp) < lp) ++loglp;
-    double2* B0 = reinterpret_cast<double2*>(work);
-    hipLaunchKernelGGL(k_specfact, dim3(1), dim3(1024), 0, st, x, n, lp, loglp, B0, B0 + lp, B0 + 2 * lp, hout);
+    hipLaunchKernelGGL(k_specfact, dim3(nlanes), dim3(1024), 0, st, x, n, lp, loglp, reinterpret_cast<double2*>(work), hout, lane_bytes);
 }
 
 }  // namespace mbfir
