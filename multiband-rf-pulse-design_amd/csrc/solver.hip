@@ -98,6 +98,8 @@ enum {
 constexpr double STEP = 0.99;
 constexpr double SIGMA_MAX = 0.25;   // cap of Mehrotra's centring parameter (oracle/conic_ipm.py SIGMA_MAX)
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
+constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding kernels (a 1024-thread block has to wait for a
+                              // whole CU when other units share the chip)
 constexpr int MAX_SWEEPS = 8;
 constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
 constexpr int WALL_ITERS = 3;
@@ -371,11 +373,11 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
     }
 }
 
-// Block x < nblk_cols: 32 columns x 32 split groups -> out[v][j] (4 loads in flight per thread);
+// Block x < nblk_cols: 32 columns x 8 split groups -> out[v][j] (4 loads in flight per thread);
 // the last block forms the y block.
-constexpr int GTC = 32, GTG = 32;
+constexpr int GTC = 32, GTG = 8;       // 256 threads: a 1024-thread block waits for a whole CU once other units share the chip
 template <int NV>
-__global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
+__global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
                                                     const double* __restrict__ val, double* __restrict__ out) {
     LANES(P, partial, val, out);
     __shared__ double sh[2 * NV][GTG][GTC + 1];
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
         for (int v = 0; v < NV; ++v)
             for (int e = 0; e < P.Ne; ++e) {
                 double a = 0;
-                for (int q = tid; q < P.nyrows; q += 1024) {
+                for (int q = tid; q < P.nyrows; q += GTC * GTG) {
                     const int r = P.yrows[q];
                     a += P.ey[3 * r + e] * val[(long)v * P.Rp + r];
                 }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_gt_finish(DProg P, const double* __res
                 __syncthreads();
                 if (tid == 0) {
                     double t = 0;
-                    for (int w = 0; w < 16; ++w) t += red[w];
+                    for (int w = 0; w < GTC * GTG / 64; ++w) t += red[w];
                     out[(long)v * P.LDV + P.Nt + e] = t;
                 }
             }
@@ -2013,20 +2015,20 @@ struct Solver::Impl {
         apply_G_winv2<NV>(dx, gdx, wbz, dz);
         double* r = rhsN;
         apply_GT<NV>(dz, tmpN);
-        hipLaunchKernelGGL(k_resid_norm<NV>, g1, dim3(1024), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
+        hipLaunchKernelGGL(k_resid_norm<NV>, g1, dim3(SCAL_T), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
         if (nsweep <= 0) return;
         const int* live = P.mask;
         P.mask = mask_row(1);
         hsolve<NV>(r, tmpN2);                                                               // z = M'M r
         for (int it = 0; it < nsweep; ++it) {
             P.mask = mask_row(it + 1);
-            hipLaunchKernelGGL(k_cg_start<NV>, g1, dim3(1024), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
+            hipLaunchKernelGGL(k_cg_start<NV>, g1, dim3(SCAL_T), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
             apply_G_winv2<NV>(pN, tmpR, nullptr, wpR);                                      // G p, W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
             if (shard_size == 1) {
                 hipLaunchKernelGGL(k_cg_step_update<NV>, gR, b256, 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1, tmpR, wpR, gdx, dz);
             } else {
-                hipLaunchKernelGGL(k_cg_step<NV>, g1, dim3(1024), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
+                hipLaunchKernelGGL(k_cg_step<NV>, g1, dim3(SCAL_T), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
                 hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
             }
             if (it + 1 < nsweep) { P.mask = mask_row(it + 2); hsolve<NV>(r, tmpN2); }
@@ -2068,7 +2070,7 @@ struct Solver::Impl {
         hipMemsetAsync(gdx, 0, sizeof(double) * NV * P.Rp, st);
         for (int it = 0; it < 2; ++it) {
             apply_GT<NV>(dz, tmpN);
-            hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
+            hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
             hipLaunchKernelGGL(k_dd_r2<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, dl, bz, gdx, dz, tmpR, ddtS);                  // r2, t
             if (P.big) hipLaunchKernelGGL(k_dd_r2_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, bz, gdx, dz, tmpR, ddtS, scratch);
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
@@ -2570,10 +2572,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
         }
         if (sharded) {
-            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
+            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
             S.allreduce(S.RB, 4, 0);
         }
-        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
+        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipMemcpy2DAsync(S.hostFlag, sizeof(int) * 4, S.flag, S.lane_bytes, sizeof(int), nlanes, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
@@ -2670,9 +2672,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 nb += 1;
             }
             if (sharded) {
-                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 0);
+                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 0);
                 S.allreduce(S.RB, 3, 0);
-                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(1024), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 1);
+                hipLaunchKernelGGL(k_scal_dtau, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, x1, xx2, S.partR, nb, mode, S.RB, 1);
             }
             return nb;                                     // unsharded: k_dir_post folds these partials itself
         };
@@ -2688,11 +2690,11 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 nb += 1;
             }
             if (sharded) {
-                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 0);
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 0);
                 S.allreduce(S.RB, 2, 1);
-                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
             } else if (mode == 1) {
-                hipLaunchKernelGGL(k_scal_step, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
+                hipLaunchKernelGGL(k_scal_step, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
             }
             return nb;
         };

@@ -136,12 +136,13 @@ def test_retry_inside_a_batch():
     assert res[1][1] == "Solved" and res[1][2]["lattice"] == 1 and res[3][1] == "Solved"
 
 
-def test_extended_precision_retry_is_reproducible_run_to_run():
-    """The 57-tap threshold design of S-C13 ends its first attempt at reduced accuracy and is repeated with the
-    extended-precision KKT solve; the strong rows are put in a fixed order on the device (k_dd_order), so two runs give
-    the same bits (an atomic slot counter alone left 1e-7 between runs)."""
+def test_extended_precision_solve_is_reproducible_run_to_run():
+    """The 57-tap threshold design of S-C13 with the extended-precision KKT solve switched on: the strong rows are put
+    in a fixed order on the device (k_dd_order), so two runs give the same bits (the atomic slot counter alone left 1e-7
+    between runs of this ill-conditioned design)."""
     f, a, d = c13(100)
-    h1, s1, i1 = mbfir.fir_ap_cvx(57, f, a, d, 0.1, 1e-3, info=True)
-    h2, s2, i2 = mbfir.fir_ap_cvx(57, f, a, d, 0.1, 1e-3, info=True)
+    o = mbfir.make_opts(ddkkt=1)
+    h1, s1, i1 = mbfir.fir_ap_cvx(57, f, a, d, 0.1, 1e-3, info=True, opts=o)
+    h2, s2, i2 = mbfir.fir_ap_cvx(57, f, a, d, 0.1, 1e-3, info=True, opts=o)
     assert s1 == s2 == "Solved" and i1["dd_iters"] > 0 and i1["dd_iters"] == i2["dd_iters"]
     assert np.array_equal(h1, h2) and i1["pcost"] == i2["pcost"]
