@@ -297,7 +297,9 @@ struct CholStep {
     double* dinvG;           // 1 / diag(L)
     int* flag;
     int nP, nMS, nT;
-    size_t lane_bytes;       // lock-step batch: blockIdx.y = lane, every pointer moves by lane * lane_bytes
+    size_t lane_bytes;       // lock-step batch: every pointer moves by lane * lane_bytes (lane from the block index,
+                             // see k_chol_step)
+    int nlanes;
     const int* mask;         // nlanes ints (or null): lanes switched off
     int phase;               // 0: one launch per panel step, every row block factorises L_kk itself (lowest latency,
                              //    one design); 1 / 2: split step for lock-step batches -- launch 1 = the diagonal
@@ -492,13 +494,31 @@ __device__ __forceinline__ T* lane_at(T* p, size_t off) { return reinterpret_cas
 
 __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
-    if (a.mask && !a.mask[blockIdx.y]) return;
-    if (blockIdx.y) {
-        const size_t off = (size_t)blockIdx.y * a.lane_bytes;
+    // 1-D grid, KIND-major over the lanes: the hardware hands out workgroups in index order, so all lanes' panel blocks
+    // (the step's critical path: 64 sequential pivots) come first, then all lanes' inverse rows (64-step substitutions),
+    // then the tile updates -- with the lane as the slow grid dimension the last lane's diagonal block queued behind
+    // ~700 other workgroups of its own launch (and behind the other units' once several share the chip)
+    int lane, b;
+    {
+        const int nl = a.nlanes;
+        int id = blockIdx.x, base = 0;
+        const int seg[3] = {a.nP, a.nMS, a.nT};
+        lane = -1; b = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (lane < 0) {
+                if (id < seg[q] * nl) { lane = id % nl; b = base + id / nl; }
+                else { id -= seg[q] * nl; base += seg[q]; }
+            }
+        }
+        if (lane < 0) { lane = id % nl; b = base + id / nl; }          // RU blocks: whatever the grid has left
+    }
+    if (a.mask && !a.mask[lane]) return;
+    if (lane) {
+        const size_t off = (size_t)lane * a.lane_bytes;
         a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
         a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
     }
-    int b = blockIdx.x;
     if (a.phase == 2) { panel_block<true>(a, b + 1, smem); return; }      // launch 2 of a split step: row blocks only
     if (b < a.nP) { panel_block<false>(a, b, smem); return; }
     b -= a.nP;
@@ -577,7 +597,7 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     a.H = H; a.M = M; a.np = np; a.nblk = nblk;
     a.d0 = W1; a.Dfac = W1 + np; a.dinvG = W1 + (long)(CB + 1) * np; a.flag = flag;
     a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
-    a.lane_bytes = lane_bytes; a.mask = mask;
+    a.lane_bytes = lane_bytes; a.mask = mask; a.nlanes = nlanes;
     hipLaunchKernelGGL(k_chol_init, dim3(std::min(1024, cdiv((long)np * np / 2, 256)), nlanes), dim3(256), 0, st, H, np, W1, M, flag, lane_bytes, mask);
     if (e0) hipEventRecord(e0, st);
     // lock-step batches split every step in two launches (see CholStep::phase): with several designs in flight the
@@ -593,11 +613,11 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
         const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
         a.phase = split ? 1 : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(a.nP + a.nMS + a.nT + nRU, nlanes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_chol_step, dim3((a.nP + a.nMS + a.nT + nRU) * nlanes), dim3(256), 0, st, a);
         ++launches;
         if (split && k < nblk && nrem > 0) {
-            a.phase = 2;
-            hipLaunchKernelGGL(k_chol_step, dim3(4 * nrem, nlanes), dim3(256), 0, st, a);
+            a.phase = 2; a.nP = 4 * nrem; a.nMS = 0; a.nT = 0;
+            hipLaunchKernelGGL(k_chol_step, dim3(4 * nrem * nlanes), dim3(256), 0, st, a);
             ++launches;
         }
     }
