@@ -296,15 +296,17 @@ struct CholStep {
     double* Dfac;            // per panel: 64x64 zero-padded column image of L_kk (see subst16)
     double* dinvG;           // 1 / diag(L)
     int* flag;
-    int nP, nMS, nT;
+    int* sync;               // nblk ints per lane: sync[k] = 1 once the image of L_kk is in Dfac (merged split step)
+    int nP, nMS, nT, nR;
     size_t lane_bytes;       // lock-step batch: every pointer moves by lane * lane_bytes (lane from the block index,
                              // see k_chol_step)
     int nlanes;
     const int* mask;         // nlanes ints (or null): lanes switched off
     int phase;               // 0: one launch per panel step, every row block factorises L_kk itself (lowest latency,
-                             //    one design); 1 / 2: split step for lock-step batches -- launch 1 = the diagonal
-                             //    block (one per lane) with the MS / T / RU blocks, launch 2 = the row blocks, which
-                             //    read the image of L_kk that launch 1 left in Dfac instead of repeating its 64 pivots
+                             //    one design); 1: split step for lock-step batches in ONE launch -- the diagonal block
+                             //    (one per lane) publishes the image of L_kk in Dfac and raises sync[k]; the row
+                             //    blocks, dispatched last, wait for it instead of repeating its 64 pivots;
+                             //    3 / 2: the same in two launches (no flag)
 };
 
 constexpr int YLD = 65;                                  // staging tiles that are read one row per lane
@@ -386,16 +388,27 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     __syncthreads();                                      // also: everybody is done with X and AR
     TRACE(3)
     double* Lz = smem + R0;
-    if (FROM_IMAGE) {                                     // the image of L_kk and 1 / diag(L_kk) as launch 1 left them
-        double2 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const double2*>(a.Dfac + kk * CB + 2 * (tid + 256 * u));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+    if (FROM_IMAGE) {                                     // the image of L_kk and 1 / diag(L_kk) as the diagonal block left them
+        // the diagonal block of this lane runs in the SAME launch (it was dispatched first): wait for its flag.  The
+        // poll is bounded, so a lost flag ends in wrong numbers (caught by the pivot checks and the tests), not a hang.
+        if (a.phase == 1) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.sync + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(4);
+            }
+            __syncthreads();
         }
-        if (tid < CB) dinv[tid] = a.dinvG[kk + tid];
+        // device-scope loads (they bypass what this XCD's L2 may still hold of the previous build's image); the
+        // diagonal block stored the image the same way, so no cache-wide invalidate / write-back is needed
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = __hip_atomic_load(a.Dfac + kk * CB + tid + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            Lz[(e >> 6) * ZLD + (e & 63)] = t[u];
+        }
+        if (tid < CB) dinv[tid] = __hip_atomic_load(a.dinvG + kk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         potf2_slabs(acc, tiles, LB, LS, dsh, dsh + 2 * CB, Lz, dinv, a.pivtol, a.flag, b == 0);
     }
@@ -411,8 +424,13 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     }
     __syncthreads();
     if (!rows) {
-        for (int e = tid; e < CB * CB; e += 256) a.Dfac[kk * CB + e] = Lz[(e >> 6) * ZLD + (e & 63)];
-        if (tid < CB) a.dinvG[kk + tid] = dinv[tid];
+        for (int e = tid; e < CB * CB; e += 256) __hip_atomic_store(a.Dfac + kk * CB + e, Lz[(e >> 6) * ZLD + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < CB) __hip_atomic_store(a.dinvG + kk + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.phase == 1) {                               // merged split step: release the row blocks of this lane
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the device-scope stores above have completed
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     const int rho = tid >> 4, lam = tid & 15;
@@ -498,41 +516,45 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     // (the step's critical path: 64 sequential pivots) come first, then all lanes' inverse rows (64-step substitutions),
     // then the tile updates -- with the lane as the slow grid dimension the last lane's diagonal block queued behind
     // ~700 other workgroups of its own launch (and behind the other units' once several share the chip)
-    int lane, b;
+    // Merged split step (phase 1): the row blocks come LAST -- they spin on the diagonal block's flag after their own
+    // preamble (tile loads, the panel k-1 update of their rows), and must not hold the CU slots the MS / T / RU blocks
+    // could use meanwhile.  nR = row blocks per lane (phase 1), nP = panel blocks dispatched first (1, or 1 + 4 nrem
+    // in the fused single-design step where every row block factorises L_kk itself).
+    int lane, b, kind = 3;                                // kind: 0 P, 1 MS, 2 T, 3 RU, 4 R
     {
         const int nl = a.nlanes;
-        int id = blockIdx.x, base = 0;
-        const int seg[3] = {a.nP, a.nMS, a.nT};
-        lane = -1; b = 0;
+        const int total = int(gridDim.x) / nl;
+        const int nRU = total - a.nP - a.nMS - a.nT - a.nR;
+        int id = blockIdx.x;
+        const int seg[5] = {a.nP, a.nMS, a.nT, nRU, a.nR};
+        lane = 0; b = 0;
+        bool found = false;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (lane < 0) {
-                if (id < seg[q] * nl) { lane = id % nl; b = base + id / nl; }
-                else { id -= seg[q] * nl; base += seg[q]; }
+        for (int q = 0; q < 5; ++q) {
+            if (!found) {
+                if (id < seg[q] * nl) { lane = id % nl; b = id / nl; kind = q; found = true; }
+                else id -= seg[q] * nl;
             }
         }
-        if (lane < 0) { lane = id % nl; b = base + id / nl; }          // RU blocks: whatever the grid has left
     }
     if (a.mask && !a.mask[lane]) return;
     if (lane) {
         const size_t off = (size_t)lane * a.lane_bytes;
         a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
-        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
+        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.sync = lane_at(a.sync, off);
     }
-    if (a.phase == 2) { panel_block<true>(a, b + 1, smem); return; }      // launch 2 of a split step: row blocks only
-    if (b < a.nP) { panel_block<false>(a, b, smem); return; }
-    b -= a.nP;
-    if (b < a.nMS) { minv_block(a, b, smem); return; }
-    b -= a.nMS;
+    if (kind == 4) { panel_block<true>(a, b + 1, smem); return; }         // row blocks of a split step
+    if (kind == 0) { panel_block<false>(a, b, smem); return; }
+    if (kind == 1) { minv_block(a, b, smem); return; }
     const int k = a.k, np = a.np;
-    if (b < a.nT) {                                       // trailing update with panel k-1, columns > k
+    if (kind == 2) {                                      // trailing update with panel k-1, columns > k
         int ti, tj;
         tile_decode(b, ti, tj);
         const long i0 = (long)(k + 1 + ti) * CB, j0 = (long)(k + 1 + tj) * CB, km = (long)(k - 1) * CB;
         tile_update<true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
         return;
     }
-    b -= a.nT;                                            // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2)
+    // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2)
     const int i = k + b / (k - 1), j = b % (k - 1);
     const long mm = (long)(k - 2) * CB;
     tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np);
@@ -541,11 +563,12 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
 // M = I (the inverse factor starts as the identity), d0 = diag(H), pivot-replacement counter = 0; one launch for
 // all lanes (a 2-D hipMemset of the lanes' M costs 0.2 ms at 8 x 8 MB, this streams at HBM rate)
 __global__ __launch_bounds__(256) void k_chol_init(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M,
-                                                   int* __restrict__ flag, size_t lane_bytes, const int* __restrict__ mask) {
+                                                   int* __restrict__ flag, int* __restrict__ sync, size_t lane_bytes, const int* __restrict__ mask) {
     if (mask && !mask[blockIdx.y]) return;
     const size_t off = (size_t)blockIdx.y * lane_bytes;
-    H = lane_at(H, off); d0 = lane_at(d0, off); M = lane_at(M, off); flag = lane_at(flag, off);
+    H = lane_at(H, off); d0 = lane_at(d0, off); M = lane_at(M, off); flag = lane_at(flag, off); sync = lane_at(sync, off);
     if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < np / CB + 1) sync[threadIdx.x] = 0;
     const long n2 = (long)np * np / 2;                     // double2 elements
     double2* M2 = reinterpret_cast<double2*>(M);
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
@@ -598,26 +621,30 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     a.d0 = W1; a.Dfac = W1 + np; a.dinvG = W1 + (long)(CB + 1) * np; a.flag = flag;
     a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
     a.lane_bytes = lane_bytes; a.mask = mask; a.nlanes = nlanes;
-    hipLaunchKernelGGL(k_chol_init, dim3(std::min(1024, cdiv((long)np * np / 2, 256)), nlanes), dim3(256), 0, st, H, np, W1, M, flag, lane_bytes, mask);
+    a.sync = reinterpret_cast<int*>(W1 + (long)(CB + 2) * np);          // behind 1 / diag(L): nblk + 1 ints
+    hipLaunchKernelGGL(k_chol_init, dim3(std::min(1024, cdiv((long)np * np / 2, 256)), nlanes), dim3(256), 0, st, H, np, W1, M, flag, a.sync, lane_bytes, mask);
     if (e0) hipEventRecord(e0, st);
-    // lock-step batches split every step in two launches (see CholStep::phase): with several designs in flight the
-    // chip is no longer empty, and the 4 * nrem row blocks of a step each repeating the 64-pivot factorisation of
-    // L_kk is what fills it
-    bool split = nlanes >= 3;
-    if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev) != 0;
+    // Lock-step batches split every step (see CholStep::phase): with several designs in flight the chip is no longer
+    // empty, and the 4 * nrem row blocks of a step each repeating the 64-pivot factorisation of L_kk is what fills it.
+    // The split costs no launch: the row blocks ride in the same launch, dispatched last, and wait for their lane's
+    // diagonal block on a flag in global memory (MBFIR_CHOL_SPLIT=2: the older two-launch form).
+    int split = nlanes >= 3 ? 1 : 0;
+    if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
     for (int k = 0; k <= nblk; ++k) {
         const int nrem = nblk - k - 1;
         a.k = k;
-        a.nP = k < nblk ? (split ? 1 : 1 + 4 * nrem) : 0;
         a.nMS = k >= 1 ? 4 * k : 0;
         a.nT = (k >= 1 && k < nblk) ? nrem * (nrem + 1) / 2 : 0;
         const int nRU = (k >= 2 && k < nblk) ? (nblk - k) * (k - 1) : 0;
-        a.phase = split ? 1 : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3((a.nP + a.nMS + a.nT + nRU) * nlanes), dim3(256), 0, st, a);
+        const int rows = k < nblk ? 4 * nrem : 0;
+        a.nP = k < nblk ? (split ? 1 : 1 + rows) : 0;
+        a.nR = split == 1 ? rows : 0;
+        a.phase = split == 1 ? 1 : (split ? 3 : 0);
+        hipLaunchKernelGGL(k_chol_step, dim3((a.nP + a.nMS + a.nT + nRU + a.nR) * nlanes), dim3(256), 0, st, a);
         ++launches;
-        if (split && k < nblk && nrem > 0) {
-            a.phase = 2; a.nP = 4 * nrem; a.nMS = 0; a.nT = 0;
-            hipLaunchKernelGGL(k_chol_step, dim3(4 * nrem * nlanes), dim3(256), 0, st, a);
+        if (split == 2 && rows > 0) {
+            a.phase = 2; a.nP = 0; a.nMS = 0; a.nT = 0; a.nR = rows;
+            hipLaunchKernelGGL(k_chol_step, dim3(rows * nlanes), dim3(256), 0, st, a);
             ++launches;
         }
     }
