@@ -334,6 +334,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
     // ---- host assembly, in parallel --------------------------------------------------------------
     std::vector<TrigProgram> progs(njobs);
     std::vector<int> arc(njobs, 0);
+    std::vector<std::vector<long>> keys(njobs);
     {
         std::atomic<int> next(0);
         auto asm_work = [&]() {
@@ -344,9 +345,16 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 jobs[q].err[0] = 0;
                 arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
                 if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
+                else if (!(sharded || lanes_cap == 1)) {
+                    // the shape key (CSR maps, lattice analysis: a sort of the grid) here, not in the serial grouping loop:
+                    // 64 headline designs cost 40 ms there with the GPU idle; the structures stay with the program
+                    const SolveOpts so = to_opts(opts, progs[q].which);
+                    keys[q] = Solver::shape_key(progs[q], so);
+                    keys[q].push_back(Solver::max_lanes(progs[q], so));
+                }
             }
         };
-        const int nth = std::max(1, std::min(njobs, std::min(8, int(std::thread::hardware_concurrency()))));
+        const int nth = std::max(1, std::min(njobs, std::min(16, int(std::thread::hardware_concurrency()))));
         std::vector<std::thread> th;
         for (int c = 1; c < nth; ++c) th.emplace_back(asm_work);
         asm_work();
@@ -360,10 +368,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
         std::map<std::vector<long>, std::vector<int>> groups;
         for (int q = 0; q < njobs; ++q) {
             if (arc[q] != 0) { units.push_back({q}); continue; }             // the single-design path reports the assembly error
-            const SolveOpts so = to_opts(opts, progs[q].which);
-            std::vector<long> key = Solver::shape_key(progs[q], so);
-            key.push_back(Solver::max_lanes(progs[q], so));
-            groups[key].push_back(q);
+            groups[keys[q]].push_back(q);
         }
         for (auto& g : groups) {
             const int cap = int(g.first.back()), G = int(g.second.size());

@@ -11,6 +11,7 @@
 // r2 = P r1 is its quadrature partner, a signed permutation of r1
 // (r2[j] = psign[j] * r1[pcol[j]]), so only A1 is ever read.
 #pragma once
+#include <memory>
 #include <vector>
 #include <string>
 
@@ -41,6 +42,9 @@ struct TrigProgram {
     int nhalf = 0;                   // linprog
     bool real_filter = false, odd_filter = false;
     int N() const { return Nt + Ne; }
+    // host-side structures the solver derives from the arrays above (CSR maps, lattice analysis): computed once by
+    // Solver::shape_key -- which mbfir_solve_batch calls from its parallel assembly threads -- and reused by the solve
+    mutable std::shared_ptr<void> prep;
     void add_row(int fr, int cl, double al, double be, double e0, double e1, double e2, double hh) {
         freq.push_back(fr); col.push_back(cl); alpha.push_back(al); beta.push_back(be);
         ey.push_back(e0); ey.push_back(e1); ey.push_back(e2); h.push_back(hh);

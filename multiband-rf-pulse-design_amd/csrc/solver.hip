@@ -1869,17 +1869,60 @@ struct Solver::Impl {
         ar.reset();
     }
     // one array per lane, all of the same length (the lanes share one arena layout); get(b) returns lane b's vector
+    // The arrays are gathered in a pinned host image of the lanes' program region and go to the device in ONE copy per
+    // lane (flush_uploads): ~35 arrays x 8 lanes as separate pageable copies cost ~10 ms per unit with the stream idle.
+    char* stage = nullptr;       // pinned
+    size_t stage_cap = 0, stage_lo = 0, stage_hi = 0;      // byte range of the arena (lane 0) the staged arrays cover
     template <class T, class F>
     T* upload(F get) {
         const size_t n0 = get(0).size();
         T* p = ar.get<T>(std::max<size_t>(n0, 1));
-        if (!ar.measuring)
+        if (!ar.measuring) {
+            const size_t off = size_t(reinterpret_cast<char*>(p) - ar.base), bytes = n0 * sizeof(T);
+            if (stage_hi == stage_lo) stage_lo = stage_hi = off;
+            if (off < stage_hi) throw HipError("upload: arrays out of order");
+            const size_t need = (off + bytes - stage_lo) * nlanes;
+            if (need > stage_cap) {                           // grow, keeping what is staged
+                char* nb = nullptr;
+                const size_t ncap = std::max(need * 2, size_t(1) << 22);
+                MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&nb), ncap));
+                if (stage) { std::memcpy(nb, stage, stage_cap); hipHostFree(stage); }
+                stage = nb; stage_cap = ncap;
+            }
+            stage_hi = off + bytes;
             for (int b = 0; b < nlanes; ++b) {
                 const std::vector<T>& v = get(b);
                 if (v.size() != n0) throw HipError("lock-step batch: lanes differ in shape");
-                if (n0) MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(p) + (size_t)b * lane_bytes, v.data(), n0 * sizeof(T), hipMemcpyHostToDevice, st));
+                if (n0) std::memcpy(stage + (off - stage_lo) * nlanes + bytes * b, v.data(), bytes);
             }
+            pend.push_back({off, bytes});
+        }
         return p;
+    }
+    struct Pend { size_t off, bytes; };
+    std::vector<Pend> pend;
+    void flush_uploads() {
+        // staged as [array][lane]; the device wants [lane][array]: one copy per (array, lane) would be the old count, so
+        // re-pack per lane in a second pinned stretch and send each lane's region in one piece
+        if (pend.empty()) return;
+        const size_t region = stage_hi - stage_lo, packed = region * nlanes;
+        const size_t base2 = (stage_hi - stage_lo) * nlanes;
+        if (base2 + packed > stage_cap) {
+            char* nb = nullptr;
+            const size_t ncap = (base2 + packed) * 2;
+            MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&nb), ncap));
+            std::memcpy(nb, stage, base2); hipHostFree(stage);
+            stage = nb; stage_cap = ncap;
+        }
+        char* out = stage + base2;
+        std::memset(out, 0, packed);
+        for (const Pend& q : pend)
+            for (int b = 0; b < nlanes; ++b)
+                std::memcpy(out + region * b + (q.off - stage_lo), stage + (q.off - stage_lo) * nlanes + q.bytes * b, q.bytes);
+        for (int b = 0; b < nlanes; ++b)
+            MBFIR_HIP(hipMemcpyAsync(ar.base + stage_lo + (size_t)b * lane_bytes, out + region * b, region, hipMemcpyHostToDevice, st));
+        pend.clear();
+        stage_lo = stage_hi = 0;
     }
     // the same stretch of every lane
     void memset_lanes(void* p, size_t bytes) {
@@ -2216,6 +2259,7 @@ Solver::~Solver() {
     comm_destroy();
     if (impl->ar.base) hipFree(impl->ar.base);
     if (impl->hostSc) hipHostFree(impl->hostSc);
+    if (impl->stage) hipHostFree(impl->stage);
     if (impl->hostFlag) hipHostFree(impl->hostFlag);
     if (impl->hostMask) hipHostFree(impl->hostMask);
     if (impl->maskT) hipFree(impl->maskT);
@@ -2307,15 +2351,35 @@ static void index_structures(const TrigProgram& Q, LaneHost& L) {
 
 // Two programs can share a lock-step batch when every array the device holds for them has the same length and
 // the scalar structure the kernels are launched with is the same: dimensions, lattice extent and chunk count.
-std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
+// index structures + lattice analysis of one program, kept with the program (TrigProgram::prep) so that the batch
+// front end can compute them in its parallel assembly threads and the solve does not repeat them
+struct LanePrep {
+    bool fold = true, dense = false;
+    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows;
+    LatticeInfo Lt;
+};
+static std::shared_ptr<LanePrep> lane_prep(const TrigProgram& Q, const SolveOpts& o) {
+    const bool fold = o.ddkkt_theta <= 0, dense = o.dense_trig != 0;
+    if (Q.prep) {
+        auto have = std::static_pointer_cast<LanePrep>(Q.prep);
+        if (have->fold == fold && have->dense == dense) return have;
+    }
+    auto pr = std::make_shared<LanePrep>();
+    pr->fold = fold; pr->dense = dense;
     LaneHost L;
     index_structures(Q, L);
-    LatticeInfo Lt;
-    if (!o.dense_trig) Lt = analyse_lattice(Q, o.ddkkt_theta <= 0);
+    pr->f_ptr.swap(L.f_ptr); pr->f_rows.swap(L.f_rows); pr->c_ptr.swap(L.c_ptr); pr->c_rows.swap(L.c_rows); pr->yrows.swap(L.yrows);
+    if (!dense) pr->Lt = analyse_lattice(Q, fold);
+    Q.prep = pr;
+    return pr;
+}
+std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
+    const std::shared_ptr<LanePrep> pr = lane_prep(Q, o);
+    const LatticeInfo& Lt = pr->Lt;
     long tbits = 0;
     std::memcpy(&tbits, &Lt.tmin, sizeof(double));
     return {long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.Mf), long(Q.R), long(Q.l), long(Q.nq3), long(Q.big),
-            long(Q.quad), long(L.f_rows.size()), long(L.c_rows.size()), long(L.yrows.size()), long(Lt.ok), long(Lt.D1),
+            long(Q.quad), long(pr->f_rows.size()), long(pr->c_rows.size()), long(pr->yrows.size()), long(Lt.ok), long(Lt.D1),
             long(Lt.ch_start.size()), long(Lt.wf.size()), tbits};
 }
 // how many lanes of this shape one context runs in lock step (memory and occupancy)
@@ -2363,10 +2427,13 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         for (double v : Qfull.c) nc += v * v;
         L.nrm_h = std::max(1.0, std::sqrt(nh)); L.nrm_c = std::max(1.0, std::sqrt(nc));
         L.degree = double(Qfull.l + Qfull.nq3 + (Qfull.big ? 1 : 0));
-        index_structures(*L.Q, L);
         // (the extended-precision KKT solve forms its strong rows from the exact w_i: its programs keep every frequency
         // on its own so that the lattice operator and those rows see the same grid to the old 2 ulp)
-        if (!o.dense_trig) L.Lt = analyse_lattice(*L.Q, o.ddkkt_theta <= 0);
+        {
+            const std::shared_ptr<LanePrep> pr = lane_prep(*L.Q, o);
+            L.f_ptr = pr->f_ptr; L.f_rows = pr->f_rows; L.c_ptr = pr->c_ptr; L.c_rows = pr->c_rows; L.yrows = pr->yrows;
+            L.Lt = pr->Lt;
+        }
         L.nsweep = o.refine;
     }
     const TrigProgram& Q = *LH[0].Q;
@@ -2450,6 +2517,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.fold_pos = UPL(int, Lt.fold_pos); P.fold_neg = UPL(int, Lt.fold_neg); P.wf = UPL(double, Lt.wf);
 #undef UPQ
 #undef UPL
+    if (!ar.measuring) S.flush_uploads();
     // ---- work buffers ----------------------------------------------------------------------
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
@@ -2499,6 +2567,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.lane_bytes = (ar.off + 4095) & ~size_t(4095);
     ar.measuring = false;
     S.ensure_arena(S.lane_bytes * nlanes + 4096);
+    S.pend.clear(); S.stage_lo = S.stage_hi = 0;
     layout();
     P.lane_bytes = S.lane_bytes;
     S.memset_lanes(zero_from, zero_bytes);
