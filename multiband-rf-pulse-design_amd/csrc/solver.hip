@@ -92,6 +92,7 @@ enum {
     S_TAU = 0, S_KAPPA, S_MU, S_SIGMA, S_ALPHA, S_ALPHA_A, S_DTAU, S_DKAP, S_DTAU_A, S_DKAP_A,
     S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
     S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
+    S_CHOLFIX /* pivots the last factorisation replaced (copied from the counter so that one D2H copy serves the host) */,
     S_RNA = 40 /* 9 residual norms, batch solve */, S_RNB = 49 /* 9 residual norms, combined solve */,
     S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */, S_COUNT = 64
 };
@@ -892,8 +893,8 @@ __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __res
 __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict__ Sc, const double* __restrict__ GTz,
                                                      const double* __restrict__ x, double* __restrict__ rx,
                                                      double* __restrict__ bx2, const double* __restrict__ partR, int nbR,
-                                                     double* __restrict__ RB, int phase) {
-    LANES(P, Sc, GTz, x, rx, bx2, partR, RB);
+                                                     double* __restrict__ RB, int phase, const int* __restrict__ flag) {
+    LANES(P, Sc, GTz, x, rx, bx2, partR, RB, flag);
     __shared__ double sh[17];
     double rz2, sz, hz, gxs2;
     if (phase != 1) {
@@ -934,6 +935,7 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
         Sc[S_RELGAP] = den > 0 ? gap / den : 1e300;
         Sc[S_PINF] = hz < 0 ? sqrt(gtz2) / (-hz) : 1e300;
         Sc[S_DINF] = cx < 0 ? sqrt(gxs2) / (-cx) : 1e300;
+        Sc[S_CHOLFIX] = flag ? double(flag[0]) : 0.0;
     }
 }
 
@@ -2641,19 +2643,18 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
         }
         if (sharded) {
-            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0);
+            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0, (const int*)nullptr);
             S.allreduce(S.RB, 4, 0);
         }
-        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2);
+        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2, (const int*)S.flag);
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
-        MBFIR_HIP(hipMemcpy2DAsync(S.hostFlag, sizeof(int) * 4, S.flag, S.lane_bytes, sizeof(int), nlanes, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
         bool any_live = false, any_best = false;
         for (int b = 0; b < nlanes; ++b) {
             LaneHost& L = LH[b];
             if (!L.live) continue;
             const double* hs = S.hostSc + (size_t)b * S_COUNT;
-            const int chol_fixes = S.hostFlag[4 * b];
+            const int chol_fixes = int(hs[S_CHOLFIX]);
             SolveInfo& info = L.info;
             if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
                 // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
