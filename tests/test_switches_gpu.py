@@ -1,0 +1,89 @@
+"""Implementation switches of the device solver must not change results: every optimisation of this round has an
+environment switch (read at solve time), and the switched-off form is the reference for the switched-on one.
+
+  MBFIR_FOLD=0         every frequency on its own instead of the +w / -w pairs of the folded lattice kernels
+  MBFIR_SHARE_SEEDS=0  every lane builds and reads its own seed tables
+  MBFIR_CHOL_SPLIT=2   the split Cholesky step as two launches (no device flag); =0 the fused single-design step
+  MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import mbfir
+
+pytestmark = pytest.mark.gpu
+
+F6 = [-0.6, -0.35, -0.1, 0.15, 0.45, 0.8]
+A6 = [0, 0, 0.7, 0.7, 0, 0]
+D3 = [0.01, 0.02, 0.01]
+
+
+class env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def relinf(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+CASES = [
+    ("fir_ap_cvx", (33, F6, A6, D3, 0.1, 1e-2), {}),                                   # symmetric grid: every point has a partner
+    ("fir_ap_cvx", (40, F6, A6, D3, 0.1, 1e-2), dict(grid_m=1201)),                    # odd grid: w = 0 pairs with itself
+    ("fir_linprog", (31, [0, 0.2, 0.35, 1], [1, 1, 0, 0], [0.02, 0.02]), {}),         # one-sided grid: no partners at all
+    ("fir_qprog_phs", (23, [-1, -0.6, -0.2, 0.2], [1, 1, 0, 0], [0.05 * np.exp(0.3j), 0.02]), {}),
+]
+
+
+@pytest.mark.parametrize("which,args,okw", CASES)
+def test_folded_lattice_kernels_equal_the_unfolded_ones(which, args, okw):
+    fn = getattr(mbfir, which)
+    opts = mbfir.make_opts(**okw) if okw else None
+    with env(MBFIR_FOLD=0):
+        h0, s0, i0 = fn(*args, info=True, opts=opts)
+    with env(MBFIR_FOLD=1):
+        h1, s1, i1 = fn(*args, info=True, opts=opts)
+    assert s0 == s1 == "Solved" and i0["lattice"] == i1["lattice"] == 1
+    assert abs(i0["iters"] - i1["iters"]) <= 1
+    assert abs(i0["pcost"] - i1["pcost"]) <= 1e-9 * max(1.0, abs(i0["pcost"]))
+    assert relinf(h1, h0) <= 1e-7
+
+
+def _batch(**envkw):
+    jobs = [("fir_ap_cvx", (64, F6, A6, D3, 0.1, 1e-2 * (1 + 0.5 * k))) for k in range(6)]
+    ctx = mbfir.Context(0)
+    try:
+        with env(**envkw):
+            res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=6))
+    finally:
+        ctx.close()
+    assert all(r[1] == "Solved" for r in res) and res[0][2]["lanes"] == 6
+    return res
+
+
+def test_lock_step_switches_are_bit_identical():
+    base = _batch()
+    for kw in (dict(MBFIR_SHARE_SEEDS=0), dict(MBFIR_CHOL_SPLIT=2), dict(MBFIR_CHOL_SPLIT=0)):
+        other = _batch(**kw)
+        for (h0, _, i0), (h1, _, i1) in zip(base, other):
+            assert np.array_equal(h0, h1) and i0["pcost"] == i1["pcost"] and i0["iters"] == i1["iters"], kw
+
+
+def test_single_chunk_blocks_agree_to_rounding():
+    base = _batch()
+    other = _batch(MBFIR_CGRP=1)
+    for (h0, _, i0), (h1, _, i1) in zip(base, other):
+        assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
