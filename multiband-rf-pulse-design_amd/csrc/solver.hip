@@ -104,7 +104,7 @@ constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding
 constexpr int MAX_SWEEPS = 8;
 constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
 constexpr int WALL_ITERS = 3;
-constexpr double REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
+constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement, oracle/conic_ipm.py */, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
 
 // ------------------------------------------------------------------------------------------------
 // device-side problem description
@@ -2325,7 +2325,7 @@ struct LaneHost {
     // IPM state
     int status = ST_MAXIT, nsweep = 0, wall = 0, iters = 0;
     bool live = true, have_best = false;
-    double best_merit = 1e300;
+    double best_merit = 1e300, rx_prev = 0;
     SolveInfo info, best_info;
 };
 
@@ -2659,7 +2659,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
                 // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
                 // measured before each sweep of the two KKT solves of the previous iteration
-                const double tol = REFTOL * hs[S_NRMC];
+                const double tol = std::max(REFTOL * hs[S_NRMC], REFETA * L.rx_prev);   // ||rx|| of the iteration the norms belong to
                 int need = 0;
                 bool unconverged = false;
                 for (int slot : {int(S_RNA), int(S_RNB)}) {
@@ -2671,6 +2671,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 }
                 L.nsweep = unconverged ? std::min(MAX_SWEEPS, L.nsweep + 1) : need;
             }
+            L.rx_prev = hs[S_DRES] * hs[S_TAU] * hs[S_NRMC];
             info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
             info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
             if (o.verbose)

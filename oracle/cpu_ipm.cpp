@@ -21,7 +21,7 @@
 namespace {
 
 typedef std::vector<double> vec;
-const double STEP = 0.99, SIGMA_MAX = 0.25, REFTOL = 1e-11, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
+const double STEP = 0.99, SIGMA_MAX = 0.25, REFTOL = 1e-11, REFETA = 1e-1, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
 const int MAX_SWEEPS = 8, WALL_ITERS = 3, NB = 64;
 enum { ST_OPTIMAL = 0, ST_PINF = 1, ST_DINF = 2, ST_MAXIT = 3, ST_NUMERICAL = 4, ST_INACC = 5 };
 
@@ -510,7 +510,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         kkt_solve(bxc.data(), bzc.data(), x2.data(), z2.data(), g2.data());
         direction(sigma, dk_c, x2.data(), z2.data(), g2.data(), ds.data(), dz.data(), dss.data(), wdz.data());
         const double alpha = step_of(dss.data(), wdz.data(), STEP);
-        nsweep = next_sweeps(REFTOL * nrm_c);
+        nsweep = next_sweeps(std::max(REFTOL * nrm_c, REFETA * nrm2(rx.data(), N)));   // forcing term, see conic_ipm.py
         for (int j = 0; j < N; ++j) x[j] += alpha * (x2[j] + dtau * x1[j]);
         for (int i = 0; i < R; ++i) { s[i] += alpha * ds[i]; z[i] += alpha * dz[i]; }
         tau += alpha * dtau; kappa += alpha * dkap;

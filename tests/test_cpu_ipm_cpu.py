@@ -12,7 +12,7 @@ D3 = [0.01, 0.02, 0.01]
 CASES = {
     "ap_feasible": lambda: assemble.assemble_fir_ap_cvx(33, F6, A6, D3, 0.1, 1e-2, 0),
     "ap_infeasible": lambda: assemble.assemble_fir_ap_cvx(8, F6, A6, D3, 0.1, 1e-2, 0),
-    "ap_odd_columns": lambda: assemble.assemble_fir_ap_cvx(21, F6, A6, [0.03, 0.05, 0.03], 0.0, 1e-1, 0),
+    "ap_odd_columns": lambda: assemble.assemble_fir_ap_cvx(21, F6, A6, [0.03, 0.05, 0.03], 0.05, 1e-1, 0),
     "qp_feasible": lambda: assemble.assemble_fir_qp_cvx(32, [0, 0.2, 0.4, 1], [1, 1, 0, 0], [0.1, 0.1], 3.0, 1.0, 0),
     "qp_infeasible": lambda: assemble.assemble_fir_qp_cvx(32, [0, 0.2, 0.4, 1], [1, 1, 0, 0], [0.1, 0.1], 120.0, 0.0, 0),
     "linprog": lambda: assemble.assemble_fir_linprog(41, [0, 0.2, 0.35, 1], [1, 1, 0, 0], [0.02, 0.02], 0),
