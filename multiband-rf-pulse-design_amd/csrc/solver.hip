@@ -1390,12 +1390,12 @@ __device__ __forceinline__ void load_m3(const double* __restrict__ w3, const dou
     if (m3c) { for (int q = 0; q < 6; ++q) m[q] = m3c[6L * c + q]; }
     else soc3_inv2(load_w3(w3, c), m);
 }
-__global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                              double* __restrict__ Dw, double* __restrict__ BB, const double* __restrict__ m3c) {
-    LANES(P, dl, w3, Dw, BB, m3c);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.Mf) return;
+// per-frequency blocks of the normal matrix: v[0] = d11, (quad: v[1] = d12, v[2] = d22), then the border values
+// b1[e] (quad: then b2[e]) -- the order of the Dw | BB arrays
+__device__ __forceinline__ void freq_block_at(const DProg& P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                              const double* __restrict__ m3c, int i, double (&v)[9]) {
     double d11 = 0, d12 = 0, d22 = 0, b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0};
+    if (i >= 0)
     for (int q = P.f_ptr[i]; q < P.f_ptr[i + 1]; ++q) {
         int r = P.f_rows[q];
         if (r < P.l) {
@@ -1423,12 +1423,36 @@ __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const doub
             }
         }
     }
-    Dw[i] = d11;
-    if (P.quad) { Dw[P.Mpad + i] = d12; Dw[2L * P.Mpad + i] = d22; }
-    for (int e = 0; e < P.Ne; ++e) {
-        BB[(long)e * P.Mpad + i] = b1[e];
-        if (P.quad) BB[(long)(P.Ne + e) * P.Mpad + i] = b2[e];
-    }
+    int o = 0;
+    v[o++] = d11;
+    if (P.quad) { v[o++] = d12; v[o++] = d22; }
+    for (int e = 0; e < P.Ne; ++e) v[o++] = b1[e];
+    if (P.quad) for (int e = 0; e < P.Ne; ++e) v[o++] = b2[e];
+}
+__global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                              double* __restrict__ Dw, double* __restrict__ BB, const double* __restrict__ m3c) {
+    LANES(P, dl, w3, Dw, BB, m3c);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.Mf) return;
+    double v[9];
+    freq_block_at(P, dl, w3, m3c, i, v);
+    int o = 0;
+    Dw[i] = v[o++];
+    if (P.quad) { Dw[P.Mpad + i] = v[o++]; Dw[2L * P.Mpad + i] = v[o++]; }
+    for (int e = 0; e < P.Ne; ++e) BB[(long)e * P.Mpad + i] = v[o++];
+    if (P.quad) for (int e = 0; e < P.Ne; ++e) BB[(long)(P.Ne + e) * P.Mpad + i] = v[o++];
+}
+// the same for the lattice path, straight into the folded operands of the moment kernel: one thread per folded
+// frequency, (pe, po) of the nv = nwv + nvb vectors (k_freq_blocks + k_freq_fold in one launch)
+__global__ __launch_bounds__(256) void k_freq_blocks_fold(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                                          const double* __restrict__ m3c, int nv, double2* __restrict__ out) {
+    LANES(P, dl, w3, m3c, out);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= P.nfold) return;
+    double a[9], b[9];
+    freq_block_at(P, dl, w3, m3c, P.fold_pos[k], a);
+    freq_block_at(P, dl, w3, m3c, P.fold_neg[k], b);
+    for (int v = 0; v < nv; ++v) out[(long)v * P.Mpad + k] = make_double2(a[v] + b[v], a[v] - b[v]);
 }
 
 // H (np x np) from the Gram matrices and the border products.  TT[v][j] = (A1' BB[v])[j].
@@ -1509,9 +1533,13 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
     H[(long)j * P.np + k] = v;
 }
 // identity rows: thread j owns row j of H (and the mirrored border entries)
-__global__ void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                             double* __restrict__ H, const double* __restrict__ m3c) {
+__device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c);
+// yy_too: one more block at the end of the grid adds the y-y block (k_H_yy's work; 256 threads)
+__global__ __launch_bounds__(256) void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                                    double* __restrict__ H, const double* __restrict__ m3c, int yy_too) {
     LANES(P, dl, w3, H, m3c);
+    if (yy_too && blockIdx.x == gridDim.x - 1) { h_yy_block(P, dl, w3, H, (long)P.np, (long)P.Nt, m3c); return; }
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
     const long np = P.np;
@@ -1545,9 +1573,8 @@ __global__ void k_H_identity(DProg P, const double* __restrict__ dl, const doubl
 }
 // y-y block: sum over rows with a non-zero ey (LP rows and Q3 cones); one block
 // out[(base + e) * ld + base + f] += ... : (H, np, Nt), or a 3 x 3 scratch (ld 3, base 0) that the lead-factor mode all-reduces
-__global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                              double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
-    LANES(P, dl, w3, H, m3c);
+__device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
     __shared__ double sh[17];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
@@ -1571,6 +1598,11 @@ __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict_
             double t = block_sum(acc[3 * e + f], sh);
             if (threadIdx.x == 0) H[(base + e) * ld + base + f] += t;
         }
+}
+__global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
+                                              double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
+    LANES(P, dl, w3, H, m3c);
+    h_yy_block(P, dl, w3, H, ld, base, m3c);
 }
 __global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
     LANES(P, yy, H);
@@ -1975,12 +2007,13 @@ struct Solver::Impl {
     }
     // border products of the H assembly: partial = A1' * BB (BB is a per-frequency array)
     // lattice mode: moments of per-frequency arrays on the progressions (t0a, na), (t0b, nb)
+    // pp == nullptr: the folded operands are in PPf already (k_freq_blocks_fold)
     void moments_array(int nv, const double* pp, const double4* seeds, int na, int nb, double* out) {
         dim3 g(cdiv(na + nb, MPTS), cdiv(P.nchunk, P.cgrp)), b(256), gf(cdiv(P.nfold, 256));
         switch (nv) {
 #define MOM_CASE(NVX)                                                                                                          \
             case NVX:                                                                                                          \
-                hipLaunchKernelGGL((k_freq_fold<NVX, false>), lane_grid(gf, nlanes), b, 0, st, P, pp, PPf);                    \
+                if (pp) hipLaunchKernelGGL((k_freq_fold<NVX, false>), lane_grid(gf, nlanes), b, 0, st, P, pp, PPf);            \
                 hipLaunchKernelGGL((k_trig_moments<NVX>), lane_grid(g, nlanes), b, 0, st, P, PPf, seeds, na, nb, partial);     \
                 break;
             MOM_CASE(1) MOM_CASE(2) MOM_CASE(3) MOM_CASE(4) MOM_CASE(6)
@@ -2150,16 +2183,18 @@ struct Solver::Impl {
     void build_H(int ddk = 0) {
         const double* dlw = ddk > 0 ? D.dlc : dl;
         const double* m3c = ddk > 0 ? D.m3c : nullptr;
-        hipLaunchKernelGGL(k_freq_blocks, lane_grid(dim3(cdiv(P.Mf, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
+        const int nwv = P.quad ? 3 : 1, nvb = P.quad ? 2 * P.Ne : P.Ne;
+        const bool one_pass = P.trig && P.Ne > 0 && P.tmin == 0.0 && nwv + nvb <= 4;
+        if (!one_pass) hipLaunchKernelGGL(k_freq_blocks, lane_grid(dim3(cdiv(P.Mf, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
         hipEvent_t g0 = timing ? next_event() : nullptr, g1 = timing ? next_event() : nullptr;
         if (P.trig) {
             if (g0) hipEventRecord(g0, st);
-            const int nwv = P.quad ? 3 : 1, nvb = P.quad ? 2 * P.Ne : P.Ne;
             const double* momb = MomB;
-            if (P.Ne > 0 && P.tmin == 0.0 && nwv + nvb <= 4) {
-                // delays start at 0: the border moments sit on the difference progression, one launch does both
-                // (BB follows the weight vectors in memory)
-                moments_array(nwv + nvb, Dw, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
+            if (one_pass) {
+                // delays start at 0: the border moments sit on the difference progression, one moment launch does both,
+                // and the per-frequency blocks go straight into its folded operands (no Dw / BB round trip)
+                hipLaunchKernelGGL(k_freq_blocks_fold, lane_grid(dim3(cdiv(P.nfold, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, m3c, nwv + nvb, PPf);
+                moments_array(nwv + nvb, nullptr, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
                 momb = Mom + 2L * nwv * P.LDM;
             } else {
                 moments_array(nwv, Dw, P.seed_h, P.D1, 2 * P.D1 - 1, Mom);
@@ -2194,9 +2229,8 @@ struct Solver::Impl {
             if (mine) hipLaunchKernelGGL(k_H_yy_add, lane_grid(dim3(1), nlanes), dim3(16), 0, st, P, RB, H);
         }
         if (mine) {
-            hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c);
-            if (!lead_factor() && P.Ne > 0 && P.nyrows > 0)
-                hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, H, (long)P.np, (long)P.Nt, m3c);
+            const int yy_too = (!lead_factor() && P.Ne > 0 && P.nyrows > 0) ? 1 : 0;
+            hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256) + yy_too), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c, yy_too);
             if (P.big) {
                 memset_lanes(qv, sizeof(double) * 3 * P.LDV);
                 if (ddk > 0) {
