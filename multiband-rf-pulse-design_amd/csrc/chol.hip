@@ -86,6 +86,11 @@ __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __res
 // So every tile sees its updates in order, each launch only reads what earlier launches wrote, and
 // the dependent chain per panel is  tile product -> potf2 -> substitution  (one launch) instead of
 // two launches with two substitutions.
+// Lock-step batches (>= 3 designs per launch) run the SPLIT form of the step: only block 0 of a lane factorises
+// L_kk; the row blocks, dispatched last in the same launch, do their own preamble and then wait for the lane's
+// diagonal block on a flag in global memory (CholStep::phase, panel_block<FROM_IMAGE>).  The only cross-workgroup
+// dependency inside a launch is that one: row blocks on the diagonal block of their own lane, which has a lower
+// workgroup index and is therefore dispatched first -- no workgroup ever waits for one that has not started.
 // M computed this way has the accuracy of a substitution-based inverse (measured: solve residual
 // 3e-5 at cond(H)=3e9, same as LAPACK trtri; multiplying explicit 64x64 inverses gives 2e-3).
 // Pivot rule: a pivot not above pivtol * H_jj is rounding noise and is replaced by H_jj itself; by
