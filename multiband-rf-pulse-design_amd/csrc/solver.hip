@@ -5,14 +5,15 @@
 // rounding): homogeneous self-dual embedding, Nesterov-Todd scaling, Mehrotra predictor-corrector
 // (step fraction 0.99, sigma = min((1-alpha_aff)^3, 0.25)), KKT systems reduced to the normal equations
 //   (G' W^-2 G) dx = bx + G' W^-2 bz ,  dz = W^-2 (G dx - bz)
-// with dz kept explicit and corrected incrementally (`refine` sweeps) so the dual equation
-// G'dz = bx holds to rounding.
+// with dz kept explicit and corrected incrementally (CG sweeps on the exact operator; their number follows a
+// controller whose target is max(1e-11 ||c||, 0.1 ||rx||)) so the dual equation G'dz = bx holds as far as the
+// iterate's own residual makes it worth.
 //
 // Per iteration on the GPU (K numbers as in SURVEY 8a / DESIGN 4):
-//   K1  G v   : lattice mode: trigonometric polynomial per frequency by a rotation recurrence
-//               (k_trig_eval) + row gather; dense mode: A1 * [v, P'v] (k_amulti, HBM-bound)
-//   K3  G' v  : per-frequency aggregation + trigonometric moments per column (k_trig_moments,
-//               k_gt_finish); dense mode: A1' * [p1, p2] (k_atmulti)
+//   K1  G v   : lattice mode: trigonometric polynomial per FOLDED frequency (+w and -w share the recurrence:
+//               cosine and sine sums apart, C + S | C - S) (k_trig_eval) + row gather; dense mode: A1 * [v, P'v] (k_amulti, HBM-bound)
+//   K3  G' v  : per-frequency aggregation folded to (p(+w) + p(-w), p(+w) - p(-w)) (k_freq_fold), trigonometric
+//               moments per column (k_trig_moments, k_gt_finish); dense mode: A1' * [p1, p2] (k_atmulti)
 //   K6  NT scaling, per-frequency 2x2 weight blocks (k_scaling, k_freq_blocks)
 //   K2  normal matrix: lattice mode from the moments of the weight vectors (Toeplitz + Hankel,
 //       k_assemble_H_lat); dense mode T_k = A1' D_k A1 on the fp64 matrix cores (gram.hip); plus the
@@ -23,7 +24,7 @@
 // One host synchronisation per iteration (termination test on 24 doubles per design).
 //
 // Lock-step batches ("lanes", solve_lanes): B designs of one shape share every launch -- blockIdx.z (Cholesky:
-// .y) is the design, all device buffers of lane b sit b * lane_bytes after lane 0's, every kernel starts with the
+// a 1-D grid ordered by block kind) is the design, all device buffers of lane b sit b * lane_bytes after lane 0's, every kernel starts with the
 // LANES(...) prologue (mask test + pointer shift); per-lane status, sweep counts and masks live on the host.
 // Extended-precision KKT solve (ddkkt.inc + ddlin.hip): double-double accumulation / factorisation of the strongly
 // weighted part of the normal matrix for nearly active cones (fir_qp_cvx, and the retry of any numerical failure).
