@@ -290,7 +290,11 @@ __device__ __forceinline__ void tile_update(double* smem, const double* __restri
 
 #ifdef CHOL_TRACE
 __device__ long long g_trace[16 * 32];
+#ifdef CHOL_TRACE_D      /* the diagonal block of lane 0 (workgroup 0 of a kind-major grid) */
+#define TRACE(slot) if (threadIdx.x == 0 && blockIdx.x == 0) g_trace[a.k * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#else
 #define TRACE(slot) if (threadIdx.x == 0 && b == 1) g_trace[a.k * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#endif
 #else
 #define TRACE(slot)
 #endif
@@ -436,6 +440,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
             __syncthreads();
             if (tid == 0) __hip_atomic_store(a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        TRACE(5)
         return;
     }
     const int rho = tid >> 4, lam = tid & 15;
