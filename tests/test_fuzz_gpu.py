@@ -48,7 +48,7 @@ def make_case(seed):
     return which, (n, f, a * ph, dc)
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_spec_matches_the_oracle(seed):
     warnings.filterwarnings("ignore", category=RuntimeWarning)
     which, args = make_case(seed)
