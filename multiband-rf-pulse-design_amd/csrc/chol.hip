@@ -217,6 +217,13 @@ __device__ __forceinline__ void slab_image(const double* LB, const double* piv, 
     }
 }
 
+#if defined(CHOL_TRACE) && defined(CHOL_TRACE_D)
+__device__ long long g_trace2[64];
+__device__ int g_trace2_k;
+#define TRACE2(slot) if (threadIdx.x == 0 && blockIdx.x == 0 && b == 1 && g_trace2_k) g_trace2[(slot)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TRACE2(slot)
+#endif
 __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, double* LB, double* LS, const double* dsh,
                                             double* piv, double* Lz, double* dinv, double pivtol, int* flag, bool count) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -224,6 +231,10 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
     int nbad = 0;
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
+        TRACE2(0)
+#if defined(CHOL_TRACE) && defined(CHOL_TRACE_D)
+        if (threadIdx.x == 0 && blockIdx.x == 0 && b == 2 && g_trace2_k) g_trace2[6] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) {                     // (1) slab b -> LB
             const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
@@ -233,16 +244,20 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
             }
         }
         __syncthreads();
+        TRACE2(1)
         if (wv == 0) {                                    // (2) eliminate: lane = row
             double t[16], rp[16], pv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) t[c] = LB[lane * LBLD + 16 * b + c];
+            TRACE2(2)
             slab_steps<0>(t, rp, pv, dsh, 16 * b, pivtol, nbad);
+            TRACE2(3)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 LB[lane * LBLD + 16 * b + c] = t[c];
                 LS[lane * LSLD + c] = -t[c] * rp[c];
             }
+            TRACE2(4)
             if (lane == 0) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) piv[16 * b + c] = pv[c];
@@ -251,6 +266,7 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
             slab_image(LB, piv, Lz, dinv, b - 1, threadIdx.x - 64, 192);
         }
         __syncthreads();
+        TRACE2(5)
         if (b == 3) break;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {                     // (3) rank-16 update of the tiles right of the slab
@@ -263,7 +279,9 @@ __device__ __forceinline__ void potf2_slabs(v4d (&acc)[3], unsigned tiles, doubl
             }
         }
     }
+    { const int b = 1; TRACE2(7) }
     slab_image(LB, piv, Lz, dinv, 3, threadIdx.x, 256);
+    { const int b = 1; TRACE2(8) }
     if (count && threadIdx.x == 0 && nbad) atomicAdd(flag, nbad);
 }
 

@@ -24,6 +24,15 @@ int main(int argc, char** argv) {
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         printf("rep %d: %.1f us, %d launches (%s)\n", rep, ms * 1e3, n, hipGetErrorString(hipGetLastError()));
     }
+    {   // inside the elimination: one more run with the slab stamps on (they cover every step; the last one stays)
+        int one = 1; hipMemcpyToSymbol(HIP_SYMBOL(g_trace2_k), &one, sizeof(int));
+        for (int b = 0; b < nl; ++b) hipMemcpy(reinterpret_cast<char*>(dH) + b * lane_bytes, H.data(), np * (size_t)np * 8, hipMemcpyHostToDevice);
+        chol_inv_launch(dH, dM, dMt, dW, np, df, 0, nullptr, nullptr, nullptr, nl, lane_bytes, nullptr);
+        hipDeviceSynchronize();
+        long long t2[64]; hipMemcpyFromSymbol(t2, HIP_SYMBOL(g_trace2), sizeof(t2));
+        printf("slab 1 of the last step (10 ns ticks): accumulators->LDS+barrier %lld | operand loads %lld | 16 pivots %lld | stores %lld | barrier %lld | rank-16 updates (to slab 2 start) %lld ; last image %lld\n",
+               t2[1] - t2[0], t2[2] - t2[1], t2[3] - t2[2], t2[4] - t2[3], t2[5] - t2[4], t2[6] - t2[5], t2[8] - t2[7]);
+    }
     long long tr[512]; hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_trace), sizeof(tr));
     for (int k : {1, 4, 8, 12}) { printf("k=%2d D block (10 ns ticks):", k); for (int s = 1; s < 6; ++s) printf(" %lld", tr[k * 16 + s] - tr[k * 16 + s - 1]); printf("  | total %lld\n", tr[k * 16 + 5] - tr[k * 16]); }
     for (int k : {1, 4, 8, 12}) printf("k=%2d: D start -> next D start %lld ticks\n", k, tr[(k + 1) * 16] - tr[k * 16]);
