@@ -240,6 +240,10 @@ int mbfir_bloch(mbfir_ctx* ctx, int ntime, const double* b1_re, const double* b1
 int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, const double* d, double* out);
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m);
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im);
+/*  mbfir_test_fold: the host-side analysis of a frequency grid w[m] for the lattice kernels (no GPU, no context): pairs
+ *  +w / -w (fold != 0), cuts the folded list into equally spaced runs.  out[6]: lattice usable, folded entries, pairs,
+ *  runs, longest run, self-check failures (must be 0).  (Own addition; nothing in the reference corresponds.) */
+int mbfir_test_fold(const double* w, int m, int fold, long* out);
 /*  mbfir_test_ddsolve: x = (H + U' diag(X) U)^-1 b through the double-double kernels of the extended-precision
  *     KKT solve; H n x n, U k x n (row-major), b and x as (hi, lo) pairs of nrhs x n arrays, nrhs <= 2;
  *     nfix receives the number of replaced pivots; Lh / Ll (optional, n x n) the Cholesky factor.            */

@@ -109,6 +109,7 @@ SYMBOLS = {
     "mbfir_test_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_specfact": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_fold": (C.c_int, [_dp, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     "mbfir_test_ddsolve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp]),
     "mbfir_test_mfma_peak": (C.c_int, [C.c_void_p, _dp, _dp]),
     "mbfir_test_time_kernels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
@@ -699,3 +700,13 @@ def mfma_peak(ctx=None):
     a, b = C.c_double(), C.c_double()
     _check(ctx, load_library().mbfir_test_mfma_peak(ctx._h, C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def test_fold(w, fold=True):
+    """Host-side grid analysis of the lattice kernels (runs without a GPU): dict(ok, nfold, pairs, runs, longest, bad)."""
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    out = (C.c_long * 6)()
+    rc = load_library().mbfir_test_fold(_ptr(w), len(w), 1 if fold else 0, out)
+    if rc != 0:
+        raise RuntimeError("mbfir_test_fold failed (%d)" % rc)
+    return dict(zip(("ok", "nfold", "pairs", "runs", "longest", "bad"), [int(v) for v in out]))

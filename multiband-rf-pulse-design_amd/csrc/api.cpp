@@ -453,6 +453,11 @@ int mbfir_test_ddsolve(mbfir_ctx* ctx, int n, int k, const double* H, const doub
     if (!ctx || n < 1 || k < 0 || nrhs < 1 || nrhs > 2 || !H || !bh || !bl || !xh || !xl || !nfix) return MBFIR_E_ARG;
     MBFIR_TRY(ctx, ctx->solver->test_ddsolve(n, k, H, U, X, nrhs, bh, bl, xh, xl, nfix, Lh, Ll));
 }
+int mbfir_test_fold(const double* w, int m, int fold, long* out) {
+    if (!w || m < 1 || !out) return MBFIR_E_ARG;
+    try { Solver::test_fold(w, m, fold, out); } catch (const std::exception&) { return MBFIR_E_HIP; }
+    return 0;
+}
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im) {
     MBFIR_TRY(ctx, ctx->solver->test_specfact(n, x, h_re, h_im));
 }

@@ -46,6 +46,9 @@ public:
                      std::vector<SolveInfo>& infos);
     static std::vector<long> shape_key(const TrigProgram& P, const SolveOpts& o);   // equal keys = may share a batch
     static int max_lanes(const TrigProgram& P, const SolveOpts& o);
+    // host analysis of a frequency grid (no GPU needed): out[0] lattice ok, [1] folded entries, [2] pairs, [3] runs,
+    // [4] longest run, [5] entries that fail the self-check (every frequency exactly once, |w| within 1 ulp of the entry's)
+    static void test_fold(const double* w, int Mf, int fold, long* out);
     // fir_ap_cvx tap extraction on the device from the solution left by the last solve() / lane of solve_lanes().
     void specfact_last(int n, double* h_re, double* h_im, int lane = 0);
     void set_solution(const std::vector<double>& x);

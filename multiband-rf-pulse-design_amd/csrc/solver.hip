@@ -2419,6 +2419,29 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
             long(Q.quad), long(pr->f_rows.size()), long(pr->c_rows.size()), long(pr->yrows.size()), long(Lt.ok), long(Lt.D1),
             long(Lt.ch_start.size()), long(Lt.wf.size()), tbits};
 }
+void Solver::test_fold(const double* w, int Mf, int fold, long* out) {
+    TrigProgram Q;
+    Q.Nt = 1; Q.Mf = Mf; Q.w.assign(w, w + Mf);
+    Q.col_kind = {0}; Q.col_tau = {0.0}; Q.col_scale = {1.0}; Q.pcol = {0}; Q.psign = {0.0};
+    const LatticeInfo L = analyse_lattice(Q, fold != 0);
+    long pairs = 0, longest = 0, bad = 0;
+    std::vector<int> seen(Mf, 0);
+    double wmax = 1.0;
+    for (int i = 0; i < Mf; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+    const double ulp = 2.2204460492503131e-16 * wmax;
+    for (size_t k = 0; k < L.wf.size(); ++k) {
+        const int ip = L.fold_pos[k], in = L.fold_neg[k];
+        if (ip >= 0 && in >= 0) ++pairs;
+        if (ip < 0 && in < 0) ++bad;
+        if (ip >= 0) { if (ip >= Mf || seen[ip]++) ++bad; else if (std::fabs(w[ip] - L.wf[k]) > ulp + 1e-300 && fold) ++bad; }
+        if (in >= 0) { if (in >= Mf || seen[in]++) ++bad; else if (std::fabs(-w[in] - L.wf[k]) > ulp + 1e-300) ++bad; }
+    }
+    for (int i = 0; i < Mf; ++i) if (seen[i] != 1) ++bad;
+    long covered = 0;
+    for (size_t c = 0; c < L.ch_start.size(); ++c) { longest = std::max<long>(longest, L.ch_count[c]); covered += L.ch_count[c]; }
+    if (L.ok && covered != long(L.wf.size())) ++bad;
+    out[0] = L.ok ? 1 : 0; out[1] = long(L.wf.size()); out[2] = pairs; out[3] = long(L.ch_start.size()); out[4] = longest; out[5] = bad;
+}
 // how many lanes of this shape one context runs in lock step (memory and occupancy)
 int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
     if (o.shard_size > 1 || o.dense_trig || o.ddkkt_theta > 0) return 1;
