@@ -316,8 +316,99 @@ __global__ __launch_bounds__(1024) void k_dd_trsv(const double* __restrict__ Lh,
     }
 }
 
+// The same solve spread over one workgroup per 32-row block and pass (2 np / 32 workgroups in ONE launch): block b
+// accumulates  - L_bc y_c  as the blocks c it depends on are published (a flag per block in global memory, value =
+// `epoch` of this call, polled with a bound), solves its diagonal block and publishes y_b.  The forward blocks have the
+// lower workgroup indices and each block only waits for lower indices, so nobody waits for a workgroup that has not
+// been dispatched.  The right-hand sides are overwritten in place with device-scope stores and read back with
+// device-scope loads (another CU, maybe another XCD, produced them); the factor is read normally (nobody writes it).
+// One workgroup walked the whole factor in 1.4 ms at np = 1088; the chain here is 34 x (diagonal solve + hand-over).
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_flag(const int* f, int epoch) {
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+}
+template <int NV>
+__global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ Lh, const double* __restrict__ Ll,
+                                                    const double* __restrict__ Lth, const double* __restrict__ Ltl,
+                                                    const double* __restrict__ rih, const double* __restrict__ ril, int np,
+                                                    double* Bh, double* Bl, int ldv, int* flags, int epoch) {
+    __shared__ double Dh[DNB * (DNB + 1)], Dl[DNB * (DNB + 1)];
+    __shared__ double ysh[2][NV][DNB], yrow[2][NV][DNB];
+    const int nb = np / DNB, g = blockIdx.x, pass = g >= nb ? 1 : 0, bb = pass ? g - nb : g;
+    const int b0 = pass == 0 ? bb * DNB : np - DNB - bb * DNB;
+    const double* Th = pass == 0 ? Lh : Lth;
+    const double* Tl = pass == 0 ? Ll : Ltl;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = tid >> 3, q8 = tid & 7;
+    for (int e = tid; e < DNB * DNB; e += 256) {             // the diagonal block (read-only data)
+        const int rr = e / DNB, c = e - rr * DNB;
+        Dh[rr * (DNB + 1) + c] = Th[(long)(b0 + rr) * np + b0 + c];
+        Dl[rr * (DNB + 1) + c] = Tl[(long)(b0 + rr) * np + b0 + c];
+    }
+    // the rows' own right-hand side first (off the chain): given (forward), or the forward result of the same rows
+    // (backward; that flag is raised long before the backward blocks this one waits for below)
+    if (pass == 1) {
+        if (tid == 0) wait_flag(flags + b0 / DNB, epoch);
+        __syncthreads();
+    }
+    dd acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        acc[v] = q8 == 0 ? dd_make(ld_dev(Bh + (long)v * ldv + b0 + r), ld_dev(Bl + (long)v * ldv + b0 + r)) : dd_make(0.0, 0.0);
+    const double* th = Th + (long)(b0 + r) * np + q8 * 4;
+    const double* tl = Tl + (long)(b0 + r) * np + q8 * 4;
+    for (int c = 0; c < bb; ++c) {
+        const int b0c = pass == 0 ? c * DNB : np - DNB - c * DNB;
+        if (tid == 0) wait_flag(flags + pass * nb + c, epoch);
+        __syncthreads();
+        if (tid < DNB * NV) {
+            const int v = tid / DNB, i = tid - v * DNB;
+            ysh[0][v][i] = ld_dev(Bh + (long)v * ldv + b0c + i);
+            ysh[1][v][i] = ld_dev(Bl + (long)v * ldv + b0c + i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const dd lv = dd_make(th[b0c + j], tl[b0c + j]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = dd_fnma(acc[v], lv, dd_make(ysh[0][v][q8 * 4 + j], ysh[1][v][q8 * 4 + j]));
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) acc[v] = dd_add(acc[v], dd_make(__shfl_xor(acc[v].h, o, 64), __shfl_xor(acc[v].l, o, 64)));
+        if (q8 == 0) { yrow[0][v][r] = acc[v].h; yrow[1][v][r] = acc[v].l; }
+    }
+    __syncthreads();
+    if (wv < NV && lane < DNB) {                              // diagonal block: one wave per right-hand side, lane = row
+        dd y = dd_make(yrow[0][wv][lane], yrow[1][wv][lane]);
+        for (int s = 0; s < DNB; ++s) {
+            const int q = pass == 0 ? s : DNB - 1 - s;
+            const dd t = dd_mul(dd_shfl(y, q), dd_make(rih[b0 + q], ril[b0 + q]));
+            if (lane == q) y = t;
+            const bool pending = pass == 0 ? lane > q : lane < q;
+            if (pending) y = dd_fnma(y, dd_make(Dh[lane * (DNB + 1) + q], Dl[lane * (DNB + 1) + q]), t);
+        }
+        st_dev(Bh + (long)wv * ldv + b0 + lane, y.h);
+        st_dev(Bl + (long)wv * ldv + b0 + lane, y.l);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the device-scope stores above have completed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// flags: 2 np / 32 ints owned by the caller (zeroed once), epoch: a value no earlier call on these flags used (> 0);
+// flags == nullptr: the single-workgroup kernel
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
-                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st) {
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags, int epoch) {
+    if (flags && (nv == 1 || nv == 2) && np % DNB == 0) {
+        const dim3 grid(2 * np / DNB);
+        if (nv == 1) hipLaunchKernelGGL(k_dd_trsv_mw<1>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch);
+        else hipLaunchKernelGGL(k_dd_trsv_mw<2>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch);
+        return;
+    }
     if (np > DD_NP_MAX) throw HipError("dd solve: matrix too large for the LDS-resident right-hand sides");
     const size_t sh = (2 * (size_t)nv * np + 2 * DNB * (DNB + 1)) * sizeof(double);
     if (nv == 1) {

@@ -1892,6 +1892,8 @@ struct Solver::Impl {
     // The dd factor reuses the buffers of the double-precision inverse: Hl = M, L' = (Mt, W1).
     DDev D{};
     double *ddB = nullptr, *ddtS = nullptr, *ddzeta = nullptr, *ddri = nullptr, *ddd0 = nullptr;
+    int* ddflags = nullptr;      // block flags of k_dd_trsv_mw; dd_epoch: the value the current call waits for
+    int dd_epoch = 0;
     int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
     int dd_iters = 0, dd_kmax_seen = 0;
 
@@ -2156,7 +2158,7 @@ struct Solver::Impl {
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
             apply_GT<NV>(wbz, tmpN2);
             hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 256)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
-            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st);
+            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch);
             apply_G<NV>(Bh, wpR);
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wpR, tmpR, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
@@ -2615,6 +2617,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         D.sX = ar.get<double>(DD_KMAX); D.U = ar.get<double>((size_t)DD_KMAX * np);
         S.ddB = ar.get<double>(4 * LDV); S.ddtS = ar.get<double>(2 * (size_t)DD_KMAX); S.ddzeta = ar.get<double>(2 * (size_t)DD_KMAX);
         S.ddri = ar.get<double>(2 * np); S.ddd0 = ar.get<double>(np);
+        S.ddflags = ar.get<int>(2 * np / 32 + 8);          // block flags of the multi-workgroup dd solve (zeroed with the arena)
     }
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
@@ -2664,7 +2667,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.timing = o.timing;
 
     const bool sharded = S.shard_size > 1;
-    S.dd_iters = 0; S.dd_kmax_seen = 0; S.chol_launch_count = 0;
+    S.dd_iters = 0; S.dd_kmax_seen = 0; S.chol_launch_count = 0; S.dd_epoch = 0;
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
         hipLaunchKernelGGL(k_cone_resid, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, v, S.partR);
@@ -2989,8 +2992,10 @@ void Solver::test_ddsolve(int n, int k, const double* Hh, const double* U, const
     dd_syrk_launch(dU.as<double>(), int(np), dX.as<double>(), df.as<int>() + 1, int(np), dH.as<double>(), dHl.as<double>(), S.st);
     dd_chol_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
                    dd0.as<double>(), int(np), 1e-28, df.as<int>(), S.st);
+    DevBuf dflags(sizeof(int) * (2 * np / 32 + 8));
+    MBFIR_HIP(hipMemsetAsync(dflags.p, 0, sizeof(int) * (2 * np / 32 + 8), S.st));
     dd_trsv_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
-                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st);
+                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st, dflags.as<int>(), 1);
     MBFIR_HIP(hipMemcpyAsync(B.data(), dB.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(Bl.data(), dBl.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(nfix, df.p, sizeof(int), hipMemcpyDeviceToHost, S.st));
