@@ -92,21 +92,24 @@ __global__ __launch_bounds__(256) void k_ddchol_diag(double* __restrict__ Hh, do
     }
     for (int j = 0; j < DNB; ++j) {
         __syncthreads();
+        // every thread forms 1 / sqrt(pivot) itself (no broadcast, one barrier less): x = 1 / sqrt(p.h) to double
+        // accuracy, then one Newton step in dd,  ri = x + x (1 - p x^2) / 2  (error 3/8 e^2, e ~ 1e-16), and r = p ri
+        dd p = dd_make(Dh[j][j], Dl[j][j]);
+        const double dj = d0[k0 + j];
+        const bool bad = !(p.h > pivtol * dj);
+        if (bad) p = dd_make(dj > 1e-300 ? dj : 1e-300, 0.0);
+        double x = 1.0 / sqrt(p.h);
+        x = x * (1.5 - 0.5 * p.h * x * x);
+        const dd e1 = dd_sub(dd_make(1.0), dd_mul_d(dd_mul_d(p, x), x));
+        const dd ri = dd_add_d(dd_mul_d(e1, 0.5 * x), x);
+        __syncthreads();                                      // everybody has read the pivot
         if (tid == 0) {
-            dd p = dd_make(Dh[j][j], Dl[j][j]);
-            const double dj = d0[k0 + j];
-            if (!(p.h > pivtol * dj)) {
-                p = dd_make(dj > 1e-300 ? dj : 1e-300, 0.0);
-                atomicAdd(flag, 1);
-            }
-            const dd r = dd_sqrt(p);
+            const dd r = dd_mul(p, ri);
             Dh[j][j] = r.h; Dl[j][j] = r.l;
-            const dd ri = dd_div(dd_make(1.0), r);
             rh[j] = ri.h; rl[j] = ri.l;
-        }
-        __syncthreads();
-        if (tid > j && tid < DNB) {
-            const dd v = dd_mul(dd_make(Dh[tid][j], Dl[tid][j]), dd_make(rh[j], rl[j]));
+            if (bad) atomicAdd(flag, 1);
+        } else if (tid > j && tid < DNB) {
+            const dd v = dd_mul(dd_make(Dh[tid][j], Dl[tid][j]), ri);
             Dh[tid][j] = v.h; Dl[tid][j] = v.l;
         }
         __syncthreads();
@@ -129,37 +132,53 @@ __global__ __launch_bounds__(256) void k_ddchol_diag(double* __restrict__ Hh, do
     if (tid < DNB) { rih[k0 + tid] = rh[tid]; ril[k0 + tid] = rl[tid]; }
 }
 
-// (2) panel rows below the diagonal block: X D' = A by forward substitution, one thread per row, the row and
-// the diagonal block in LDS
-__global__ __launch_bounds__(64) void k_ddchol_trsm(double* __restrict__ Hh, double* __restrict__ Hl,
-                                                    double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
-                                                    const double* __restrict__ rih, const double* __restrict__ ril) {
-    __shared__ double Dh[DNB][DNB], Dl[DNB][DNB];
-    __shared__ double ah[DNB][65], al[DNB][65];
+// (2) panel rows below the diagonal block: X D' = A by forward substitution.  Eight threads per row: thread q of a
+// row keeps the solved entries c = q (mod 8) in registers and contributes their products to every later column; the
+// eight partial sums meet by three xor-shuffles.  (One thread per row walked 496 dependent dd products: 55 us a panel.)
+__global__ __launch_bounds__(256) void k_ddchol_trsm(double* __restrict__ Hh, double* __restrict__ Hl,
+                                                     double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
+                                                     const double* __restrict__ rih, const double* __restrict__ ril) {
+    __shared__ double Dh[DNB][DNB + 1], Dl[DNB][DNB + 1];
+    __shared__ double ah[DNB][33], al[DNB][33];
     __shared__ double rh[DNB], rl[DNB];
-    const int tid = threadIdx.x, i = k0 + DNB + blockIdx.x * 64 + tid;
-    for (int e = tid; e < DNB * DNB; e += 64) {
+    const int tid = threadIdx.x, rr = tid >> 3, q8 = tid & 7;
+    const int i0 = k0 + DNB + blockIdx.x * 32, i = i0 + rr;
+    for (int e = tid; e < DNB * DNB; e += 256) {
         const int r = e / DNB, c = e - r * DNB;
         Dh[r][c] = Hh[(long)(k0 + r) * np + k0 + c];
         Dl[r][c] = Hl[(long)(k0 + r) * np + k0 + c];
+        const bool lv = i0 + r < np;                          // row r of this block, column c of the panel
+        ah[c][r] = lv ? Hh[(long)(i0 + r) * np + k0 + c] : 0.0;
+        al[c][r] = lv ? Hl[(long)(i0 + r) * np + k0 + c] : 0.0;
     }
     if (tid < DNB) { rh[tid] = rih[k0 + tid]; rl[tid] = ril[k0 + tid]; }
-    const bool live = i < np;
-    for (int c = 0; c < DNB; ++c) {
-        ah[c][tid] = live ? Hh[(long)i * np + k0 + c] : 0.0;
-        al[c][tid] = live ? Hl[(long)i * np + k0 + c] : 0.0;
-    }
     __syncthreads();
-    if (!live) return;
+    dd x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = dd_make(0.0, 0.0);
+#pragma unroll
     for (int c = 0; c < DNB; ++c) {
-        dd v = dd_make(ah[c][tid], al[c][tid]);
-        for (int q = 0; q < c; ++q) v = dd_fnma(v, dd_make(ah[q][tid], al[q][tid]), dd_make(Dh[c][q], Dl[c][q]));
-        v = dd_mul(v, dd_make(rh[c], rl[c]));
-        ah[c][tid] = v.h; al[c][tid] = v.l;
+        dd sum = dd_make(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = 8 * k + q8;
+            if (8 * k < c) {                                  // (static bound; q < c tested per lane)
+                const dd t = dd_mul(x[k], dd_make(Dh[c][q], Dl[c][q]));
+                if (q < c) sum = dd_add(sum, t);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) sum = dd_add(sum, dd_make(__shfl_xor(sum.h, o, 64), __shfl_xor(sum.l, o, 64)));
+        const dd v = dd_mul(dd_sub(dd_make(ah[c][rr], al[c][rr]), sum), dd_make(rh[c], rl[c]));
+        if ((c & 7) == q8) x[c >> 3] = v;
     }
-    for (int c = 0; c < DNB; ++c) {
-        Hh[(long)i * np + k0 + c] = ah[c][tid]; Hl[(long)i * np + k0 + c] = al[c][tid];
-        Lth[(long)(k0 + c) * np + i] = ah[c][tid]; Ltl[(long)(k0 + c) * np + i] = al[c][tid];
+    if (i < np) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 8 * k + q8;
+            Hh[(long)i * np + k0 + c] = x[k].h; Hl[(long)i * np + k0 + c] = x[k].l;
+            Lth[(long)(k0 + c) * np + i] = x[k].h; Ltl[(long)(k0 + c) * np + i] = x[k].l;
+        }
     }
 }
 
@@ -239,7 +258,7 @@ void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* ri
         hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
         const int rows = np - k0 - DNB;
         if (rows <= 0) break;
-        hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 64)), dim3(64), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
+        hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 32)), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
         const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
         hipLaunchKernelGGL(k_ddchol_update, dim3(nt * (nt + 1) / 2), dim3(256), UPD_LDS, st, Hh, Hl, np, k0);
     }
