@@ -143,3 +143,20 @@ def test_spectral_factorisation_matches_oracle(n):
 def test_fp64_peak_microbenchmark_runs():
     mf, va = mbfir.mfma_peak()
     assert 5.0 < mf < 200.0 and 5.0 < va < 200.0
+
+
+def test_double_double_solve_with_one_right_hand_side_equals_the_first_of_two():
+    """k_dd_trsv_mw<1> against k_dd_trsv_mw<2>: the blocks' sums run in the same order per right-hand side, so the
+    single solve reproduces column 0 of the double solve bit for bit."""
+    rng = np.random.default_rng(9)
+    n, k = 300, 40
+    B = rng.standard_normal((n + 30, n))
+    Hw = B.T @ B
+    Hw = 0.5 * (Hw + Hw.T)
+    U = rng.standard_normal((k, n))
+    X = 10.0 ** rng.uniform(8, 14, k)
+    b = rng.standard_normal((2, n))
+    bl = np.zeros((2, n))
+    xh2, xl2, _ = mbfir.test_ddsolve(Hw, U, X, b, bl)
+    xh1, xl1, _ = mbfir.test_ddsolve(Hw, U, X, b[:1], bl[:1])
+    assert np.array_equal(xh1[0], xh2[0]) and np.array_equal(xl1[0], xl2[0])
