@@ -293,9 +293,10 @@ __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
 }
 
 // C_tile (64x64 at dst) -= A_tile * B_tile (TRANSB: B_tile') through the MFMA helper
+// first: the tile has not been written in this factorisation yet -- its old content (the previous build's) counts as 0
 template <bool TRANSB>
 __device__ __forceinline__ void tile_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ Bg,
-                                            double* __restrict__ dst, int np) {
+                                            double* __restrict__ dst, int np, bool first = false) {
     double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
     double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
     load_block(P, Ag, np);
@@ -303,7 +304,8 @@ __device__ __forceinline__ void tile_update(double* smem, const double* __restri
     __syncthreads();
     v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
     mma64<TRANSB>(P, Q, 0, CB, acc);
-    acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
+    if (first) acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = -v; });
+    else acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
 }
 
 #ifdef CHOL_TRACE
@@ -318,7 +320,7 @@ __device__ long long g_trace[16 * 32];
 #endif
 
 struct CholStep {
-    double* H; double* M; int np, nblk, k;
+    double* H; double* M; double* Mt; int np, nblk, k;   // Mt: written by the inverse-row blocks when not null
     const double* d0; double pivtol;
     double* Dfac;            // per panel: 64x64 zero-padded column image of L_kk (see subst16)
     double* dinvG;           // 1 / diag(L)
@@ -513,11 +515,14 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
     }
     __syncthreads();
     {
+        // R_rj as the updates left it; tiles no update ever reached hold the previous build's numbers and stand for
+        // their initial value: the identity on the diagonal (j == r), zero next to it (j == r - 1)
         const int c = lane & 15;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int t = 16 * wv + (lane >> 4) + 4 * q;
-            Ct[c * YLD + t] = M[(kr + t) * np + (long)j * CB + c0 + c] - acc[q];
+            const double r0 = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : M[(kr + t) * np + (long)j * CB + c0 + c];
+            Ct[c * YLD + t] = r0 - acc[q];
         }
     }
     __syncthreads();
@@ -533,6 +538,11 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
     double* dst = M + (kr + t) * np + (long)j * CB + c0 + c4;
     *reinterpret_cast<double2*>(dst) = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]);
     *reinterpret_cast<double2*>(dst + 2) = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
+    if (a.Mt) {                                           // the transpose for the second triangular GEMV, straight from the staging tile
+        const int c = tid >> 4, t4 = (tid & 15) * 4;      // 16 rows of Mt (columns of this block) x 64 entries
+        double* dt = a.Mt + ((long)j * CB + c0 + c) * np + kr + t4;
+        dt[0] = Ct[c * YLD + t4]; dt[1] = Ct[c * YLD + t4 + 1]; dt[2] = Ct[c * YLD + t4 + 2]; dt[3] = Ct[c * YLD + t4 + 3];
+    }
 }
 
 template <class T>
@@ -570,6 +580,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
         const size_t off = (size_t)lane * a.lane_bytes;
         a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
         a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.sync = lane_at(a.sync, off);
+        if (a.Mt) a.Mt = lane_at(a.Mt, off);
     }
     if (kind == 4) { panel_block<true>(a, b + 1, smem); return; }         // row blocks of a split step
     if (kind == 0) { panel_block<false>(a, b, smem); return; }
@@ -585,24 +596,19 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2)
     const int i = k + b / (k - 1), j = b % (k - 1);
     const long mm = (long)(k - 2) * CB;
-    tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np);
+    // (the inverse factor is not initialised: R = I is implied -- a tile's first update, by panel j = k - 2, WRITES it)
+    tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np, j == k - 2);
 }
 
-// M = I (the inverse factor starts as the identity), d0 = diag(H), pivot-replacement counter = 0; one launch for
-// all lanes (a 2-D hipMemset of the lanes' M costs 0.2 ms at 8 x 8 MB, this streams at HBM rate)
-__global__ __launch_bounds__(256) void k_chol_init(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M,
+// d0 = diag(H), pivot-replacement counter = 0, panel flags = 0; one launch for all lanes.  The inverse factor is NOT
+// initialised any more (64 MB of writes per unit of 8 at np = 1024): the update and inverse-row blocks imply R = I.
+__global__ __launch_bounds__(256) void k_chol_init(const double* __restrict__ H, int np, double* __restrict__ d0,
                                                    int* __restrict__ flag, int* __restrict__ sync, size_t lane_bytes, const int* __restrict__ mask) {
     if (mask && !mask[blockIdx.y]) return;
     const size_t off = (size_t)blockIdx.y * lane_bytes;
-    H = lane_at(H, off); d0 = lane_at(d0, off); M = lane_at(M, off); flag = lane_at(flag, off); sync = lane_at(sync, off);
+    H = lane_at(H, off); d0 = lane_at(d0, off); flag = lane_at(flag, off); sync = lane_at(sync, off);
     if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
     if (blockIdx.x == 0 && threadIdx.x < np / CB + 1) sync[threadIdx.x] = 0;
-    const long n2 = (long)np * np / 2;                     // double2 elements
-    double2* M2 = reinterpret_cast<double2*>(M);
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n2; e += (long)gridDim.x * 256) {
-        const long i = (2 * e) / np, j = (2 * e) - i * np;
-        M2[e] = make_double2(j == i ? 1.0 : 0.0, j + 1 == i ? 1.0 : 0.0);
-    }
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < np; j += (long)gridDim.x * 256) d0[j] = H[j * np + j];
 }
 // also clears the lane's pivot-replacement counter
@@ -650,7 +656,8 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
     a.lane_bytes = lane_bytes; a.mask = mask; a.nlanes = nlanes;
     a.sync = reinterpret_cast<int*>(W1 + (long)(CB + 2) * np);          // behind 1 / diag(L): nblk + 1 ints
-    hipLaunchKernelGGL(k_chol_init, dim3(std::min(1024, cdiv((long)np * np / 2, 256)), nlanes), dim3(256), 0, st, H, np, W1, M, flag, a.sync, lane_bytes, mask);
+    a.Mt = Mt;
+    hipLaunchKernelGGL(k_chol_init, dim3(cdiv(np, 256), nlanes), dim3(256), 0, st, H, np, W1, flag, a.sync, lane_bytes, mask);
     if (e0) hipEventRecord(e0, st);
     // Lock-step batches split every step (see CholStep::phase): with several designs in flight the chip is no longer
     // empty, and the 4 * nrem row blocks of a step each repeating the 64-pivot factorisation of L_kk is what fills it.
@@ -678,7 +685,6 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     }
     if (e1) hipEventRecord(e1, st);
     if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
-    hipLaunchKernelGGL(k_transpose, dim3(np / 32, np / 32, nlanes), dim3(32, 8), 0, st, M, Mt, np, lane_bytes, mask);
     return launches;                                      // k_chol_step launches issued
 }
 

@@ -2958,13 +2958,31 @@ void Solver::test_chol(int n, const double* Hh, double* out_l, double* out_m) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) Hp[i * np + j] = Hh[(size_t)i * n + j];
     DevBuf dH(np * np * 8), dM(np * np * 8), dMt(np * np * 8), dW((np * np + 65 * np) * 8), df(16), dL(np * np * 8);
+    // The inverse factor is never initialised by the factorisation (the solver zeroes its arena once per solve, later
+    // builds find the previous build's numbers in the lower tiles): mimic that -- zero once, factorise a DIFFERENT
+    // matrix first, then the one asked for -- and check the transpose the inverse-row blocks write beside it.
+    MBFIR_HIP(hipMemsetAsync(dM.p, 0, np * np * 8, S.st));
+    MBFIR_HIP(hipMemsetAsync(dMt.p, 0, np * np * 8, S.st));
+    {
+        std::vector<double> H2(Hp);
+        for (size_t i = 0; i < np; ++i) H2[i * np + i] = 2.0 * H2[i * np + i] + 1.0;
+        MBFIR_HIP(hipMemcpyAsync(dH.p, H2.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
+        chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st, nullptr);
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+    }
     MBFIR_HIP(hipMemcpyAsync(dH.p, Hp.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
     chol_inv_launch(dH.as<double>(), dM.as<double>(), dMt.as<double>(), dW.as<double>(), int(np), df.as<int>(), S.st,
                     dL.as<double>());
     MBFIR_HIP(hipMemcpy2DAsync(out_l, (size_t)n * 8, dL.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpy2DAsync(out_m, (size_t)n * 8, dM.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+    std::vector<double> Mh(np * np), Mth(np * np);
+    MBFIR_HIP(hipMemcpyAsync(Mh.data(), dM.p, np * np * 8, hipMemcpyDeviceToHost, S.st));
+    MBFIR_HIP(hipMemcpyAsync(Mth.data(), dMt.p, np * np * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));
     MBFIR_HIP(hipGetLastError());
+    for (size_t i = 0; i < np; ++i)
+        for (size_t j = 0; j < np; ++j)
+            if (Mh[i * np + j] != Mth[j * np + i]) throw HipError("test_chol: the stored transpose differs from the inverse factor");
 }
 
 // x = (H + U' diag(X) U)^-1 b through the double-double kernels (ddlin.hip); b and x are dd (hi, lo), nrhs <= 2
