@@ -2542,7 +2542,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         P.seeds_shared = same ? 1 : 0;
     }
     if (const char* ev = std::getenv("MBFIR_SHARE_SEEDS")) P.seeds_shared = P.seeds_shared && std::atoi(ev) != 0;
-    P.cgrp = 2;          // one pair of interleaved chunks per block: measured best at 1 and at 8 lanes, and the same sums in both
+    P.cgrp = 4;          // two pairs of interleaved chunks per block, for one design and for lanes alike (the same sums in both):
+                         // half the partial-moment traffic of one pair per block -- with four units in flight the solver moves
+                         // 3 TB/s through HBM, and that, not the recurrences, is what the moment kernels then wait for
     if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
     P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
