@@ -1509,6 +1509,7 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
     LANES(P, Mom, MomB, H);
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (k >= P.np || j >= P.np) return;
+    if (k > (j | 63)) return;                             // the factorisations read the lower 64 x 64 tiles only
     double v = 0;
     const long mw = 2L * P.LDM;
     if (j < P.Nt && k < P.Nt) {
