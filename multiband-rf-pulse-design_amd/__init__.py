@@ -489,7 +489,7 @@ def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False, solutions=
                 params[1:1 + len(objv)] = list(objv)
                 params[3] = float(len(objv))
         hre, him = np.zeros(n), np.zeros(n)
-        zbuf = np.zeros(2 * n + 8) if solutions else None
+        zbuf = np.zeros(4 * n + 16) if solutions else None       # every designer has at most 2n + 3 unknowns; checked below
         keep.append((f, a, d, hre, him, zbuf))
         J = arr[q]
         if solutions:
@@ -510,6 +510,8 @@ def solve_batch(jobs, *, opts=None, streams=4, ctxs=None, info=False, solutions=
                 raise ValueError("job %d: invalid argument" % q)
             raise MbfirError("job %d failed (%d): %s" % (q, arr[q].rc, arr[q].err.decode(errors="replace")))
         res = _finish(ctxs[0], arr[q].rc, hre, him, inf, info)
+        if solutions and inf.n_unknowns > len(keep[q][5]):
+            raise MbfirError("job %d: the conic solution has %d unknowns, the buffer %d" % (q, inf.n_unknowns, len(keep[q][5])))
         out.append(res + (keep[q][5][: inf.n_unknowns],) if solutions else res)
     return out
 

@@ -374,7 +374,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
             const int cap = int(g.first.back()), G = int(g.second.size());
             // enough units to occupy every context, no more lanes per unit than the shape allows
             int per = std::min(cap, std::max(1, (G + nctx - 1) / nctx));
-            if (lanes_cap > 1) per = std::min(std::min(lanes_cap, 64), G);
+            if (lanes_cap > 1) per = std::min(std::min(lanes_cap, cap), G);      // an explicit request never exceeds what the shape allows
             for (int i = 0; i < G; i += per) units.emplace_back(g.second.begin() + i, g.second.begin() + std::min(G, i + per));
         }
     }
@@ -420,8 +420,10 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 }
                 for (int q : redo) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
             } catch (const std::exception& e) {
+                // the unit as a whole failed (a shape the lock-step path rejects, a device error): every design of it
+                // goes through the single-design path, which reports its own verdict or error
                 ctx->err = e.what();
-                for (int q : U) { jobs[q].rc = MBFIR_E_HIP; jobs[q].info.status = MBFIR_E_HIP; finish_job(q); }
+                for (int q : U) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
             }
         }
     };

@@ -342,6 +342,22 @@ constexpr int YLD = 65;                                  // staging tiles that a
 constexpr int R0 = 0, R1 = CB * CLD, R2 = 2 * CB * CLD, R3 = R2 + 1152;
 constexpr int STEP_LDS = R3 + 336;                       // 79.4 KB
 
+// ---- in-launch hand-offs between workgroups (cdna_hip_programming.md guideline 16, recipe R1) -------------------
+// A pivot counter at or above CHOL_SYNC_LOST (dev_common.h) means a bounded flag poll expired: the factorisation is void.
+constexpr int CHOL_SPIN_LIMIT = 1 << 21;                  // x s_sleep(4) + one L2 round trip: several seconds
+
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ONE lane polls ONE word (relaxed, agent scope: an sc1 load) until it reaches `want`; false + sentinel on expiry
+__device__ __forceinline__ bool wait_flag(const int* word, int want, int* pivflag) {
+    int spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins >= CHOL_SPIN_LIMIT) { atomicAdd(pivflag, CHOL_SYNC_LOST); return false; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
+
 template <bool FROM_IMAGE>
 __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -418,17 +434,18 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     TRACE(3)
     double* Lz = smem + R0;
     if (FROM_IMAGE) {                                     // the image of L_kk and 1 / diag(L_kk) as the diagonal block left them
-        // the diagonal block of this lane runs in the SAME launch (it was dispatched first): wait for its flag.  The
-        // poll is bounded, so a lost flag ends in wrong numbers (caught by the pivot checks and the tests), not a hang.
+        // the diagonal block of this lane runs in the SAME launch: wait for its flag.  The poll is bounded; a poll that
+        // expires raises CHOL_SYNC_LOST in the lane's pivot counter, which the host turns into an error (the numbers
+        // this block goes on to produce from the stale image are never used) -- no hang, no silent wrong factor.
         if (a.phase == 1) {
-            if (tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(a.sync + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(4);
-            }
+            if (tid == 0) wait_flag(a.sync + k, 1, a.flag);
             __syncthreads();
         }
-        // device-scope loads (they bypass what this XCD's L2 may still hold of the previous build's image); the
-        // diagonal block stored the image the same way, so no cache-wide invalidate / write-back is needed
+        // Hand-off by write-through stores and L1-bypassing loads (cdna_hip_programming.md guideline 16, R1): every
+        // byte of the image is stored sc1 by the diagonal block, each storing wave drains its stores (s_waitcnt
+        // vmcnt(0)) before the workgroup barrier behind which ONE lane stores the flag, the flag is polled by ONE lane
+        // with sc1 loads, the other waves pass a barrier after the poll, and every load of the image is an sc1 load
+        // (served past this CU's L1, which another CU's stores never refresh) -- no L2 write-back / invalidate.
         double t[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) t[u] = __hip_atomic_load(a.Dfac + kk * CB + tid + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -456,8 +473,8 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         for (int e = tid; e < CB * CB; e += 256) __hip_atomic_store(a.Dfac + kk * CB + e, Lz[(e >> 6) * ZLD + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < CB) __hip_atomic_store(a.dinvG + kk + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.phase == 1) {                               // merged split step: release the row blocks of this lane
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the device-scope stores above have completed
-            __syncthreads();
+            drain_stores();                               // every storing wave: its sc1 stores have left the CU ...
+            __syncthreads();                              // ... before the one lane that signals for all of them does
             if (tid == 0) __hip_atomic_store(a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TRACE(5)

@@ -8,6 +8,7 @@
 // sum factorised, in dd they survive.  Everything here is fp64 VALU work with error-free transformations:
 // there is no matrix-core path for dd.
 #include "dev_common.h"
+#include <mutex>
 #include "dd_dev.h"
 #include "solver.h"
 
@@ -337,25 +338,39 @@ __global__ __launch_bounds__(1024) void k_dd_trsv(const double* __restrict__ Lh,
 
 // The same solve spread over one workgroup per 32-row block and pass (2 np / 32 workgroups in ONE launch): block b
 // accumulates  - L_bc y_c  as the blocks c it depends on are published (a flag per block in global memory, value =
-// `epoch` of this call, polled with a bound), solves its diagonal block and publishes y_b.  The forward blocks have the
-// lower workgroup indices and each block only waits for lower indices, so nobody waits for a workgroup that has not
-// been dispatched.  The right-hand sides are overwritten in place with device-scope stores and read back with
-// device-scope loads (another CU, maybe another XCD, produced them); the factor is read normally (nobody writes it).
+// `epoch` of this call, polled with a bound), solves its diagonal block and publishes y_b.
+// Forward progress does not rest on the order in which the hardware dispatches workgroups: a workgroup takes its block
+// from a TICKET counter (flags[2 nb], never reset: launch number e of one solve hands out (e-1) grid .. e grid - 1) in
+// dependency order -- forward blocks first, each block only waits for lower tickets, and a ticket is drawn by a
+// workgroup that is already running -- so nobody waits for a workgroup that has not started.
+// Hand-off (cdna_hip_programming.md guideline 16, R1): the right-hand sides are overwritten in place with sc1
+// (write-through) stores, every storing wave drains them (s_waitcnt vmcnt(0)) before the barrier behind which ONE lane
+// stores the flag; the consumer polls with ONE lane, passes a barrier, and reads the published entries with sc1 loads
+// (another CU, maybe another XCD, produced them); the factor is read normally (nobody writes it).  A poll that expires
+// adds DD_SYNC_LOST to the pivot counter, which the host turns into an error.
 // One workgroup walked the whole factor in 1.4 ms at np = 1088; the chain here is 34 x (diagonal solve + hand-over).
 __device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wait_flag(const int* f, int epoch) {
+__device__ __forceinline__ void wait_flag(const int* f, int epoch, int* lost) {
     int spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (++spins >= (1 << 22)) { atomicAdd(lost, DD_SYNC_LOST); return; }
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 template <int NV>
 __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ Lh, const double* __restrict__ Ll,
                                                     const double* __restrict__ Lth, const double* __restrict__ Ltl,
                                                     const double* __restrict__ rih, const double* __restrict__ ril, int np,
-                                                    double* Bh, double* Bl, int ldv, int* flags, int epoch) {
+                                                    double* Bh, double* Bl, int ldv, int* flags, int epoch, int* lost) {
     __shared__ double Dh[DNB * (DNB + 1)], Dl[DNB * (DNB + 1)];
     __shared__ double ysh[2][NV][DNB], yrow[2][NV][DNB];
-    const int nb = np / DNB, g = blockIdx.x, pass = g >= nb ? 1 : 0, bb = pass ? g - nb : g;
+    __shared__ int ticket;
+    const int nb = np / DNB;
+    if (threadIdx.x == 0) ticket = atomicAdd(flags + 2 * nb, 1) - (epoch - 1) * int(gridDim.x);
+    __syncthreads();
+    const int g = ticket, pass = g >= nb ? 1 : 0, bb = pass ? g - nb : g;
+    if (g < 0 || g >= 2 * nb) { if (threadIdx.x == 0) atomicAdd(lost, DD_SYNC_LOST); return; }     // (a ticket word somebody else touched)
     const int b0 = pass == 0 ? bb * DNB : np - DNB - bb * DNB;
     const double* Th = pass == 0 ? Lh : Lth;
     const double* Tl = pass == 0 ? Ll : Ltl;
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ L
     // the rows' own right-hand side first (off the chain): given (forward), or the forward result of the same rows
     // (backward; that flag is raised long before the backward blocks this one waits for below)
     if (pass == 1) {
-        if (tid == 0) wait_flag(flags + b0 / DNB, epoch);
+        if (tid == 0) wait_flag(flags + b0 / DNB, epoch, lost);
         __syncthreads();
     }
     dd acc[NV];
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ L
     const double* tl = Tl + (long)(b0 + r) * np + q8 * 4;
     for (int c = 0; c < bb; ++c) {
         const int b0c = pass == 0 ? c * DNB : np - DNB - c * DNB;
-        if (tid == 0) wait_flag(flags + pass * nb + c, epoch);
+        if (tid == 0) wait_flag(flags + pass * nb + c, epoch, lost);
         __syncthreads();
         if (tid < DNB * NV) {
             const int v = tid / DNB, i = tid - v * DNB;
@@ -413,30 +428,31 @@ __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ L
         st_dev(Bh + (long)wv * ldv + b0 + lane, y.h);
         st_dev(Bl + (long)wv * ldv + b0 + lane, y.l);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the device-scope stores above have completed
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave: its sc1 stores have left the CU ...
+    __syncthreads();                                              // ... before the one lane that signals for all of them does
     if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// flags: 2 np / 32 ints owned by the caller (zeroed once), epoch: a value no earlier call on these flags used (> 0);
-// flags == nullptr: the single-workgroup kernel
+// flags: 2 np / 32 + 1 ints owned by the caller (zeroed once; the last one is the ticket counter), epoch: 1, 2, 3, ...
+// over the calls that use these flags (every call with the same np); lost: the counter a lost hand-off is reported in
+// (DD_SYNC_LOST, next to the replaced pivots); flags == nullptr: the single-workgroup kernel
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
-                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags, int epoch) {
-    if (flags && (nv == 1 || nv == 2) && np % DNB == 0) {
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags, int epoch, int* lost) {
+    if (flags && lost && (nv == 1 || nv == 2) && np % DNB == 0) {
         const dim3 grid(2 * np / DNB);
-        if (nv == 1) hipLaunchKernelGGL(k_dd_trsv_mw<1>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch);
-        else hipLaunchKernelGGL(k_dd_trsv_mw<2>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch);
+        if (nv == 1) hipLaunchKernelGGL(k_dd_trsv_mw<1>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch, lost);
+        else hipLaunchKernelGGL(k_dd_trsv_mw<2>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch, lost);
         return;
     }
     if (np > DD_NP_MAX) throw HipError("dd solve: matrix too large for the LDS-resident right-hand sides");
     const size_t sh = (2 * (size_t)nv * np + 2 * DNB * (DNB + 1)) * sizeof(double);
     if (nv == 1) {
-        static bool set1 = false;
-        if (!set1) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set1 = true; }
+        static std::once_flag set1;                       // (mbfir_solve_batch runs its contexts on parallel host threads)
+        std::call_once(set1, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
         hipLaunchKernelGGL(k_dd_trsv<1>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
     } else if (nv == 2) {
-        static bool set2 = false;
-        if (!set2) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); set2 = true; }
+        static std::once_flag set2;
+        std::call_once(set2, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
         hipLaunchKernelGGL(k_dd_trsv<2>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
     } else {
         throw HipError("dd solve: unsupported number of right-hand sides");

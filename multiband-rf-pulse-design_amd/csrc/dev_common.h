@@ -104,7 +104,12 @@ void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
                     double pivtol, int* flag, hipStream_t st);
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
-                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags = nullptr, int epoch = 0);
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags = nullptr, int epoch = 0,
+                    int* lost = nullptr);
+// In-launch hand-offs between workgroups (chol.hip, ddlin.hip) poll with a bound; a poll that expires adds this to the
+// pivot-replacement counter of the factorisation it belongs to, and the host turns a counter at or above it into an error.
+constexpr int CHOL_SYNC_LOST = 1 << 20;
+constexpr int DD_SYNC_LOST = CHOL_SYNC_LOST;
 
 // Spectral factorisation (fir_ap_cvx.m:185-186,264-304): x (2n-1) -> n taps (re, im interleaved
 // in hout[2n]).  work must hold 6*lp doubles, lp = 8*2^ceil(log2(2n-1)).

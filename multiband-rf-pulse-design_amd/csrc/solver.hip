@@ -2159,7 +2159,7 @@ struct Solver::Impl {
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
             apply_GT<NV>(wbz, tmpN2);
             hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 256)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
-            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch);
+            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch, flag);
             apply_G<NV>(Bh, wpR);
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wpR, tmpR, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
@@ -2447,7 +2447,10 @@ void Solver::test_fold(const double* w, int Mf, int fold, long* out) {
 }
 // how many lanes of this shape one context runs in lock step (memory and occupancy)
 int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
+    // lock-step batches exist on the lattice path only; the extended-precision KKT solve (on by default for
+    // fir_qp_cvx) and row-sharded solves run one design at a time
     if (o.shard_size > 1 || o.dense_trig || o.ddkkt_theta > 0) return 1;
+    if (!lane_prep(Q, o)->Lt.ok) return 1;                // a grid / column set without the lattice structure: dense path
     const long np = round_up(Q.N(), 64);
     return int(std::max<long>(1, std::min<long>(MAX_LANES, std::min<long>(32, 16384 / np))));
 }
@@ -2714,11 +2717,15 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
         MBFIR_HIP(hipStreamSynchronize(st));
         bool any_live = false, any_best = false;
+        for (int b = 0; b < nlanes; ++b) S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;      // 1: the lane has a new best iterate
         for (int b = 0; b < nlanes; ++b) {
             LaneHost& L = LH[b];
             if (!L.live) continue;
             const double* hs = S.hostSc + (size_t)b * S_COUNT;
             const int chol_fixes = int(hs[S_CHOLFIX]);
+            // a hand-off between workgroups inside the factorisation (or the extended-precision triangular solve) was
+            // lost: its bounded poll expired and the block went on with stale data -- the numbers are void
+            if (chol_fixes >= CHOL_SYNC_LOST) throw HipError("internal error: an in-launch hand-off of the KKT factorisation timed out (device flag never raised)");
             SolveInfo& info = L.info;
             if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
                 // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
@@ -2748,7 +2755,6 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
             if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { finish(ST_PRIMAL_INFEASIBLE); continue; }
             if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { finish(ST_DUAL_INFEASIBLE); continue; }
-            S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;
             if (hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
                 // best iterate for the reduced-accuracy exit: residuals within the reduced tolerance,
                 // smallest gap measure (mirrors oracle/conic_ipm.py)
@@ -2766,17 +2772,16 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             if (L.wall >= WALL_ITERS) { finish(ST_NUMERICAL); continue; }
             any_live = true;
         }
-        if (any_best) {                                       // xbest = x / tau on the lanes with a new best iterate
+        if (any_best) {
+            // xbest = x / tau on the lanes with a new best iterate -- including a lane that max_iter (or the numerical
+            // wall) retires in this very iteration: its best_info is this iterate's, so xbest has to be as well (the
+            // new-best bits were cleared for every lane above and are set by the merit test alone, not by `live`)
             if (nlanes > 1) {
-                for (int b = 0; b < nlanes; ++b)
-                    if (!LH[b].live) S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;
                 MBFIR_HIP(hipMemcpyAsync(S.maskT + (MAX_SWEEPS + 1) * MAX_LANES, S.hostMask + (MAX_SWEEPS + 1) * MAX_LANES, sizeof(int) * MAX_LANES,
                                          hipMemcpyHostToDevice, st));
                 P.mask = S.mask_row(MAX_SWEEPS + 1);
             }
-            bool want = nlanes > 1;
-            for (int b = 0; b < nlanes && !want; ++b) want = LH[b].live && S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b];
-            if (want) hipLaunchKernelGGL(k_finish_x, lane_grid(dim3(S.nbN), nlanes), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
+            hipLaunchKernelGGL(k_finish_x, lane_grid(dim3(S.nbN), nlanes), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
             P.mask = S.mask_row(0);
         }
         if (!any_live) break;
@@ -3016,7 +3021,7 @@ void Solver::test_ddsolve(int n, int k, const double* Hh, const double* U, const
     DevBuf dflags(sizeof(int) * (2 * np / 32 + 8));
     MBFIR_HIP(hipMemsetAsync(dflags.p, 0, sizeof(int) * (2 * np / 32 + 8), S.st));
     dd_trsv_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
-                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st, dflags.as<int>(), 1);
+                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st, dflags.as<int>(), 1, df.as<int>());
     MBFIR_HIP(hipMemcpyAsync(B.data(), dB.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(Bl.data(), dBl.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(nfix, df.p, sizeof(int), hipMemcpyDeviceToHost, S.st));
