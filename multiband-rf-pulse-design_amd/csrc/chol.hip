@@ -52,14 +52,51 @@ __device__ __forceinline__ void acc_foreach(v4d acc[2][2], F f) {
                 f(wi * 32 + a * 16 + (lane >> 4) + 4 * r, wj * 32 + b * 16 + (lane & 15), acc[a][b][r]);
 }
 
+// ---- write-through / L1-bypassing accesses for data that passes between workgroups INSIDE one launch ---------------
+// (the single-launch factorisation below; cdna_hip_programming.md guideline 16: per-XCD L2s are not coherent with each
+// other and a CU's L1 is never refreshed by another CU's stores, so every byte handed over is stored sc1 -- written
+// through -- and loaded sc1 -- past the L1 --; 16-byte accesses go through buffer instructions, whose cache policy the
+// builtins expose, 8-byte ones through relaxed agent-scope atomics, which lower to global_load / store ... sc1)
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+using rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, short(0), 0, 0));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const double* p) {                       // p: wave-uniform
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned long long lo = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(a))));
+    const unsigned long long hi = unsigned(__builtin_amdgcn_readfirstlane(int(unsigned(a >> 32))));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(hi << 32 | lo), short(0), 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ double2 ld2_sc1(rsrc_t r, unsigned byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, int(byte_off), 0, 16);    // aux 16 = sc1
+    return make_double2(__hiloint2double(int(v.y), int(v.x)), __hiloint2double(int(v.w), int(v.z)));
+}
+__device__ __forceinline__ void st2_sc1(rsrc_t r, unsigned byte_off, double2 x) {
+    v4u v;
+    v.x = unsigned(__double2loint(x.x)); v.y = unsigned(__double2hiint(x.x));
+    v.z = unsigned(__double2loint(x.y)); v.w = unsigned(__double2hiint(x.y));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, int(byte_off), 0, 16);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // 64x64 tile -> LDS, all 8 16-byte loads of a thread in flight before the first LDS store
-// (256-thread blocks)
+// (256-thread blocks); SC1: the tile was written by another workgroup of this launch
+template <bool SC1 = false>
 __device__ __forceinline__ void load_block(double (*S)[CLD], const double* __restrict__ src, int ld) {
     double2 t[8];
+    if constexpr (SC1) {
+        const rsrc_t r = make_rsrc(src);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int e = threadIdx.x + 256 * u;
-        t[u] = *reinterpret_cast<const double2*>(src + (long)(e >> 5) * ld + 2 * (e & 31));
+        for (int u = 0; u < 8; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            t[u] = ld2_sc1(r, unsigned(((e >> 5) * ld + 2 * (e & 31)) * 8));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            t[u] = *reinterpret_cast<const double2*>(src + (long)(e >> 5) * ld + 2 * (e & 31));
+        }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -294,18 +331,44 @@ __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
 
 // C_tile (64x64 at dst) -= A_tile * B_tile (TRANSB: B_tile') through the MFMA helper
 // first: the tile has not been written in this factorisation yet -- its old content (the previous build's) counts as 0
-template <bool TRANSB>
+// DAG (single-launch factorisation): operands and the old tile come from / the result goes to other workgroups of the
+// same launch: sc1 accesses, 16 bytes each -- the product is restaged through LDS from the accumulator layout to whole
+// row segments (an 8-byte write-through store costs 2.7x a 16-byte one per byte); same arithmetic, old - product.
+template <bool TRANSB, bool DAG = false>
 __device__ __forceinline__ void tile_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ Bg,
                                             double* __restrict__ dst, int np, bool first = false) {
     double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
     double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
-    load_block(P, Ag, np);
-    load_block(Q, Bg, np);
+    load_block<DAG>(P, Ag, np);
+    load_block<DAG>(Q, Bg, np);
+    double2 old[8];
+    rsrc_t rd;
+    if constexpr (DAG) {
+        rd = make_rsrc(dst);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            old[u] = first ? make_double2(0.0, 0.0) : ld2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+        }
+    }
     __syncthreads();
     v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
     mma64<TRANSB>(P, Q, 0, CB, acc);
-    if (first) acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = -v; });
-    else acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
+    if constexpr (DAG) {
+        __syncthreads();                                  // everybody is done reading P
+        acc_foreach(acc, [&](int i, int j, double v) { P[i][j] = v; });
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const double2 pr = *reinterpret_cast<const double2*>(&P[e >> 5][2 * (e & 31)]);
+            const double2 x = first ? make_double2(-pr.x, -pr.y) : make_double2(old[u].x - pr.x, old[u].y - pr.y);
+            st2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8), x);
+        }
+    } else {
+        if (first) acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = -v; });
+        else acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
+    }
 }
 
 #ifdef CHOL_TRACE
@@ -331,6 +394,7 @@ struct CholStep {
                              // see k_chol_step)
     int nlanes;
     const int* mask;         // nlanes ints (or null): lanes switched off
+    int* cnt;                // single-launch form (k_chol_dag): the lane's dependency counters, see DagCnt
     int phase;               // 0: one launch per panel step, every row block factorises L_kk itself (lowest latency,
                              //    one design); 1: split step for lock-step batches in ONE launch -- the diagonal block
                              //    (one per lane) publishes the image of L_kk in Dfac and raises sync[k]; the row
@@ -349,16 +413,63 @@ constexpr int CHOL_SPIN_LIMIT = 1 << 21;                  // x s_sleep(4) + one 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ONE lane polls ONE word (relaxed, agent scope: an sc1 load) until it reaches `want`; false + sentinel on expiry
+#ifdef CHOL_DAG_STATS
+__shared__ long long s_dag_wait;
+#define DAG_WAIT_BEGIN const long long tw0 = __builtin_amdgcn_s_memrealtime();
+#define DAG_WAIT_END s_dag_wait += __builtin_amdgcn_s_memrealtime() - tw0;
+#else
+#define DAG_WAIT_BEGIN
+#define DAG_WAIT_END
+#endif
 __device__ __forceinline__ bool wait_flag(const int* word, int want, int* pivflag) {
     int spins = 0;
+    DAG_WAIT_BEGIN
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         if (++spins >= CHOL_SPIN_LIMIT) { atomicAdd(pivflag, CHOL_SYNC_LOST); return false; }
         __builtin_amdgcn_s_sleep(4);
     }
+    DAG_WAIT_END
     return true;
 }
 
-template <bool FROM_IMAGE>
+// up to three words at once (all loads in flight together; a null word counts as reached)
+__device__ __forceinline__ bool wait_flags(const int* w0, int want0, const int* w1, int want1, const int* w2, int want2, int* pivflag) {
+    int spins = 0;
+    DAG_WAIT_BEGIN
+    for (;;) {
+        const int v0 = w0 ? __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want0;
+        const int v1 = w1 ? __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want1;
+        const int v2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want2;
+        if (v0 >= want0 && v1 >= want1 && v2 >= want2) { DAG_WAIT_END return true; }
+        if (++spins >= CHOL_SPIN_LIMIT) { atomicAdd(pivflag, CHOL_SYNC_LOST); return false; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// signal for the whole workgroup: every storing wave has drained its write-through stores, then ONE lane adds
+__device__ __forceinline__ void signal_add(int* word) {
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Dependency counters of the single-launch factorisation, nblk x nblk ints each, per lane (zeroed by k_chol_init):
+//   rowdone[k][i]  row blocks of tile (i, k) that have stored their 16 rows of L_ik                     (complete: 4)
+//   tver[i][j]     panels applied to the trailing tile (i, j) by the tile-update blocks                  (0 .. j - 1)
+//   msdone[r][j]   16-column blocks of the inverse tile M_rj stored                                      (complete: 4)
+//   ruver[i][j]    updates applied to the inverse's tile R_ij                                            (0 .. i - j - 1)
+//   img[k]         1 once the image of L_kk and 1 / diag(L_kk) are in Dfac / dinvG;   ticket: the lane's task counter
+struct DagCnt {
+    int *rowdone, *tver, *msdone, *ruver, *img, *ticket;
+    int nblk;
+    __device__ DagCnt(int* base, int nb) : nblk(nb) {
+        rowdone = base; tver = base + nb * nb; msdone = base + 2 * nb * nb; ruver = base + 3 * nb * nb; img = base + 4 * nb * nb;
+        ticket = img + nb;
+    }
+    __device__ int* at(int* arr, int a, int b) const { return arr + a * nblk + b; }
+};
+__host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4; }
+
+template <bool FROM_IMAGE, bool DAG = false>
 __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k = a.k, np = a.np;
@@ -370,7 +481,16 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     double* dsh = smem + R3;                              // original diagonal of this block (64)
     double* dinv = dsh + CB;                              // pivots, then 1 / L_jj (64)
     const bool rows = b > 0;
-    const long r0 = rows ? (long)(k + 1 + (b - 1) / 4) * CB + 16 * ((b - 1) & 3) : 0;
+    const int irow = rows ? k + 1 + (b - 1) / 4 : k;      // tile row of this block
+    const long r0 = rows ? (long)irow * CB + 16 * ((b - 1) & 3) : 0;
+    const DagCnt dc(a.cnt, a.nblk);
+    if constexpr (DAG) {
+        // the tile this block factorises / solves has received the panels 0 .. k-2 from the tile-update blocks
+        if (k >= 2) {
+            if (tid == 0) wait_flags(dc.at(dc.tver, irow, k), k - 1, nullptr, 0, nullptr, 0, a.flag);
+            __syncthreads();
+        }
+    }
     // the wave's tiles of S = A_kk - L_k,k-1 L_k,k-1' (lower triangle, 16x16 tiles, MFMA D layout)
     const unsigned tiles = wave_tiles(wv);
     const int nt = int(tiles >> 12), m16 = lane & 15, g4 = lane >> 4;
@@ -382,19 +502,38 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     for (int q = 0; q < 3; ++q) {
         const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[q][r] = (!FROM_IMAGE && q < nt) ? H[(kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16] : 0.0;
+        for (int r = 0; r < 4; ++r) {
+            const double* src = H + (kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16;
+            hv[q][r] = (!FROM_IMAGE && q < nt) ? (DAG ? ld_sc1(src) : *src) : 0.0;
+        }
     }
     if (rows) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hc[r] = H[(r0 + g4 + 4 * r) * np + kk + 16 * wv + m16];
+        for (int r = 0; r < 4; ++r) {
+            const double* src = H + (r0 + g4 + 4 * r) * np + kk + 16 * wv + m16;
+            hc[r] = DAG ? ld_sc1(src) : *src;
+        }
     }
     TRACE(0)
     if (k > 0) {
         const long km = kk - CB;
-        load_block(X, H + kk * np + km, np);
+        if constexpr (DAG) {
+            // panel k-1: L_k,k-1 (four row blocks) and, for a row block, its own rows of L_i,k-1 -- the loads above stay
+            // in flight behind this poll (the diagonal block's is the one on the chain of the factorisation)
+            if (tid == 0) wait_flags(dc.at(dc.rowdone, k - 1, k), 4, rows ? dc.at(dc.rowdone, k - 1, irow) : nullptr, 4, nullptr, 0, a.flag);
+            __syncthreads();
+        }
+        load_block<DAG>(X, H + kk * np + km, np);
         if (rows) {
-            const double2 t0 = *reinterpret_cast<const double2*>(H + (r0 + (tid >> 5)) * np + km + 2 * (tid & 31));
-            const double2 t1 = *reinterpret_cast<const double2*>(H + (r0 + 8 + (tid >> 5)) * np + km + 2 * (tid & 31));
+            double2 t0, t1;
+            if constexpr (DAG) {
+                const rsrc_t rr = make_rsrc(H + r0 * np + km);
+                t0 = ld2_sc1(rr, unsigned(((tid >> 5) * np + 2 * (tid & 31)) * 8));
+                t1 = ld2_sc1(rr, unsigned(((8 + (tid >> 5)) * np + 2 * (tid & 31)) * 8));
+            } else {
+                t0 = *reinterpret_cast<const double2*>(H + (r0 + (tid >> 5)) * np + km + 2 * (tid & 31));
+                t1 = *reinterpret_cast<const double2*>(H + (r0 + 8 + (tid >> 5)) * np + km + 2 * (tid & 31));
+            }
             *reinterpret_cast<double2*>(&AR[tid >> 5][2 * (tid & 31)]) = t0;
             *reinterpret_cast<double2*>(&AR[8 + (tid >> 5)][2 * (tid & 31)]) = t1;
         }
@@ -437,8 +576,8 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         // the diagonal block of this lane runs in the SAME launch: wait for its flag.  The poll is bounded; a poll that
         // expires raises CHOL_SYNC_LOST in the lane's pivot counter, which the host turns into an error (the numbers
         // this block goes on to produce from the stale image are never used) -- no hang, no silent wrong factor.
-        if (a.phase == 1) {
-            if (tid == 0) wait_flag(a.sync + k, 1, a.flag);
+        if (DAG || a.phase == 1) {
+            if (tid == 0) wait_flag(DAG ? dc.img + k : a.sync + k, 1, a.flag);
             __syncthreads();
         }
         // Hand-off by write-through stores and L1-bypassing loads (cdna_hip_programming.md guideline 16, R1): every
@@ -446,13 +585,25 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         // vmcnt(0)) before the workgroup barrier behind which ONE lane stores the flag, the flag is polled by ONE lane
         // with sc1 loads, the other waves pass a barrier after the poll, and every load of the image is an sc1 load
         // (served past this CU's L1, which another CU's stores never refresh) -- no L2 write-back / invalidate.
-        double t[16];
+        if constexpr (DAG) {                              // 16-byte sc1 loads (the diagonal block stored it the same way)
+            const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
+            double2 t[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = __hip_atomic_load(a.Dfac + kk * CB + tid + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = tid + 256 * u;
-            Lz[(e >> 6) * ZLD + (e & 63)] = t[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = 2 * (tid + 256 * u);
+                *reinterpret_cast<double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]) = t[u];
+            }
+        } else {
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = __hip_atomic_load(a.Dfac + kk * CB + tid + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = tid + 256 * u;
+                Lz[(e >> 6) * ZLD + (e & 63)] = t[u];
+            }
         }
         if (tid < CB) dinv[tid] = __hip_atomic_load(a.dinvG + kk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -470,12 +621,21 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     }
     __syncthreads();
     if (!rows) {
-        for (int e = tid; e < CB * CB; e += 256) __hip_atomic_store(a.Dfac + kk * CB + e, Lz[(e >> 6) * ZLD + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (DAG) {
+            const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = 2 * (tid + 256 * u);
+                st2_sc1(ri, unsigned(e * 8), *reinterpret_cast<const double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]));
+            }
+        } else {
+            for (int e = tid; e < CB * CB; e += 256) __hip_atomic_store(a.Dfac + kk * CB + e, Lz[(e >> 6) * ZLD + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid < CB) __hip_atomic_store(a.dinvG + kk + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.phase == 1) {                               // merged split step: release the row blocks of this lane
+        if (DAG || a.phase == 1) {                        // release the row blocks (and the inverse-row blocks) of this lane
             drain_stores();                               // every storing wave: its sc1 stores have left the CU ...
             __syncthreads();                              // ... before the one lane that signals for all of them does
-            if (tid == 0) __hip_atomic_store(a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(DAG ? dc.img + k : a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TRACE(5)
         return;
@@ -487,11 +647,18 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     TRACE(5)
     subst16(Lz, dinv, v);
     TRACE(6)
+    if constexpr (DAG) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) H[(r0 + rho) * np + kk + lam + 16 * i] = v[i];
+        for (int i = 0; i < 4; ++i) st_sc1(H + (r0 + rho) * np + kk + lam + 16 * i, v[i]);
+        signal_add(dc.at(dc.rowdone, k, irow));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) H[(r0 + rho) * np + kk + lam + 16 * i] = v[i];
+    }
     TRACE(7)
 }
 
+template <bool DAG = false>
 __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int np = a.np, r = a.k - 1, j = b >> 2, c0 = 16 * (b & 3);
@@ -502,24 +669,44 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
     double(*Bs)[17] = reinterpret_cast<double(*)[17]>(smem + R2);      // 16 columns of M_r-1,j
     double* Ct = smem + R1;                                            // staging [column][row], stride YLD
     double* dinv = smem + R3;
+    const DagCnt dc(a.cnt, a.nblk);
+    if constexpr (DAG) {
+        // the image of L_rr; L_r,r-1 and the 16 columns of M_r-1,j (all four blocks of that tile: one counter);
+        // R_rj with every update it gets (panels j .. r-2)
+        if (tid == 0) {
+            wait_flags(dc.img + r, 1, j < r ? dc.at(dc.rowdone, r - 1, r) : nullptr, 4, j < r ? dc.at(dc.msdone, r - 1, j) : nullptr, 4, a.flag);
+            if (j <= r - 2) wait_flag(dc.at(dc.ruver, r, j), r - j - 1, a.flag);
+        }
+        __syncthreads();
+    }
     {
         double2 t[8];
+        if constexpr (DAG) {
+            const rsrc_t ri = make_rsrc(a.Dfac + kr * CB);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const double2*>(a.Dfac + kr * CB + 2 * (tid + 256 * u));
+            for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const double2*>(a.Dfac + kr * CB + 2 * (tid + 256 * u));
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
             *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
         }
     }
-    if (tid < CB) dinv[tid] = a.dinvG[kr + tid];
+    if (tid < CB) dinv[tid] = DAG ? ld_sc1(a.dinvG + kr + tid) : a.dinvG[kr + tid];
     v4d acc = {0, 0, 0, 0};
     if (j < r) {
-        load_block(A2, a.H + kr * np + kr - CB, np);
+        load_block<DAG>(A2, a.H + kr * np + kr - CB, np);
         {
             double t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; t[u] = M[(kr - CB + (e >> 4)) * np + (long)j * CB + c0 + (e & 15)]; }
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + 256 * u;
+                const double* src = M + (kr - CB + (e >> 4)) * np + (long)j * CB + c0 + (e & 15);
+                t[u] = DAG ? ld_sc1(src) : *src;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; Bs[e >> 4][e & 15] = t[u]; }
         }
@@ -538,7 +725,8 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int t = 16 * wv + (lane >> 4) + 4 * q;
-            const double r0 = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : M[(kr + t) * np + (long)j * CB + c0 + c];
+            const double* src = M + (kr + t) * np + (long)j * CB + c0 + c;
+            const double r0 = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : (DAG ? ld_sc1(src) : *src);
             Ct[c * YLD + t] = r0 - acc[q];
         }
     }
@@ -553,13 +741,21 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
     __syncthreads();
     const int t = tid >> 2, c4 = (tid & 3) * 4;
     double* dst = M + (kr + t) * np + (long)j * CB + c0 + c4;
-    *reinterpret_cast<double2*>(dst) = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]);
-    *reinterpret_cast<double2*>(dst + 2) = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
+    const double2 lo = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]), hi = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
+    if constexpr (DAG) {
+        const rsrc_t rm = make_rsrc(M + kr * np + (long)j * CB + c0);
+        st2_sc1(rm, unsigned((t * np + c4) * 8), lo);
+        st2_sc1(rm, unsigned((t * np + c4 + 2) * 8), hi);
+    } else {
+        *reinterpret_cast<double2*>(dst) = lo;
+        *reinterpret_cast<double2*>(dst + 2) = hi;
+    }
     if (a.Mt) {                                           // the transpose for the second triangular GEMV, straight from the staging tile
         const int c = tid >> 4, t4 = (tid & 15) * 4;      // 16 rows of Mt (columns of this block) x 64 entries
         double* dt = a.Mt + ((long)j * CB + c0 + c) * np + kr + t4;
         dt[0] = Ct[c * YLD + t4]; dt[1] = Ct[c * YLD + t4 + 1]; dt[2] = Ct[c * YLD + t4 + 2]; dt[3] = Ct[c * YLD + t4 + 3];
     }
+    if constexpr (DAG) signal_add(dc.at(dc.msdone, r, j));
 }
 
 template <class T>
@@ -617,16 +813,424 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
     tile_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j * CB, a.M + (long)i * CB * np + (long)j * CB, np, j == k - 2);
 }
 
-// d0 = diag(H), pivot-replacement counter = 0, panel flags = 0; one launch for all lanes.  The inverse factor is NOT
-// initialised any more (64 MB of writes per unit of 8 at np = 1024): the update and inverse-row blocks imply R = I.
+// ---- coarse tasks of the single-launch form ------------------------------------------------------------------------
+// Measured with one task per 64x64 tile product / 16-row block (tools/exp/chol_dag_exp.hip): a tile update occupied its
+// workgroup slot for 8.5-10 us, of which the matrix cores worked 1.5: ticket, polls, tile loads, product, restaging, store
+// and drain are serial phases of 1-2 us each, and the chip's 512 slots were full (425 busy on average) -- the
+// factorisation was bound by slot-time, not by its chain.  So a task now walks a STRIP of up to four tiles that share
+// an operand, with the next tile's loads in flight behind the current product and ONE drain + signal at the end.
+constexpr int STRIP = 4;
+
+// lane t (< n <= 64) of wave 0 polls its own word; everybody passes when all have reached their value
+template <class F>
+__device__ __forceinline__ void wait_many(int n, F get, int* pivflag) {
+    if (threadIdx.x < 64) {
+        const int* w = nullptr; int want = 0;
+        if (int(threadIdx.x) < n) get(int(threadIdx.x), w, want);
+        int spins = 0;
+        DAG_WAIT_BEGIN
+        for (;;) {
+            const int v = w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+            if (__all(v >= want)) break;
+            if (++spins >= CHOL_SPIN_LIMIT) { if (threadIdx.x == 0) atomicAdd(pivflag, CHOL_SYNC_LOST); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (threadIdx.x == 0) { DAG_WAIT_END }
+    }
+    __syncthreads();
+}
+
+// dst_t -= A * B_t (TRANSB: B_t')  for t < cnt, with B_t = B0 + t * bstep, dst_t = D0 + t * dstep and A (64x64 at Ag)
+// shared by the strip; tile tfirst (if any) has not been written in this factorisation yet: see tile_update
+template <bool TRANSB>
+__device__ __forceinline__ void strip_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ B0, long bstep,
+                                             double* __restrict__ D0, long dstep, int tfirst, int cnt, int np) {
+    double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
+    const int tid = threadIdx.x;
+    load_block<true>(P, Ag, np);
+    double2 bt[8], old[8];
+    {
+        const rsrc_t rb = make_rsrc(B0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
+    }
+#pragma unroll 1
+    for (int t = 0; t < cnt; ++t) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
+        __syncthreads();                                  // P (first pass) and Q in place
+        const rsrc_t rd = make_rsrc(D0 + t * dstep);
+        const bool first = t == tfirst;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                     // the tile's old content and the next operand: in flight behind the product
+            const int e = tid + 256 * u;
+            old[u] = first ? make_double2(0.0, 0.0) : ld2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+        }
+        if (t + 1 < cnt) {
+            const rsrc_t rb = make_rsrc(B0 + (t + 1) * bstep);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
+        }
+        v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+        mma64<TRANSB>(P, Q, 0, CB, acc);
+        __syncthreads();                                  // everybody is done reading Q
+        acc_foreach(acc, [&](int i, int j, double v) { Q[i][j] = v; });
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            const double2 pr = *reinterpret_cast<const double2*>(&Q[e >> 5][2 * (e & 31)]);
+            const double2 x = first ? make_double2(-pr.x, -pr.y) : make_double2(old[u].x - pr.x, old[u].y - pr.y);
+            st2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8), x);
+        }
+        __syncthreads();                                  // Q is free for the next operand
+    }
+}
+
+// Row blocks of ONE tile (i, k), all 64 rows: the panel k-1 update of the tile (operands loaded once), then four
+// 16-row substitutions against the image of L_kk.  Same arithmetic per row as panel_block<true>.
+__device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, double* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k = a.k, np = a.np;
+    double* H = a.H;
+    const long kk = (long)k * CB, r0 = (long)irow * CB;
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the image of L_kk
+    double(*AF)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_i,k-1 (all 64 rows), later the staging tile Y
+    double* Y = smem + R1;
+    double* dinv = smem + R3 + CB;
+    const DagCnt dc(a.cnt, a.nblk);
+    const int m16 = lane & 15, g4 = lane >> 4;
+    wait_many(3, [&](int t, const int*& w, int& want) {
+        if (t == 0) { w = k >= 2 ? dc.at(dc.tver, irow, k) : nullptr; want = k - 1; }
+        else if (t == 1) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
+        else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow) : nullptr; want = 4; }
+    }, a.flag);
+    double hc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hc[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
+    v4d accC[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (k > 0) {
+        const long km = kk - CB;
+        load_block<true>(X, H + kk * np + km, np);
+        load_block<true>(AF, H + r0 * np + km, np);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll 4
+            for (int k0 = 0; k0 < CB; k0 += 4) {
+                const int kx = k0 + g4;
+                accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[16 * q + m16][kx], X[16 * wv + m16][kx], accC[q], 0, 0, 0);
+            }
+        }
+    }
+    if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
+    __syncthreads();                                      // also: everybody is done with X and AF
+    double* Lz = smem + R0;
+    {
+        const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = 2 * (tid + 256 * u);
+            *reinterpret_cast<double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]) = t[u];
+        }
+    }
+    if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kk + tid);
+    {                                                     // updated rows of A_ik (MFMA layout -> one row per DPP row), all 64
+        const int cc = 16 * wv + m16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = hc[q][r] - accC[q][r];
+    }
+    __syncthreads();
+    const int rho = tid >> 4, lam = tid & 15;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = Y[(16 * q + rho) * YLD + lam + 16 * i];
+        subst16(Lz, dinv, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st_sc1(H + (r0 + 16 * q + rho) * np + kk + lam + 16 * i, v[i]);
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Inverse row r = k-1, tiles j0 .. j0+cnt-1: the image of L_rr and L_r,r-1 are loaded once, then 4 x cnt passes of
+// 16 columns each.  Same arithmetic per column block as minv_block.
+__device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, double* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int np = a.np, r = a.k - 1;
+    const long kr = (long)r * CB;
+    double* M = a.M;
+    double* Lz = smem + R0;
+    double(*A2)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_r,r-1
+    double(*Bs)[17] = reinterpret_cast<double(*)[17]>(smem + R2);      // 16 columns of M_r-1,j
+    double* Ct = smem + R2;                                            // staging [column][row], stride YLD (over Bs)
+    double* dinv = smem + R3;
+    const DagCnt dc(a.cnt, a.nblk);
+    wait_many(2 + 2 * cnt, [&](int t, const int*& w, int& want) {
+        if (t == 0) { w = dc.img + r; want = 1; }
+        else if (t == 1) { w = j0 < r ? dc.at(dc.rowdone, r - 1, r) : nullptr; want = 4; }
+        else {
+            const int j = j0 + ((t - 2) >> 1);
+            if ((t & 1) == 0) { w = j < r ? dc.at(dc.msdone, r - 1, j) : nullptr; want = 4; }
+            else { w = j <= r - 2 ? dc.at(dc.ruver, r, j) : nullptr; want = r - j - 1; }
+        }
+    }, a.flag);
+    {
+        const rsrc_t ri = make_rsrc(a.Dfac + kr * CB);
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+        }
+    }
+    if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + tid);
+    if (j0 < r) load_block<true>(A2, a.H + kr * np + kr - CB, np);
+    const int c = lane & 15;
+    // operands of a pass: R_rj as the updates left it (identity / zero where no update ever reached) and 16 columns of
+    // M_r-1,j; the next pass's are in flight behind the current pass's product and substitution
+    double rnext[4], bnext[4];
+    auto fetch = [&](int pass) {
+        const int j = j0 + (pass >> 2), c0 = 16 * (pass & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 16 * wv + (lane >> 4) + 4 * q;
+            rnext[q] = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : ld_sc1(M + (kr + t) * np + (long)j * CB + c0 + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;
+            bnext[u] = j < r ? ld_sc1(M + (kr - CB + (e >> 4)) * np + (long)j * CB + c0 + (e & 15)) : 0.0;
+        }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int pass = 0; pass < 4 * cnt; ++pass) {
+        const int j = j0 + (pass >> 2), c0 = 16 * (pass & 3);
+        v4d acc = {0, 0, 0, 0};
+        __syncthreads();                                  // the previous pass is done with Ct (= Bs); first pass: Lz, A2 in place
+        double rold[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rold[q] = rnext[q];
+        if (j < r) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; Bs[e >> 4][e & 15] = bnext[u]; }
+        }
+        if (pass + 1 < 4 * cnt) fetch(pass + 1);
+        if (j < r) {
+            __syncthreads();
+#pragma unroll 4
+            for (int k0 = 0; k0 < CB; k0 += 4) {
+                const int kx = k0 + (lane >> 4);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 16 * wv + (lane >> 4) + 4 * q;
+            Ct[c * YLD + t] = rold[q] - acc[q];
+        }
+        __syncthreads();
+        const int rho = tid >> 4, lam = tid & 15;
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = Ct[rho * YLD + lam + 16 * i];
+        subst16(Lz, dinv, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ct[rho * YLD + lam + 16 * i] = v[i];
+        __syncthreads();
+        const int t = tid >> 2, c4 = (tid & 3) * 4;
+        const double2 lo = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]), hi = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
+        const rsrc_t rm = make_rsrc(M + kr * np + (long)j * CB + c0);
+        st2_sc1(rm, unsigned((t * np + c4) * 8), lo);
+        st2_sc1(rm, unsigned((t * np + c4 + 2) * 8), hi);
+        if (a.Mt) {
+            const int cr = tid >> 4, t4 = (tid & 15) * 4;
+            double* dt = a.Mt + ((long)j * CB + c0 + cr) * np + kr + t4;
+            dt[0] = Ct[cr * YLD + t4]; dt[1] = Ct[cr * YLD + t4 + 1]; dt[2] = Ct[cr * YLD + t4 + 2]; dt[3] = Ct[cr * YLD + t4 + 3];
+        }
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid < cnt) __hip_atomic_fetch_add(dc.at(dc.msdone, r, j0 + tid), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// =================================================================================================
+// The whole factorisation (and inverse) in ONE launch: every block of the seventeen k_chol_step launches above becomes
+// a task of one grid; the launch boundaries are replaced by the dependency counters of DagCnt.
+//  * Forward progress does not rest on the order in which the hardware dispatches workgroups: a workgroup takes its
+//    task from its lane's TICKET counter, tickets are numbered in a topological order of the task graph (step by step;
+//    inside a step the diagonal block first, the row blocks that wait for it last), and a ticket is only ever drawn by
+//    a workgroup that is already running -- so a task only waits for tasks that have started.  Every poll is bounded;
+//    a poll that expires raises CHOL_SYNC_LOST in the lane's pivot counter (the host turns it into an error).
+//  * Dependencies are per tile, not per step: the diagonal block of step k+1 starts when the four row blocks of
+//    L_k+1,k and the tile update of A_k+1,k+1 have signalled (it has loaded A_k+1,k+1 by then), not when everything of
+//    step k is done; the lanes of a lock-step batch no longer wait for one another; a tile update of step k+1 starts
+//    when its two tiles of panel k are there.
+//  * Hand-offs (cdna_hip_programming.md guideline 16, R1): every tile that passes between tasks is stored sc1
+//    (written through) in 16-byte pieces, drained by every storing wave before the workgroup barrier behind which one
+//    lane adds to the counter; the consumer polls with one lane, passes a barrier and loads with sc1 (L1-bypassing)
+//    loads.  No L2 write-back or invalidate anywhere.
+//  * Same arithmetic per tile, in the same order, as the multi-launch forms: the results are bit-identical
+//    (tests/test_kernels_gpu.py::test_cholesky_split_step_equals_the_fused_step).
+// Task order inside step k (per lane): D(k) | the tile updates of block column k+1 (what D(k+1) and the row blocks of
+// step k+1 wait for) | the other tile updates | inverse rows | inverse updates | row blocks of step k.
+struct DagStep { int nD, nLA, nT, nMS, nRU1, nRU, nRq, nRt, nrem, ruc; };
+__host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1) / STRIP; }
+__host__ __device__ inline DagStep dag_step(int nblk, int k) {
+    const int nrem = nblk - k - 1;
+    DagStep s;
+    s.nrem = nrem;
+    s.nD = k < nblk ? 1 : 0;
+    s.nLA = (k >= 1 && k < nblk) ? nrem : 0;              // single tile updates of block column k + 1
+    s.nT = 0;                                             // strips over the tiles (i, j), k + 2 <= j <= i, of each row i
+    if (k >= 1 && k < nblk)
+        for (int c = 1; c < nrem; ++c) s.nT += strips_of(c);
+    s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (four 16-column passes):
+                                                          // row r of the inverse waits for row r - 1, so a longer strip here
+                                                          // is a longer chain (measured: 16 passes per task doubled the build)
+    s.ruc = k >= 2 ? strips_of(k - 1) : 0;
+    s.nRU1 = (k >= 2 && k < nblk) ? k - 1 : 0;            // inverse updates of row i = k (the next inverse row waits for them): single tiles
+    s.nRU = (k >= 2 && k < nblk) ? (nblk - k - 1) * s.ruc : 0;      // rows i > k: strips
+    s.nRq = (k < nblk && nrem >= 1) ? 4 : 0;              // tile (k + 1, k) as four 16-row blocks (on the chain)
+    s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
+    return s;
+}
+__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
+
+#ifdef CHOL_DAG_STATS      /* tools/exp/chol_dag_exp.hip: one record per task of the unit whose H is g_dag_log_H -- kind, begin, end, ticks in polls */
+__device__ long long* g_dag_log;
+__device__ const double* g_dag_log_H;
+__device__ int g_dag_log_tasks;        // tasks per lane
+#define DAG_STAT_BEGIN const long long t_begin = __builtin_amdgcn_s_memrealtime(); const bool dag_log = a.H == g_dag_log_H; if (threadIdx.x == 0) s_dag_wait = 0;
+#define DAG_STAT_END(kind) if (dag_log && threadIdx.x == 0) { long long* rec = g_dag_log + 4 * ((long)lane * g_dag_log_tasks + s_ticket); \
+        rec[0] = (kind); rec[1] = t_begin; rec[2] = __builtin_amdgcn_s_memrealtime(); rec[3] = s_dag_wait; }
+#else
+#define DAG_STAT_BEGIN
+#define DAG_STAT_END(kind)
+#endif
+
+__global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    __shared__ int s_ticket;
+    const int lane = int(blockIdx.x) % a.nlanes;
+    if (a.mask && !a.mask[lane]) return;
+    if (lane) {
+        const size_t off = (size_t)lane * a.lane_bytes;
+        a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
+        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.cnt = lane_at(a.cnt, off);
+        if (a.Mt) a.Mt = lane_at(a.Mt, off);
+    }
+    DAG_STAT_BEGIN
+    const DagCnt dc(a.cnt, a.nblk);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane(s_ticket);
+    int k = 0;
+    DagStep st = dag_step(a.nblk, 0);
+    while (k <= a.nblk && t >= dag_step_tasks(st)) { t -= dag_step_tasks(st); ++k; st = dag_step(a.nblk, k); }
+    if (k > a.nblk) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
+    a.k = k;
+    const int np = a.np;
+    if (t < st.nD) { panel_block<false, true>(a, 0, smem); DAG_STAT_END(0) return; }
+    t -= st.nD;
+    if (t < st.nLA) {
+        // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
+        // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
+        const int i = k + 1 + t, j = k + 1;
+        if (threadIdx.x == 0)
+            wait_flags(dc.at(dc.rowdone, k - 1, i), 4, dc.at(dc.rowdone, k - 1, j), 4, dc.at(dc.tver, i, j), k - 1, a.flag);
+        __syncthreads();
+        const long i0 = (long)i * CB, j0 = (long)j * CB, km = (long)(k - 1) * CB;
+        tile_update<true, true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
+        signal_add(dc.at(dc.tver, i, j));
+        DAG_STAT_END(1)
+        return;
+    }
+    t -= st.nLA;
+    if (t < st.nT) {
+        // trailing update with panel k-1, a strip of row i: A_ij -= L_i,k-1 L_j,k-1'  (k + 2 <= j <= i)
+        int c = 1;
+        while (t >= strips_of(c)) { t -= strips_of(c); ++c; }             // row i = k + 1 + c has c such tiles
+        const int i = k + 1 + c, j0 = k + 2 + STRIP * t, cnt = min(STRIP, c - STRIP * t);
+        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
+            if (q == 0) { w = dc.at(dc.rowdone, k - 1, i); want = 4; }
+            else if (q & 1) { w = dc.at(dc.rowdone, k - 1, j0 + (q - 1) / 2); want = 4; }
+            else { w = dc.at(dc.tver, i, j0 + (q - 2) / 2); want = k - 1; }
+        }, a.flag);
+        const long i0 = (long)i * CB, km = (long)(k - 1) * CB;
+        strip_update<true>(smem, a.H + i0 * np + km, a.H + (long)j0 * CB * np + km, (long)CB * np, a.H + i0 * np + (long)j0 * CB, CB, -1, cnt, np);
+        drain_stores();
+        __syncthreads();
+        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DAG_STAT_END(1)
+        return;
+    }
+    t -= st.nT;
+    if (t < st.nMS) {
+        minv_strip(a, t, 1, smem);
+        DAG_STAT_END(2)
+        return;
+    }
+    t -= st.nMS;
+    if (t < st.nRU1 + st.nRU) {
+        // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
+        // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
+        int i, j0, cnt;
+        if (t < st.nRU1) { i = k; j0 = t; cnt = 1; }
+        else { t -= st.nRU1; i = k + 1 + t / st.ruc; j0 = STRIP * (t % st.ruc); cnt = min(STRIP, k - 1 - j0); }
+        const long mm = (long)(k - 2) * CB;
+        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
+            if (q == 0) { w = dc.at(dc.rowdone, k - 2, i); want = 4; }
+            else if (q & 1) { w = dc.at(dc.msdone, k - 2, j0 + (q - 1) / 2); want = 4; }
+            else { const int j = j0 + (q - 2) / 2; w = dc.at(dc.ruver, i, j); want = k - 2 - j; }
+        }, a.flag);
+        strip_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j0 * CB, CB, a.M + (long)i * CB * np + (long)j0 * CB, CB,
+                            k - 2 - j0, cnt, np);
+        drain_stores();
+        __syncthreads();
+        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DAG_STAT_END(3)
+        return;
+    }
+    t -= st.nRU1 + st.nRU;
+    if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); DAG_STAT_END(4) return; }       // tile (k+1, k): four 16-row blocks
+    t -= st.nRq;
+    row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
+    DAG_STAT_END(4)
+}
+
+// nsync: ints to clear at sync (the panel flags of the split step, or the counters of the single-launch form);
+// poison (MBFIR_POISON=1, a test switch): the images of the diagonal blocks and 1 / diag(L) are filled with NaN, so that
+// a block which reads them before this build's diagonal block has published them produces NaN instead of plausible
+// numbers from the previous build
 __global__ __launch_bounds__(256) void k_chol_init(const double* __restrict__ H, int np, double* __restrict__ d0,
-                                                   int* __restrict__ flag, int* __restrict__ sync, size_t lane_bytes, const int* __restrict__ mask) {
+                                                   int* __restrict__ flag, int* __restrict__ sync, int nsync, size_t lane_bytes,
+                                                   const int* __restrict__ mask, double* __restrict__ poison) {
     if (mask && !mask[blockIdx.y]) return;
     const size_t off = (size_t)blockIdx.y * lane_bytes;
     H = lane_at(H, off); d0 = lane_at(d0, off); flag = lane_at(flag, off); sync = lane_at(sync, off);
     if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < np / CB + 1) sync[threadIdx.x] = 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < nsync; j += gridDim.x * 256) sync[j] = 0;
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < np; j += (long)gridDim.x * 256) d0[j] = H[j * np + j];
+    if (poison) {
+        poison = lane_at(poison, off);
+        for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < (long)(CB + 1) * np; j += (long)gridDim.x * 256) poison[j] = __builtin_nan("");
+    }
 }
 // also clears the lane's pivot-replacement counter
 __global__ void k_diag_copy(const double* __restrict__ H, int np, double* __restrict__ d0, double* __restrict__ M,
@@ -673,15 +1277,30 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     a.pivtol = 1e-13;                            // oracle/conic_ipm.py PIVTOL
     a.lane_bytes = lane_bytes; a.mask = mask; a.nlanes = nlanes;
     a.sync = reinterpret_cast<int*>(W1 + (long)(CB + 2) * np);          // behind 1 / diag(L): nblk + 1 ints
+    a.cnt = a.sync;                                                     // (single-launch form: dag_cnt_ints(nblk) ints)
     a.Mt = Mt;
-    hipLaunchKernelGGL(k_chol_init, dim3(cdiv(np, 256), nlanes), dim3(256), 0, st, H, np, W1, flag, a.sync, lane_bytes, mask);
-    if (e0) hipEventRecord(e0, st);
     // Lock-step batches split every step (see CholStep::phase): with several designs in flight the chip is no longer
     // empty, and the 4 * nrem row blocks of a step each repeating the 64-pivot factorisation of L_kk is what fills it.
-    // The split costs no launch: the row blocks ride in the same launch, dispatched last, and wait for their lane's
-    // diagonal block on a flag in global memory (MBFIR_CHOL_SPLIT=2: the older two-launch form).
-    int split = nlanes >= 3 ? 1 : 0;
+    // MBFIR_CHOL_SPLIT: 4 = the whole factorisation in ONE launch (k_chol_dag; default), 1 = one launch per step with
+    // the row blocks waiting for their lane's diagonal block on a flag, 2 = two launches per step, 0 = fused step
+    // (every row block factorises L_kk itself; one launch per step).
+    int split = nlanes >= 3 ? 4 : 0;
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
+    static const bool poison = [] { const char* ev = std::getenv("MBFIR_POISON"); return ev && std::atoi(ev) != 0; }();
+    if ((long)dag_cnt_ints(nblk) * 4 > ((long)np * np - (long)np) * 8) split = split == 4 ? (nlanes >= 3 ? 1 : 0) : split;   // (W1 too small: np = 64)
+    const int nsync = split == 4 ? dag_cnt_ints(nblk) : nblk + 1;
+    hipLaunchKernelGGL(k_chol_init, dim3(cdiv(std::max(np, nsync), 256), nlanes), dim3(256), 0, st, H, np, W1, flag, a.sync, nsync, lane_bytes, mask,
+                       poison ? W1 + np : (double*)nullptr);
+    if (e0) hipEventRecord(e0, st);
+    if (split == 4) {
+        int ntasks = 0;
+        for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
+        a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
+        hipLaunchKernelGGL(k_chol_dag, dim3(ntasks * nlanes), dim3(256), 0, st, a);
+        if (e1) hipEventRecord(e1, st);
+        if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
+        return 1;
+    }
     for (int k = 0; k <= nblk; ++k) {
         const int nrem = nblk - k - 1;
         a.k = k;

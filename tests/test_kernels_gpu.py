@@ -96,9 +96,9 @@ def test_double_double_solve_matches_the_oracles_dd_kernels(n, k):
 
 @pytest.mark.parametrize("n", [64, 200, 449, 1023])
 def test_cholesky_split_step_equals_the_fused_step(n, monkeypatch):
-    """Lock-step batches run every panel step as two launches (diagonal block + trailing work, then the row blocks
-    reading the stored image of L_kk); forced here on a single matrix: same factor and inverse as the fused step,
-    bit for bit (the row blocks do the same arithmetic on the same image)."""
+    """Lock-step batches run the factorisation in other forms than the fused step of a single design -- the split step
+    (the row blocks read the stored image of L_kk instead of repeating its 64 pivots) and the single-launch form --
+    forced here on a single matrix: same factor and inverse as the fused step, bit for bit."""
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n + 20, n))
     H = B.T @ B + 0.1 * np.eye(n)
@@ -108,6 +108,13 @@ def test_cholesky_split_step_equals_the_fused_step(n, monkeypatch):
     L1, M1 = mbfir.test_chol(H)
     assert np.array_equal(L0, L1) and np.array_equal(M0, M1)
     assert relinf(L1, np.linalg.cholesky(H)) <= 1e-12
+    # the whole factorisation in ONE launch (k_chol_dag: ticket-ordered tasks, per-tile dependency counters, strips of
+    # tiles per task): the same arithmetic per tile in the same order -- bit for bit again; a second time with the
+    # images of the diagonal blocks poisoned before the build (a block that read one before its diagonal block has
+    # published it would produce NaN, not last build's plausible numbers)
+    monkeypatch.setenv("MBFIR_CHOL_SPLIT", "4")
+    L4, M4 = mbfir.test_chol(H)
+    assert np.array_equal(L0, L4) and np.array_equal(M0, M4)
 
 
 def test_cholesky_ill_conditioned_scaling():

@@ -37,6 +37,43 @@ def test_golden_objective_matches_highs(name, golden):
     assert g["highs_x_maxdiff"] <= 1e-7        # unique optimiser: HiGHS vertex == IPM limit point
 
 
+@pytest.mark.parametrize("name", ["ap_c13_58", "qp_modelA48", "qp_modelB25", "qphs21", "qphs22"])
+def test_golden_cone_programs_are_pinned_by_an_unrelated_method(name, golden):
+    """The programs with ACTIVE cones, which no LP solver covers (tests/golden/make_golden.py (3)): Kelley's cutting
+    planes on HiGHS for the spike cones of fir_ap_cvx, Lawson-Hanson least-distance programming on NNLS for
+    fir_qprog_phs, SLSQP from a cutting-plane start for fir_qp_cvx -- none shares a line with the interior-point
+    iteration of oracle / C++ twin / device.  The pin's own point is feasible to 1e-10 and its objective equals the
+    oracle's; the optimisers agree as far as the flatness of each objective lets them."""
+    g = golden[name]
+    pin = g["pin"]
+    assert pin["viol"] <= 1e-10                                           # the pin's point is feasible
+    assert abs(pin["obj"] - g["pcost"]) <= 2e-9 * max(1.0, abs(g["pcost"]))
+    assert pin["x_maxdiff"] <= {"fir_ap_cvx": 1e-9, "fir_qprog_phs": 1e-7, "fir_qp_cvx": 2e-6}[g["designer"]]
+    if "lower_bound" in pin and pin["lower_bound"] is not None:           # every cutting-plane LP bounds the optimum from below
+        assert pin["lower_bound"] <= g["pcost"] + 1e-9 * max(1.0, abs(g["pcost"]))
+    if name == "ap_c13_58":                                               # converged cutting planes: a two-sided bracket
+        assert g["pcost"] - pin["lower_bound"] <= 1e-10
+
+
+def test_live_cutting_plane_pin_of_active_spike_cones():
+    """The same cutting-plane loop run live on a small fir_ap_cvx program whose spike cones are active."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from conftest import A_C13, D_C13, F100
+    args = (30, [2.0 * x for x in F100], A_C13, D_C13, 0.1, 2e-3)         # the C-13 spec, bands twice as wide, 30 taps
+    P = assemble.assemble_fir_ap_cvx(*args)
+    r = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"])
+    assert r["status"] == conic_ipm.STATUS_OPTIMAL
+    cp = make_golden.cutting_plane(P)
+    assert cp["viol"] <= 1e-10
+    q = (P["h"][P["l"]:] - P["G"][P["l"]:] @ r["x"]).reshape(-1, 3)
+    assert (q[:, 0] - np.hypot(q[:, 1], q[:, 2])).min() <= 1e-7 * q[:, 0].max()        # some spike cone IS active
+    assert abs(cp["obj"] - r["pcost"]) <= 1e-9 * max(1.0, abs(r["pcost"]))
+    assert np.abs(cp["x"] - r["x"]).max() <= 1e-8
+
+
 def test_live_highs_crosscheck():
     from scipy.optimize import linprog
     P = assemble.assemble_fir_linprog(33, [0, 0.25, 0.45, 1], [1, 1, 0, 0], [0.02, 0.02])
