@@ -1286,7 +1286,8 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     // (every row block factorises L_kk itself; one launch per step).
     int split = nlanes >= 3 ? 4 : 0;
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
-    static const bool poison = [] { const char* ev = std::getenv("MBFIR_POISON"); return ev && std::atoi(ev) != 0; }();
+    bool poison = false;
+    if (const char* ev = std::getenv("MBFIR_POISON")) poison = std::atoi(ev) != 0;
     if ((long)dag_cnt_ints(nblk) * 4 > ((long)np * np - (long)np) * 8) split = split == 4 ? (nlanes >= 3 ? 1 : 0) : split;   // (W1 too small: np = 64)
     const int nsync = split == 4 ? dag_cnt_ints(nblk) : nblk + 1;
     hipLaunchKernelGGL(k_chol_init, dim3(cdiv(std::max(np, nsync), 256), nlanes), dim3(256), 0, st, H, np, W1, flag, a.sync, nsync, lane_bytes, mask,

@@ -70,6 +70,10 @@ def test_row_sharded_bench_as_two_processes_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["shard"]["collectives_per_iteration"] > 0 and "hook" in d["shard"]["reductions"]
+    # the measured split into the replicated factorisation and the shardable row work, and the bound it implies
+    ps = d["shard"]["phase_split_ms"]
+    assert ps["replicated_factorisation"] > 0 and ps["shardable_row_work_one_gpu"] > 0 and ps["sharded_solve_total"] > 0
+    assert 1.0 <= d["shard"]["amdahl_bound_speedup_at_this_n_gpus"] <= 2.0
 
 
 def test_two_rank_batch_bench_carries_the_shard_leg():

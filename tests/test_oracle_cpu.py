@@ -74,6 +74,26 @@ def test_live_cutting_plane_pin_of_active_spike_cones():
     assert np.abs(cp["x"] - r["x"]).max() <= 1e-8
 
 
+def test_headline_fixture_is_certified_and_pinned_by_highs():
+    """tests/golden/c3_golden.json (the BASELINE headline instance: n=512, 16384 grid points, fir_ap_cvx form): the
+    oracle's point carries a primal-dual certificate re-evaluated in plain NumPy, and HiGHS -- on the LP relaxation,
+    whose optimum leaves every spike cone slack and therefore IS the SOCP optimum -- returns the same objective within
+    the two gaps and the same x to 2e-10."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_golden.json")) as fh:
+        g = json.load(fh)["c3_ap_512_16384"]
+    c = g["certificate"]
+    assert g["status"] == 0 and g["chol_fixes"] == 0
+    assert c["pres"] <= 1e-10 and c["dres"] <= 1e-9 and c["s_outside"] >= -1e-12 and c["z_outside"] >= -1e-12
+    assert 0 <= c["pcost"] - c["dcost"] <= 1e-9 * max(1.0, abs(c["pcost"])) and abs(c["sz"] - (c["pcost"] - c["dcost"])) <= 1e-12
+    assert g["highs_status"] == 0 and g["highs_cones_slack"] and g["min_spike_cone_slack"] > 0
+    assert abs(g["highs_obj"] - g["pcost"]) <= 1e-10                       # (objective ~6.5e-4: 3e-8 relative, inside relgap 9e-8)
+    assert c["dcost"] - 1e-12 <= g["highs_obj"] <= c["pcost"] + 1e-12      # HiGHS's optimum lies inside the oracle's own bracket
+    assert g["highs_x_maxdiff"] <= 1e-9
+    assert len(g["x"]) == 1024 and len(g["h_re"]) == 512
+
+
 def test_live_highs_crosscheck():
     from scipy.optimize import linprog
     P = assemble.assemble_fir_linprog(33, [0, 0.25, 0.45, 1], [1, 1, 0, 0], [0.02, 0.02])

@@ -126,3 +126,31 @@ def test_row_sharded_solve_on_a_tiny_grid_where_shards_disagree_about_the_lattic
         assert s == s0
         if s0 == "Solved":
             assert relinf(h, h0) <= 1e-6 and np.array_equal(h, res[0][0])
+
+
+def test_config5_row_sharded_at_full_size_in_loop_back():
+    """BASELINE config 5 AT SIZE in its row-sharded form (n=2048 taps, 131072 grid points, N=4096 unknowns), two
+    contexts on one GPU with the loop-back all-reduce: the same verdict, objective and taps as the unsharded solve, the
+    ranks' taps bit-identical, the sharded solve's own point feasible on independently assembled rows (every cone row
+    and 4000 random LP rows), and the number of collectives per iteration on record.  The first multi-GPU run of this
+    size is then not a blind one."""
+    from conftest import c13
+    n, m = 2048, 131072
+    f, a, d = c13(n, "duration")
+    args = (n, f, a, d, 0.1, 1e-3)
+    h0, s0, i0 = mbfir.fir_ap_cvx(*args, opts=mbfir.make_opts(grid_m=m), info=True)
+    assert s0 == "Solved" and i0["n_freq"] == m + 10
+    z0 = mbfir.get_context().last_solution(i0["n_unknowns"])
+    res = _run_sharded("fir_ap_cvx", args, 2, grid_m=m)
+    for r in res:
+        assert not isinstance(r, Exception), r
+    for h, s, info in res:
+        assert s == "Solved" and info["lattice"] == 1 and info["n_unknowns"] == 4096
+        assert abs(info["pcost"] - i0["pcost"]) <= 1e-8 * max(1.0, abs(i0["pcost"]))
+        assert info["pres"] <= 1e-8 and info["dres"] <= 1e-8 and (info["gap"] <= 1e-10 or info["relgap"] <= 1e-8)
+        assert np.array_equal(h, res[0][0])                       # every rank returns the same taps, bit for bit
+        assert relinf(h, h0) <= 1e-4                              # (the taps of this instance are determined to ~1e-5 by its gap)
+        assert abs(info["iters"] - i0["iters"]) <= 2
+        assert 0 < info["collectives"] <= 40 * (info["iters"] + 1)
+    assert sum(i["n_freq"] for _, _, i in res) == m + 10
+    assert abs(res[0][2]["pcost"] - (np.asarray(mbfir.assemble_dense(0, n, f, a, d, (0.1, 1e-3), m, rows=[0])[1]["c"]) @ z0)) <= 1e-9

@@ -3,7 +3,9 @@ environment switch (read at solve time), and the switched-off form is the refere
 
   MBFIR_FOLD=0         every frequency on its own instead of the +w / -w pairs of the folded lattice kernels
   MBFIR_SHARE_SEEDS=0  every lane builds and reads its own seed tables
-  MBFIR_CHOL_SPLIT=2   the split Cholesky step as two launches (no device flag); =0 the fused single-design step
+  MBFIR_CHOL_SPLIT     4 (default for lock-step batches): the factorisation in one launch; 1: one launch per panel step with
+                       the device flag; 2: the split step as two launches; 0: the fused single-design step
+  MBFIR_POISON=1       NaN in the diagonal-block images before every build (a stale read shows deterministically)
   MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
 """
 import os
@@ -75,8 +77,15 @@ def _batch(**envkw):
 
 
 def test_lock_step_switches_are_bit_identical():
+    """The default lock-step batch runs the factorisation in ONE launch (MBFIR_CHOL_SPLIT=4: ticket-ordered tasks,
+    dependency counters); the per-step forms (1: split step with the device flag, 2: two launches per step, 0: fused
+    step) do the same arithmetic per tile in the same order.  MBFIR_POISON=1 fills the images of the diagonal blocks
+    and 1 / diag(L) with NaN before every build: a block that read them before this build's diagonal block had
+    published them would carry NaN into the factor (instead of the previous build's plausible numbers), so
+    bit-identical taps under the poison show every in-launch hand-off of the image in order, deterministically."""
     base = _batch()
-    for kw in (dict(MBFIR_SHARE_SEEDS=0), dict(MBFIR_CHOL_SPLIT=2), dict(MBFIR_CHOL_SPLIT=0)):
+    for kw in (dict(MBFIR_SHARE_SEEDS=0), dict(MBFIR_CHOL_SPLIT=1), dict(MBFIR_CHOL_SPLIT=2), dict(MBFIR_CHOL_SPLIT=0), dict(MBFIR_POISON=1),
+               dict(MBFIR_POISON=1, MBFIR_CHOL_SPLIT=1)):
         other = _batch(**kw)
         for (h0, _, i0), (h1, _, i1) in zip(base, other):
             assert np.array_equal(h0, h1) and i0["pcost"] == i1["pcost"] and i0["iters"] == i1["iters"], kw

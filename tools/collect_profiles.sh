@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-2 profile collection on the GPU box (run through gpurun from the repo root).  Every rocprofv3 call puts the
+# Profile collection (round 3) on the GPU box (run through gpurun from the repo root).  Every rocprofv3 call puts the
 # program itself after `--` (python3 ...), counters go in their own passes with --kernel-trace only.
-#   bash tools/collect_profiles.sh            -> gpurun_out/r02/*  (then: python tools/rocprof_summary.py)
+#   bash tools/collect_profiles.sh            -> gpurun_out/r03/*  (then: python tools/rocprof_summary.py)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r02
+OUT=gpurun_out/r03
 mkdir -p $OUT
 UNIT="tools/gpu_lanes_one.py 512 16384 8 8 1 1"          # one lock-step unit of 8 headline designs, one stream
 # 1. the bench line itself, then the same command under the kernel trace
@@ -24,7 +24,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/dense_pmc_fetch -o dense -- python3 $DENSE > $OUT/dense_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dense_pmc_write -o dense -- python3 $DENSE > $OUT/dense_pmc_write.log 2>&1 || exit 1
 # the traces are hundreds of MB: condense them here, keep only the summaries (gpurun copies back <= 64 MiB)
-MBFIR_PROFILE_DST=gpurun_out/r02_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
-cp $OUT/bench.json $OUT/summary.log gpurun_out/r02_profiles/ 2>/dev/null
+MBFIR_PROFILE_DST=gpurun_out/r03_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
+cp $OUT/bench.json $OUT/summary.log gpurun_out/r03_profiles/ 2>/dev/null
 rm -rf $OUT
-ls -la gpurun_out/r02_profiles
+ls -la gpurun_out/r03_profiles

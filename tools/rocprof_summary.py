@@ -1,6 +1,6 @@
-"""Condense the rocprofv3 CSV output of tools/collect_profiles.sh (gpurun_out/r02) into the tracked files under
+"""Condense the rocprofv3 CSV output of tools/collect_profiles.sh (gpurun_out/r03) into the tracked files under
 profiles/: per-kernel duration statistics, per-kernel counter sums / per-launch averages, the MFMA-busy fractions and
-the HBM-side traffic per launch that bench.py reads (profiles/r02_pmc_traffic.json)."""
+the HBM-side traffic per launch that bench.py reads (profiles/r03_pmc_traffic.json)."""
 import csv
 import glob
 import json
@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+SRC = os.path.join(ROOT, "gpurun_out", "r03")
 DST = os.environ.get("MBFIR_PROFILE_DST", os.path.join(ROOT, "profiles"))
 
 
@@ -63,17 +63,17 @@ def counter_sums(d):
 def main():
     os.makedirs(DST, exist_ok=True)
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    for d, out in (("bench_trace", "r02_bench_kernel_stats.csv"), ("unit_trace", "r02_unit8_kernel_stats.csv"),
-                   ("dense_trace", "r02_dense_kernel_stats.csv")):
+    for d, out in (("bench_trace", "r03_bench_kernel_stats.csv"), ("unit_trace", "r03_unit8_kernel_stats.csv"),
+                   ("dense_trace", "r03_dense_kernel_stats.csv")):
         kernel_stats(d, out)
     if os.path.exists(os.path.join(SRC, "bench.json")):
-        with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, "r02_bench.json"), "w") as out:
+        with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, "r03_bench.json"), "w") as out:
             out.write(fh.read())
     report = {"commit": commit}
     for tag, lanes in (("unit", 8), ("dense", 1)):
         busy, insts = counter_sums(tag + "_pmc_busy"), counter_sums(tag + "_pmc_insts")
         fetch, write = counter_sums(tag + "_pmc_fetch"), counter_sums(tag + "_pmc_write")
-        with open(os.path.join(DST, "r02_pmc_mfma_%s.csv" % tag), "w") as fh:
+        with open(os.path.join(DST, "r03_pmc_mfma_%s.csv" % tag), "w") as fh:
             fh.write("kernel,calls,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,GRBM_GUI_ACTIVE,mfma_busy_over_sq_busy,"
                      "SQ_INSTS_VALU_MFMA_MOPS_F64,SQ_INSTS_VALU_MFMA_F64,SQ_INSTS_VALU,FETCH_SIZE_per_launch,WRITE_SIZE_per_launch\n")
             for k in sorted(busy, key=lambda kk: -busy[kk].get("SQ_BUSY_CYCLES", 0)):
@@ -87,13 +87,13 @@ def main():
 
 
 def finalize(dst, commit):
-    """profiles/r02_pmc_traffic.json (read by bench.py) from the per-kernel CSVs: k_chol_step from the lock-step unit of
+    """profiles/r03_pmc_traffic.json (read by bench.py) from the per-kernel CSVs: k_chol_step from the lock-step unit of
     8 designs, k_gram from the dense single design.  FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE is doubled
     for 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section).  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES
     (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 1024)."""
     report = {"commit": commit}
-    for tag, kern, key, lanes in (("unit", "k_chol_step", "k_chol_step", 8), ("dense", "k_gram", "k_gram", 1)):
-        path = os.path.join(dst, "r02_pmc_mfma_%s.csv" % tag)
+    for tag, kern, key, lanes in (("unit", "k_chol_dag", "k_chol", 8), ("dense", "k_gram", "k_gram", 1)):
+        path = os.path.join(dst, "r03_pmc_mfma_%s.csv" % tag)
         if not os.path.exists(path):
             continue
         with open(path) as fh:
@@ -109,21 +109,21 @@ def finalize(dst, commit):
                     report["%s_mfma_util" % key] = float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui / 8 * 1024) if gui else None
                     report["%s_mfma_flop_per_launch" % key] = float(r["SQ_INSTS_VALU_MFMA_MOPS_F64"]) * 512 / calls
                     report["%s_launches_profiled" % key] = int(calls)
-                    if key == "k_chol_step":
+                    if key == "k_chol":
                         report["lanes"] = lanes
                     break
-    with open(os.path.join(dst, "r02_pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(dst, "r03_pmc_traffic.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report, indent=1))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "finalize":
-        # local step: copy the box's summaries (gpurun_out/r02_profiles) into profiles/ and stamp the commit
+        # local step: copy the box's summaries (gpurun_out/r03_profiles) into profiles/ and stamp the commit
         import shutil
-        src = os.path.join(ROOT, "gpurun_out", "r02_profiles")
+        src = os.path.join(ROOT, "gpurun_out", "r03_profiles")
         dst = os.path.join(ROOT, "profiles")
-        for f in glob.glob(os.path.join(src, "r02_*")):
+        for f in glob.glob(os.path.join(src, "r03_*")):
             shutil.copy(f, dst)
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         finalize(dst, commit)
