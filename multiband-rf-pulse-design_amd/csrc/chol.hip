@@ -190,6 +190,38 @@ __device__ __forceinline__ void subst16(const double* __restrict__ Lz, const dou
     v[0] = v0 * dm0; v[1] = v1 * dm1; v[2] = v2 * dm2; v[3] = v3 * dm3;
 }
 
+// Two right-hand sides per thread, the two chains interleaved: a substitution step is a dependent mul -> DPP -> fma
+// chain of ~22 ns against ~3 ns of issue per instruction, so a second, independent chain rides in the shadow of the
+// first (same arithmetic per chain as subst16: bit-identical results)
+template <int J>
+__device__ __forceinline__ void subst16x2_steps(const double* __restrict__ lz, double dm0, double dm1, double dm2, double dm3,
+                                                double& a0, double& a1, double& a2, double& a3, double& b0, double& b1, double& b2, double& b3) {
+    if constexpr (J < 64) {
+        constexpr int I = J >> 4;
+        const double ca = I == 0 ? a0 * dm0 : I == 1 ? a1 * dm1 : I == 2 ? a2 * dm2 : a3 * dm3;
+        const double cb = I == 0 ? b0 * dm0 : I == 1 ? b1 * dm1 : I == 2 ? b2 * dm2 : b3 * dm3;
+        const double xa = row_bcast<(J & 15)>(ca), xb = row_bcast<(J & 15)>(cb);
+        const double* lr = lz + J * ZLD;
+        if constexpr (I < 2) {
+            const double2 lo = *reinterpret_cast<const double2*>(lr);
+            if constexpr (I == 0) { a0 -= xa * lo.x; b0 -= xb * lo.x; }
+            a1 -= xa * lo.y; b1 -= xb * lo.y;
+        }
+        const double2 hi = *reinterpret_cast<const double2*>(lr + 32);
+        if constexpr (I < 3) { a2 -= xa * hi.x; b2 -= xb * hi.x; }
+        a3 -= xa * hi.y; b3 -= xb * hi.y;
+        subst16x2_steps<J + 1>(lz, dm0, dm1, dm2, dm3, a0, a1, a2, a3, b0, b1, b2, b3);
+    }
+}
+__device__ __forceinline__ void subst16x2(const double* __restrict__ Lz, const double* __restrict__ dinv, double (&va)[4], double (&vb)[4]) {
+    const int lam = threadIdx.x & 15;
+    const double dm0 = dinv[lam], dm1 = dinv[lam + 16], dm2 = dinv[lam + 32], dm3 = dinv[lam + 48];
+    double a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3], b0 = vb[0], b1 = vb[1], b2 = vb[2], b3 = vb[3];
+    subst16x2_steps<0>(Lz + 2 * lam, dm0, dm1, dm2, dm3, a0, a1, a2, a3, b0, b1, b2, b3);
+    va[0] = a0 * dm0; va[1] = a1 * dm1; va[2] = a2 * dm2; va[3] = a3 * dm3;
+    vb[0] = b0 * dm0; vb[1] = b1 * dm1; vb[2] = b2 * dm2; vb[3] = b3 * dm3;
+}
+
 // ---- factorisation of the 64x64 diagonal block: four 16-column slabs -------------------------------
 // The trailing matrix lives in MFMA accumulators (the ten lower 16x16 tiles, dealt to the 4 waves by
 // the table below); per slab
@@ -888,16 +920,17 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
     }
 }
 
-// Row blocks of ONE tile (i, k), all 64 rows: the panel k-1 update of the tile (operands loaded once), then four
-// 16-row substitutions against the image of L_kk.  Same arithmetic per row as panel_block<true>.
+// Row blocks of ONE tile (i, k), all 64 rows: the panel k-1 update of the tile (operands loaded once), then two passes
+// of two interleaved 16-row substitutions against the image of L_kk.  Same arithmetic per row as panel_block<true>.
 __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k = a.k, np = a.np;
     double* H = a.H;
     const long kk = (long)k * CB, r0 = (long)irow * CB;
-    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the image of L_kk
-    double(*AF)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_i,k-1 (all 64 rows), later the staging tile Y
-    double* Y = smem + R1;
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the staging tile Y
+    double(*AF)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_i,k-1 (all 64 rows), later the image of L_kk
+    double* Y = smem + R0;
+    double* Lz = smem + R1;
     double* dinv = smem + R3 + CB;
     const DagCnt dc(a.cnt, a.nblk);
     const int m16 = lane & 15, g4 = lane >> 4;
@@ -906,11 +939,6 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
         else if (t == 1) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
         else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow) : nullptr; want = 4; }
     }, a.flag);
-    double hc[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hc[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
     v4d accC[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (k > 0) {
         const long km = kk - CB;
@@ -928,12 +956,21 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     }
     if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
     __syncthreads();                                      // also: everybody is done with X and AF
-    double* Lz = smem + R0;
-    {
+    {                                                     // the tile itself (MFMA layout) and the image of L_kk: in flight together
+        double hc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hc[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
         const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
         double2 t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+        const int cc = 16 * wv + m16;                     // updated rows of A_ik (MFMA layout -> one row per DPP row), all 64
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = hc[q][r] - accC[q][r];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = 2 * (tid + 256 * u);
@@ -941,40 +978,36 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
         }
     }
     if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kk + tid);
-    {                                                     // updated rows of A_ik (MFMA layout -> one row per DPP row), all 64
-        const int cc = 16 * wv + m16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = hc[q][r] - accC[q][r];
-    }
     __syncthreads();
     const int rho = tid >> 4, lam = tid & 15;
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        double v[4];
+    for (int q = 0; q < 4; q += 2) {                      // rows 16 q + rho and 16 (q + 1) + rho: two interleaved substitutions
+        double va[4], vb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = Y[(16 * q + rho) * YLD + lam + 16 * i];
-        subst16(Lz, dinv, v);
+        for (int i = 0; i < 4; ++i) { va[i] = Y[(16 * q + rho) * YLD + lam + 16 * i]; vb[i] = Y[(16 * q + 16 + rho) * YLD + lam + 16 * i]; }
+        subst16x2(Lz, dinv, va, vb);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st_sc1(H + (r0 + 16 * q + rho) * np + kk + lam + 16 * i, v[i]);
+        for (int i = 0; i < 4; ++i) {
+            st_sc1(H + (r0 + 16 * q + rho) * np + kk + lam + 16 * i, va[i]);
+            st_sc1(H + (r0 + 16 * q + 16 + rho) * np + kk + lam + 16 * i, vb[i]);
+        }
     }
     drain_stores();
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Inverse row r = k-1, tiles j0 .. j0+cnt-1: the image of L_rr and L_r,r-1 are loaded once, then 4 x cnt passes of
-// 16 columns each.  Same arithmetic per column block as minv_block.
+// Inverse row r = k-1, tiles j0 .. j0+cnt-1: the image of L_rr is loaded once, L_r,r-1 is held in REGISTERS in the
+// matrix cores' operand layout (no LDS tile), then 2 x cnt passes of 32 columns each -- two interleaved substitutions per
+// thread.  Same arithmetic per column block as minv_block.
 __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int np = a.np, r = a.k - 1;
     const long kr = (long)r * CB;
     double* M = a.M;
     double* Lz = smem + R0;
-    double(*A2)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_r,r-1
-    double(*Bs)[17] = reinterpret_cast<double(*)[17]>(smem + R2);      // 16 columns of M_r-1,j
-    double* Ct = smem + R2;                                            // staging [column][row], stride YLD (over Bs)
+    double(*Bs)[33] = reinterpret_cast<double(*)[33]>(smem + R1);          // 32 columns of M_r-1,j
+    double* Ct = smem + R1 + 64 * 33;                                      // staging [column][row], stride YLD, 32 columns
     double* dinv = smem + R3;
     const DagCnt dc(a.cnt, a.nblk);
     wait_many(2 + 2 * cnt, [&](int t, const int*& w, int& want) {
@@ -998,70 +1031,80 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
         }
     }
     if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + tid);
-    if (j0 < r) load_block<true>(A2, a.H + kr * np + kr - CB, np);
+    double af[16];                                        // L_r,r-1: row 16 wv + (lane & 15), columns 4 q + (lane >> 4)
+    if (j0 < r) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = ld_sc1(a.H + (kr + 16 * wv + (lane & 15)) * np + kr - CB + 4 * q + (lane >> 4));
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = 0.0;
+    }
     const int c = lane & 15;
-    // operands of a pass: R_rj as the updates left it (identity / zero where no update ever reached) and 16 columns of
+    // operands of a pass: R_rj as the updates left it (identity / zero where no update ever reached) and 32 columns of
     // M_r-1,j; the next pass's are in flight behind the current pass's product and substitution
-    double rnext[4], bnext[4];
+    double rnext[2][4], bnext[8];
     auto fetch = [&](int pass) {
-        const int j = j0 + (pass >> 2), c0 = 16 * (pass & 3);
+        const int j = j0 + (pass >> 1), c0 = 32 * (pass & 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = 16 * wv + (lane >> 4) + 4 * q;
-            rnext[q] = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : ld_sc1(M + (kr + t) * np + (long)j * CB + c0 + c);
-        }
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int q = 0; q < 4; ++q) {
+                const int t = 16 * wv + (lane >> 4) + 4 * q, cc = c0 + 16 * h + c;
+                rnext[h][q] = j == r ? (t == cc ? 1.0 : 0.0) : j == r - 1 ? 0.0 : ld_sc1(M + (kr + t) * np + (long)j * CB + cc);
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
-            bnext[u] = j < r ? ld_sc1(M + (kr - CB + (e >> 4)) * np + (long)j * CB + c0 + (e & 15)) : 0.0;
+            bnext[u] = j < r ? ld_sc1(M + (kr - CB + (e >> 5)) * np + (long)j * CB + c0 + (e & 31)) : 0.0;
         }
     };
     fetch(0);
 #pragma unroll 1
-    for (int pass = 0; pass < 4 * cnt; ++pass) {
-        const int j = j0 + (pass >> 2), c0 = 16 * (pass & 3);
-        v4d acc = {0, 0, 0, 0};
-        __syncthreads();                                  // the previous pass is done with Ct (= Bs); first pass: Lz, A2 in place
-        double rold[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rold[q] = rnext[q];
+    for (int pass = 0; pass < 2 * cnt; ++pass) {
+        const int j = j0 + (pass >> 1), c0 = 32 * (pass & 1);
+        v4d acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if (j < r) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = tid + 256 * u; Bs[e >> 4][e & 15] = bnext[u]; }
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; Bs[e >> 5][e & 31] = bnext[u]; }
         }
-        if (pass + 1 < 4 * cnt) fetch(pass + 1);
+        __syncthreads();                                  // Bs (and, first pass, Lz) in place; the previous pass is done with Ct
         if (j < r) {
-            __syncthreads();
-#pragma unroll 4
-            for (int k0 = 0; k0 < CB; k0 += 4) {
-                const int kx = k0 + (lane >> 4);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int kx = 4 * q + (lane >> 4);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], Bs[kx][c], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], Bs[kx][16 + c], acc[1], 0, 0, 0);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = 16 * wv + (lane >> 4) + 4 * q;
-            Ct[c * YLD + t] = rold[q] - acc[q];
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = 16 * wv + (lane >> 4) + 4 * q;
+                Ct[(16 * h + c) * YLD + t] = rnext[h][q] - acc[h][q];
+            }
+        if (pass + 1 < 2 * cnt) fetch(pass + 1);          // in flight behind the substitution
         __syncthreads();
         const int rho = tid >> 4, lam = tid & 15;
-        double v[4];
+        double va[4], vb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = Ct[rho * YLD + lam + 16 * i];
-        subst16(Lz, dinv, v);
+        for (int i = 0; i < 4; ++i) { va[i] = Ct[rho * YLD + lam + 16 * i]; vb[i] = Ct[(16 + rho) * YLD + lam + 16 * i]; }
+        subst16x2(Lz, dinv, va, vb);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Ct[rho * YLD + lam + 16 * i] = v[i];
+        for (int i = 0; i < 4; ++i) { Ct[rho * YLD + lam + 16 * i] = va[i]; Ct[(16 + rho) * YLD + lam + 16 * i] = vb[i]; }
         __syncthreads();
-        const int t = tid >> 2, c4 = (tid & 3) * 4;
-        const double2 lo = make_double2(Ct[c4 * YLD + t], Ct[(c4 + 1) * YLD + t]), hi = make_double2(Ct[(c4 + 2) * YLD + t], Ct[(c4 + 3) * YLD + t]);
-        const rsrc_t rm = make_rsrc(M + kr * np + (long)j * CB + c0);
-        st2_sc1(rm, unsigned((t * np + c4) * 8), lo);
-        st2_sc1(rm, unsigned((t * np + c4 + 2) * 8), hi);
-        if (a.Mt) {
-            const int cr = tid >> 4, t4 = (tid & 15) * 4;
-            double* dt = a.Mt + ((long)j * CB + c0 + cr) * np + kr + t4;
-            dt[0] = Ct[cr * YLD + t4]; dt[1] = Ct[cr * YLD + t4 + 1]; dt[2] = Ct[cr * YLD + t4 + 2]; dt[3] = Ct[cr * YLD + t4 + 3];
+        {
+            const int t = tid >> 2, c8 = (tid & 3) * 8;  // row t of the tile, columns c0 + c8 .. + 7
+            const rsrc_t rm = make_rsrc(M + kr * np + (long)j * CB + c0);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2)
+                st2_sc1(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
+        }
+        if (a.Mt) {                                       // the transpose for the second triangular GEMV, straight from the staging tile
+            const int cr = tid >> 3, t8 = (tid & 7) * 8;  // 32 rows of Mt (columns of this pass) x 64 entries
+            double* dt = a.Mt + ((long)j * CB + c0 + cr) * np + kr + t8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dt[u] = Ct[cr * YLD + t8 + u];
         }
     }
     drain_stores();

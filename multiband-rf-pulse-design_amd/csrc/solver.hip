@@ -2452,7 +2452,9 @@ int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
     if (o.shard_size > 1 || o.dense_trig || o.ddkkt_theta > 0) return 1;
     if (!lane_prep(Q, o)->Lt.ok) return 1;                // a grid / column set without the lattice structure: dense path
     const long np = round_up(Q.N(), 64);
-    return int(std::max<long>(1, std::min<long>(MAX_LANES, std::min<long>(32, 16384 / np))));
+    long cap = std::min<long>(32, 16384 / np);
+    if (const char* ev = std::getenv("MBFIR_MAX_LANES")) cap = std::atol(ev);          // (experiments: tools/sweep_lanes.sh)
+    return int(std::max<long>(1, std::min<long>(MAX_LANES, cap)));
 }
 
 int Solver::solve(const TrigProgram& Qfull, const SolveOpts& o, std::vector<double>& xout, SolveInfo& info) {

@@ -16,3 +16,5 @@ for _ in range(reps):
     print("n %d m %d: %d designs lanes %d streams %d: %.3f s = %.1f designs/s iters %d..%d ms_chol %.1f ms_gram %.1f ms_solve %.1f" % (
         n, m, count, lanes, streams, dt, count / dt, min(r[2]["iters"] for r in res), max(r[2]["iters"] for r in res),
         res[0][2]["ms_chol"], res[0][2]["ms_gram"], res[0][2]["ms_solve"]), flush=True)
+if os.environ.get("MBFIR_PRINT_ITERS"):
+    print("iters per design:", [r[2]["iters"] for r in res], flush=True)
