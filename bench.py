@@ -56,11 +56,13 @@ def _cpu_quota():
 
 def cpu_baseline(job, grid_m, gpu_iters, iters_cpu):
     """The oracle's C++ / OpenMP solver (oracle/cpu_ipm.cpp: the same algorithm as the GPU solver on the DENSE normal
-    matrix, AVX2 register-blocked Gram product) on this box's host cores, on ONE design of the batch.
+    matrix, register-blocked Gram product on the widest FMA the host has: rebuilt with -march=native on the box it is
+    timed on) on this box's host cores, on ONE design of the batch.
     iters_cpu < 0: the whole design to convergence on all cores, plus a 1-thread sample of 2 iterations extrapolated
     to the same iteration count; > 0: assembly + that many IPM iterations on all cores, extrapolated (labelled)."""
     from oracle import assemble, cpu_ipm
     warnings.filterwarnings("ignore", category=RuntimeWarning)
+    isa = cpu_ipm.use_native_build() or (cpu_ipm.isa() + " -- portable x86-64-v3 build, the -march=native rebuild failed on this box")
     n, f, a, d, obj, peak = job[1]
     t0 = time.perf_counter()
     P = assemble.assemble_fir_ap_cvx(n, f, a, d, obj, peak, grid_m)
@@ -96,6 +98,7 @@ def cpu_baseline(job, grid_m, gpu_iters, iters_cpu):
                   "to the full design" % (cores, t_asm, iters_cpu, gpu_iters, t_iter))
     return {"value": 1.0 / t_design, "unit": "designs/s", "cores": int(cores), "kind": "port", "sample": sample,
             "extrapolated": not full, "s_per_iteration": t_iter, "iters_per_s": 1.0 / t_iter,
+            "build": "g++ -O3 -march=native -fopenmp, compiled on this box: " + isa,
             "gram_fraction": r["seconds_factor"] / max(r["seconds_total"], 1e-9), "single_thread": single,
             "thread_trials_s_per_2_factorisations": {str(k): v for k, v in trials.items()}, "cpus_visible": avail, "cpu_quota": _cpu_quota(),
             "pcost": float(r["pcost"]) if full else None}
@@ -129,8 +132,8 @@ def s_lp_baseline(mbfir, ctx):
 
 
 def pmc_traffic():
-    """HBM-side bytes per k_chol_step launch from this round's PMC passes (tools/rocprof_summary.py writes
-    profiles/r02_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
+    """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from this round's PMC passes (tools/rocprof_summary.py writes
+    profiles/r03_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
@@ -147,7 +150,7 @@ def main():
     ap.add_argument("--grid-m", type=int, default=16384)
     ap.add_argument("--mode", choices=["batch", "shard"], default="batch")
     ap.add_argument("--designs", type=int, default=64, help="distinct designs per step and rank")
-    ap.add_argument("--lanes", type=int, default=8, help="designs per lock-step unit (mbfir_opts.lanes; 1 = one design per stream)")
+    ap.add_argument("--lanes", type=int, default=16, help="designs per lock-step unit (mbfir_opts.lanes; 1 = one design per stream)")
     ap.add_argument("--streams", type=int, default=4, help="contexts / HIP streams the units are spread over")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="cpu_baseline leg: -1 the oracle to convergence on one design "
                     "(1-3 minutes), k > 0 the first k iterations extrapolated, 0 skip")
@@ -320,24 +323,47 @@ def main():
         except Exception:
             peak_mfma = peak_valu = float("nan")
         ul = max(1, uinfo["lanes"])
-        # k_chol_step: one launch per 64-wide panel step of the Cholesky + triangular inverse, for all lanes of the
-        # unit at once; algorithmic flop per launch = lanes x 2/3 np^3 / (np/64 + 1)
+        # k_chol_dag: ONE launch per factorisation (Cholesky + triangular inverse) for all lanes of the unit at once.
+        # Algorithmic flop per launch: lanes x 2/3 np^3 with the explicit inverse the solves use (an implementation
+        # choice), lanes x 1/3 np^3 by SURVEY.md 8(d)'s F_chol = N^3 / 3 -- both fractions are printed.  Measured twice:
+        # one unit alone on the GPU (HIP events around its launches; agrees with rocprofv3) and under the bench's own load
+        # (the same events inside the timed batch, `streams` units in flight).
         chol_launches = uinfo["chol_launches"]
         chol_flop_per_launch = ul * uinfo["chol_flop"] * uinfo["builds"] / max(1, chol_launches)
         chol_avg_ms = uinfo["ms_chol"] / max(1, chol_launches)
         chol_ach = chol_flop_per_launch / (chol_avg_ms * 1e-3) / 1e12 if uinfo["ms_chol"] > 0 else 0.0
+        # under load: every unit of the timed batch reports the summed device time of its factorisations
+        seen, load_ms, load_launches, load_flop = set(), 0.0, 0, 0.0
+        for i in infos:
+            key = (i["ms_chol"], i["ms_solve"], i["lanes"])               # one entry per unit (its lanes share the figures)
+            if key in seen or i["chol_launches"] <= 0:
+                continue
+            seen.add(key)
+            load_ms += i["ms_chol"]; load_launches += i["chol_launches"]
+            load_flop += max(1, i["lanes"]) * i["chol_flop"] * i["builds"]
+        load_avg_ms = load_ms / max(1, load_launches)
+        load_ach = load_flop / max(load_ms * 1e-3, 1e-12) / 1e12
         pmc = pmc_traffic()
-        roof_chol = {"kernel": "k_chol_step (blocked Cholesky + triangular inverse, one launch per 64-wide panel for all %d lanes "
-                               "of a lock-step unit; tile products on v_mfma_f64_16x16x4_f64)" % ul, "bound": "mfma",
+        per_step = chol_launches > uinfo["builds"] + 1                     # (MBFIR_CHOL_SPLIT=0..2: one launch per panel step)
+        roof_chol = {"kernel": ("k_chol_step (one launch per 64-wide panel step" if per_step else "k_chol_dag (blocked Cholesky + triangular inverse of all "
+                                "%d lanes of a lock-step unit in ONE launch: ticket-ordered tasks, per-tile dependency counters" % ul) +
+                               "; tile products on v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": chol_ach, "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": chol_ach / PEAK_FP64_MATRIX_TF,
-                     "traffic": (pmc or {}).get("k_chol_step_bytes_per_launch") if infos[0]["n_unknowns"] == 1024 and ul == (pmc or {}).get("lanes") else None,
-                     "traffic_source": None if pmc is None else "profiles/r02_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
+                     "frac_survey_8d_factor_only": 0.5 * chol_ach / PEAK_FP64_MATRIX_TF,
+                     "achieved_under_load": load_ach, "frac_under_load": load_ach / PEAK_FP64_MATRIX_TF, "avg_launch_ms_under_load": load_avg_ms,
+                     "under_load_note": "per-unit rate with %d units in flight (each unit has the chip to itself only part of the time); "
+                                        "whole-chip rate = this x the units that overlap" % nstream,
+                     "traffic": (pmc or {}).get("k_chol_bytes_per_launch") if infos[0]["n_unknowns"] == 1024 and ul == (pmc or {}).get("lanes") and not per_step else None,
+                     "traffic_source": None if pmc is None else "profiles/r03_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
                                        "commit %s, %s lanes)" % (pmc.get("commit"), pmc.get("lanes")),
-                     "flop_per_launch": chol_flop_per_launch, "launches": chol_launches, "avg_launch_ms": chol_avg_ms, "lanes": ul,
-                     "note": "dependency-chain bound per design (1024 sequential pivots per build); the lanes of a lock-step unit "
-                             "fill the CUs the chain of one design leaves idle; measured on one unit alone on the GPU",
+                     "flop_per_launch": chol_flop_per_launch, "flop_per_launch_factor_only": 0.5 * chol_flop_per_launch,
+                     "launches": chol_launches, "avg_launch_ms": chol_avg_ms, "lanes": ul,
+                     "note": "two dependency chains per design (1024 sequential pivots; 16 inverse rows, each waiting for the one above); "
+                             "the lanes of a lock-step unit fill the CUs the chains of one design leave idle; measured on one unit alone on the GPU",
                      "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
-                     "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu}
+                     "register_only_mfma_loop_tflops": peak_mfma, "register_only_fma_loop_tflops": peak_valu,
+                     "microbenchmark_note": "a register-only loop of independent v_mfma_f64_16x16x4 (8 accumulators per wave, 4 waves per SIMD) "
+                                            "runs power-capped at a lower clock than kernels that wait on memory; it is NOT a peak (k_gram sustains more)"}
         gram_flop = uinfo["gram_flop"]
         if lattice:
             gram_ach = ul * gram_flop * uinfo["builds"] / (uinfo["ms_gram"] * 1e-3) / 1e12 if uinfo["ms_gram"] > 0 else 0.0
@@ -355,8 +381,7 @@ def main():
                          "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": gram_ach / PEAK_FP64_MATRIX_TF,
                          "traffic": None, "flop_per_launch": flop_per_launch, "launches": launches,
                          "avg_launch_ms": uinfo["ms_gram"] / max(1, launches),
-                         "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)",
-                         "peak_measured_mfma_f64": peak_mfma, "peak_measured_valu_f64": peak_valu}
+                         "peak_source": "AMD public MI355X fp64 matrix figure (not in MI355X_MICROARCH.md)"}
         dominant, other = (roof_chol, roof_gram) if uinfo["ms_chol"] >= uinfo["ms_gram"] else (roof_gram, roof_chol)
         others = [other]
         if dense_info is not None and dense_info["gram_launches"] > 0:
@@ -394,11 +419,13 @@ def main():
         if world == 1 and args.cpu_iters != 0:
             cb = cpu_baseline(jobs[0], args.grid_m, infos[0]["iters"], args.cpu_iters)
             out["cpu_baseline"] = cb
-            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            # (no headline ratio: the batch runs 64 designs at once on an O(Mf N) operator, the CPU leg one design on the
+            # dense O(Mf N^2) one; the like-for-like pair is the GPU's dense path against it, below)
             if dense_info is not None:
                 # like for like: the oracle forms the dense normal matrix, so does the GPU's dense path (one design, one stream)
                 out["cpu_baseline"]["gpu_dense_path_designs_per_s"] = 1e3 / dense_info["ms_total"]
                 out["cpu_baseline"]["gpu_dense_path_over_cpu"] = 1e3 / dense_info["ms_total"] / cb["value"]
+                out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["gpu_dense_path_over_cpu"]       # dense vs dense, one design each
                 if cb["pcost"] is not None:
                     out["cpu_baseline"]["pcost_gpu_vs_cpu"] = [infos[0]["pcost"], cb["pcost"]]
             out["cpu_baseline"]["s_lp_config1"] = s_lp_baseline(mbfir, ctx)

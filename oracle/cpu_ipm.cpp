@@ -217,6 +217,32 @@ inline void mk4x8(const double* A, int aoff, const double* Bq, int nr, double* C
     _mm256_storeu_pd(C, _mm256_add_pd(_mm256_loadu_pd(C), c30)); _mm256_storeu_pd(C + 4, _mm256_add_pd(_mm256_loadu_pd(C + 4), c31));
 }
 
+#ifdef __AVX512F__
+// the same product on 512-bit registers (built with -march=native on a machine that has them: oracle/Makefile,
+// _ref/libcpu_ipm_native.so): 8 x 8 block, 8 accumulators, one panel-row load and eight broadcast-FMAs per row; every
+// element sums its products in the same order as in mk4x8, so the two kernels agree bit for bit
+inline void mk8x8(const double* A, const double* Bq, int nr, double* C, int ldc) {
+    __m512d c0 = _mm512_setzero_pd(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    for (int r = 0; r < nr; ++r) {
+        const __m512d b = _mm512_loadu_pd(Bq + 8 * r);
+        const double* a = A + 8 * r;
+        c0 = _mm512_fmadd_pd(_mm512_set1_pd(a[0]), b, c0); c1 = _mm512_fmadd_pd(_mm512_set1_pd(a[1]), b, c1);
+        c2 = _mm512_fmadd_pd(_mm512_set1_pd(a[2]), b, c2); c3 = _mm512_fmadd_pd(_mm512_set1_pd(a[3]), b, c3);
+        c4 = _mm512_fmadd_pd(_mm512_set1_pd(a[4]), b, c4); c5 = _mm512_fmadd_pd(_mm512_set1_pd(a[5]), b, c5);
+        c6 = _mm512_fmadd_pd(_mm512_set1_pd(a[6]), b, c6); c7 = _mm512_fmadd_pd(_mm512_set1_pd(a[7]), b, c7);
+    }
+    const __m512d cs[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+    for (int i = 0; i < 8; ++i) _mm512_storeu_pd(C + (size_t)i * ldc, _mm512_add_pd(_mm512_loadu_pd(C + (size_t)i * ldc), cs[i]));
+}
+#endif
+extern "C" const char* cpu_ipm_isa(void) {
+#ifdef __AVX512F__
+    return "avx512f (8 x 8 zmm Gram kernel)";
+#else
+    return "avx2+fma (4 x 8 ymm Gram kernel)";
+#endif
+}
+
 void gram(const double* Bp, int R, int N, double* H) {
     const int npan = (N + 7) / 8, nt = (npan + 3) / 4, RB = 128;
     std::vector<std::pair<int, int>> tiles;
@@ -233,8 +259,12 @@ void gram(const double* Bp, int R, int N, double* H) {
                 const double* A = Bp + ((size_t)(pi0 + pa) * R + r0) * 8;
                 for (int pb = 0; pb < npj; ++pb) {
                     const double* Bq = Bp + ((size_t)(pj0 + pb) * R + r0) * 8;
+#ifdef __AVX512F__
+                    mk8x8(A, Bq, nr, C + (pa * 8) * 32 + pb * 8, 32);
+#else
                     mk4x8(A, 0, Bq, nr, C + (pa * 8) * 32 + pb * 8, 32);
                     mk4x8(A, 4, Bq, nr, C + (pa * 8 + 4) * 32 + pb * 8, 32);
+#endif
                 }
             }
         }

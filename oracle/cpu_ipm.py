@@ -13,16 +13,40 @@ _lib = None
 _dp = ctypes.POINTER(ctypes.c_double)
 
 
+def _bind(path):
+    L = ctypes.CDLL(path)
+    L.cpu_ipm_solve.restype = ctypes.c_int
+    L.cpu_ipm_solve.argtypes = ([ctypes.c_int, ctypes.c_int, _dp, _dp, _dp] + [ctypes.c_int] * 4 + [ctypes.c_double] * 3 +
+                                [ctypes.c_int, ctypes.c_int, _dp, _dp])
+    L.cpu_ipm_isa.restype = ctypes.c_char_p
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_PATH):
             subprocess.run(["make", "-C", _HERE, "_ref/libcpu_ipm.so"], check=True, capture_output=True)
-        _lib = ctypes.CDLL(_PATH)
-        _lib.cpu_ipm_solve.restype = ctypes.c_int
-        _lib.cpu_ipm_solve.argtypes = ([ctypes.c_int, ctypes.c_int, _dp, _dp, _dp] + [ctypes.c_int] * 4 + [ctypes.c_double] * 3 +
-                                       [ctypes.c_int, ctypes.c_int, _dp, _dp])
+        _lib = _bind(_PATH)
     return _lib
+
+
+def use_native_build():
+    """Rebuild the solver with -march=native ON THIS MACHINE (the one the timing runs on) and switch to it; returns the
+    instruction set the build selected, or None (and keeps the portable x86-64-v3 build) when the compiler is missing
+    or the rebuilt library does not load."""
+    global _lib
+    path = os.path.join(_HERE, "_ref", "libcpu_ipm_native.so")
+    try:
+        subprocess.run(["make", "-B", "-C", _HERE, "_ref/libcpu_ipm_native.so"], check=True, capture_output=True)
+        _lib = _bind(path)
+        return _lib.cpu_ipm_isa().decode()
+    except Exception:                                       # noqa: BLE001
+        return None
+
+
+def isa():
+    return lib().cpu_ipm_isa().decode()
 
 
 def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10, reltol=1e-8, refine=2, threads=0):

@@ -6,7 +6,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r03
 mkdir -p $OUT
-UNIT="tools/gpu_lanes_one.py 512 16384 8 8 1 1"          # one lock-step unit of 8 headline designs, one stream
+UNIT="tools/gpu_lanes_one.py 512 16384 16 16 1 1"          # one lock-step unit of 16 headline designs, one stream
 # 1. the bench line itself, then the same command under the kernel trace
 python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench_trace.log 2>&1 || exit 1

@@ -63,14 +63,14 @@ def counter_sums(d):
 def main():
     os.makedirs(DST, exist_ok=True)
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    for d, out in (("bench_trace", "r03_bench_kernel_stats.csv"), ("unit_trace", "r03_unit8_kernel_stats.csv"),
+    for d, out in (("bench_trace", "r03_bench_kernel_stats.csv"), ("unit_trace", "r03_unit16_kernel_stats.csv"),
                    ("dense_trace", "r03_dense_kernel_stats.csv")):
         kernel_stats(d, out)
     if os.path.exists(os.path.join(SRC, "bench.json")):
         with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, "r03_bench.json"), "w") as out:
             out.write(fh.read())
     report = {"commit": commit}
-    for tag, lanes in (("unit", 8), ("dense", 1)):
+    for tag, lanes in (("unit", 16), ("dense", 1)):
         busy, insts = counter_sums(tag + "_pmc_busy"), counter_sums(tag + "_pmc_insts")
         fetch, write = counter_sums(tag + "_pmc_fetch"), counter_sums(tag + "_pmc_write")
         with open(os.path.join(DST, "r03_pmc_mfma_%s.csv" % tag), "w") as fh:
@@ -92,7 +92,7 @@ def finalize(dst, commit):
     for 16-B/lane streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section).  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES
     (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 1024)."""
     report = {"commit": commit}
-    for tag, kern, key, lanes in (("unit", "k_chol_dag", "k_chol", 8), ("dense", "k_gram", "k_gram", 1)):
+    for tag, kern, key, lanes in (("unit", "k_chol_dag", "k_chol", 16), ("dense", "k_gram", "k_gram", 1)):
         path = os.path.join(dst, "r03_pmc_mfma_%s.csv" % tag)
         if not os.path.exists(path):
             continue
