@@ -35,7 +35,7 @@ SIGMA_MAX = 0.25              # cap of Mehrotra's centring parameter (see solve(
 # iteration's step was short (the gate looks at the PREVIOUS step so that the device solver, which talks to its host
 # once per iteration, can take the same decision), aimed at a step CORR_DALPHA longer, the trial products pulled into
 # [CORR_BMIN, CORR_BMAX] x sigma mu, accepted when the step grows by at least CORR_ACCEPT x CORR_DALPHA.
-CORR_GATE = 0.7
+CORR_GATE = 0.0                # 0: off (the default until the C++ twin and the device solver carry the same step)
 CORR_DALPHA = 0.3
 CORR_BMIN, CORR_BMAX = 0.1, 10.0
 CORR_ACCEPT = 0.1
