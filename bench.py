@@ -274,7 +274,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    lanes = 1 if args.dense else max(1, args.lanes)
+    lanes = max(1, args.lanes)                   # (the dense path batches too; the solver caps the lanes by the memory of the trig matrices)
     opts = mbfir.make_opts(grid_m=args.grid_m, dense_trig=int(args.dense), lanes=lanes)
     jobs = sweep_jobs(mbfir, args.n, args.designs)
 
@@ -374,8 +374,11 @@ def main():
                          "note": "replaces the dense Gram products (17.2 GFLOP per design and build on the matrix cores) by "
                                  "%.2f GFLOP of recurrences; peak = fp64 vector peak (same figure as the matrix peak)" % (gram_flop / 1e9)}
         else:
-            launches = uinfo["gram_launches"]
-            flop_per_launch = gram_flop / max(1, launches // max(1, uinfo["builds"]))
+            # dense path: the events bracket the k_gram launches of ALL live lanes of a build (one launch per lane and weight
+            # vector); lanes that finish early drop out, so with ul > 1 this is a lower bound of the per-launch rate -- the
+            # exact single-launch figure is the dense single-design leg below (roofline_other)
+            launches = uinfo["gram_launches"] * ul
+            flop_per_launch = gram_flop / max(1, uinfo["gram_launches"] // max(1, uinfo["builds"]))
             gram_ach = flop_per_launch / (uinfo["ms_gram"] / max(1, launches) * 1e-3) / 1e12 if uinfo["ms_gram"] > 0 else 0.0
             roof_gram = {"kernel": "k_gram (A' D A, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": gram_ach,
                          "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s", "frac": gram_ach / PEAK_FP64_MATRIX_TF,

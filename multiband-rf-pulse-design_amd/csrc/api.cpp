@@ -375,7 +375,20 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
             // enough units to occupy every context, no more lanes per unit than the shape allows
             int per = std::min(cap, std::max(1, (G + nctx - 1) / nctx));
             if (lanes_cap > 1) per = std::min(std::min(lanes_cap, cap), G);      // an explicit request never exceeds what the shape allows
-            for (int i = 0; i < G; i += per) units.emplace_back(g.second.begin() + i, g.second.begin() + std::min(G, i + per));
+            // Which designs share a unit: neighbours in the job list (a sweep's neighbours tend to need similar
+            // iteration counts, so the lanes of a unit finish together) or, MBFIR_UNIT_ORDER=1, dealt round-robin over
+            // the units (every unit gets its share of the slow designs: at the end of the batch all streams still
+            // have live lanes instead of one stream running the slow unit alone)
+            const int nunits = (G + per - 1) / per;
+            int order = 0;
+            if (const char* ev = std::getenv("MBFIR_UNIT_ORDER")) order = std::atoi(ev);
+            if (order == 1 && nunits > 1) {
+                std::vector<std::vector<int>> us(nunits);
+                for (int i = 0; i < G; ++i) us[i % nunits].push_back(g.second[i]);
+                for (auto& u : us) units.push_back(u);
+            } else {
+                for (int i = 0; i < G; i += per) units.emplace_back(g.second.begin() + i, g.second.begin() + std::min(G, i + per));
+            }
         }
     }
     std::atomic<int> next(0);

@@ -851,7 +851,10 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
 // and drain are serial phases of 1-2 us each, and the chip's 512 slots were full (425 busy on average) -- the
 // factorisation was bound by slot-time, not by its chain.  So a task now walks a STRIP of up to four tiles that share
 // an operand, with the next tile's loads in flight behind the current product and ONE drain + signal at the end.
-constexpr int STRIP = 4;
+#ifndef CHOL_STRIP
+#define CHOL_STRIP 4
+#endif
+constexpr int STRIP = CHOL_STRIP;
 
 // lane t (< n <= 64) of wave 0 polls its own word; everybody passes when all have reached their value
 template <class F>
@@ -897,7 +900,11 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
 #pragma unroll
         for (int u = 0; u < 8; ++u) {                     // the tile's old content and the next operand: in flight behind the product
             const int e = tid + 256 * u;
+#ifdef CHOL_EXP_NO_RMW      /* timing experiment only (tools/exp): no read of the old tile */
+            old[u] = make_double2(0.0, 0.0);
+#else
             old[u] = first ? make_double2(0.0, 0.0) : ld2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+#endif
         }
         if (t + 1 < cnt) {
             const rsrc_t rb = make_rsrc(B0 + (t + 1) * bstep);
@@ -914,7 +921,11 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
             const int e = tid + 256 * u;
             const double2 pr = *reinterpret_cast<const double2*>(&Q[e >> 5][2 * (e & 31)]);
             const double2 x = first ? make_double2(-pr.x, -pr.y) : make_double2(old[u].x - pr.x, old[u].y - pr.y);
+#ifdef CHOL_EXP_NO_RMW      /* ... and no write either (one 16-byte store per thread keeps the result alive) */
+            if (u == 0 && x.x == 1.2345e300) st2_sc1(rd, 0, x);
+#else
             st2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8), x);
+#endif
         }
         __syncthreads();                                  // Q is free for the next operand
     }

@@ -176,6 +176,7 @@ inline dim3 lane_grid(dim3 g, int nlanes) { g.z = nlanes; return g; }
 // ------------------------------------------------------------------------------------------------
 // trig matrix
 __global__ void k_build_A1(DProg P, double* __restrict__ A1) {
+    LANES(P, A1);
     int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= P.Nt || i >= P.Mf) return;
     double sn, cs;
@@ -186,6 +187,7 @@ __global__ void k_build_A1(DProg P, double* __restrict__ A1) {
 // XX = [v ; P'v]  (second half only when quad)
 template <int NV>
 __global__ void k_make_xx(DProg P, const double* __restrict__ v, double* __restrict__ XX) {
+    LANES(P, v, XX);
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
 #pragma unroll
@@ -200,7 +202,8 @@ __global__ void k_make_xx(DProg P, const double* __restrict__ v, double* __restr
 template <int NVV>
 __global__ __launch_bounds__(256) void k_amulti(const double* __restrict__ A1, int ld, int Mf,
                                                 const double* __restrict__ XX, int ldv,
-                                                double* __restrict__ UU, int Mpad) {
+                                                double* __restrict__ UU, int Mpad, size_t lane_bytes, const int* __restrict__ lane_mask) {
+    LANES_RAW(lane_bytes, lane_mask, A1, XX, UU);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
     if (row >= Mf) return;
@@ -284,6 +287,7 @@ constexpr int AT_ROWS = 256;
 template <int NVV, bool AGG>
 __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restrict__ A1, const double* __restrict__ src,
                                                  double* __restrict__ partial) {
+    LANES(P, A1, src, partial);
     __shared__ double sh[4][NVV][128];
     __shared__ double pp[NVV][AT_ROWS];
     const int lane = threadIdx.x, wq = threadIdx.y, tid = wq * 64 + lane;
@@ -1459,6 +1463,7 @@ __global__ __launch_bounds__(256) void k_freq_blocks_fold(DProg P, const double*
 // H (np x np) from the Gram matrices and the border products.  TT[v][j] = (A1' BB[v])[j].
 __global__ void k_assemble_H(DProg P, const double* __restrict__ T, const double* __restrict__ TT,
                              double* __restrict__ H, double pad_diag) {
+    LANES(P, T, TT, H);
     int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
     if (k >= P.np || j >= P.np) return;
     double v = 0;
@@ -1868,6 +1873,7 @@ struct Solver::Impl {
     bool taps_valid = false;     // hout holds the taps of the last unit's solutions (specfact_last)
     long chol_launch_count = 0;  // k_chol_step launches of the current solve
     size_t lane_bytes = 0;
+    bool lane_live[64] = {};     // host copy of mask row 0 (the dense Gram products are launched per lane)
     int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
                                  // still need CG sweep q, row MAX_SWEEPS + 1 = scratch (lanes with a new best iterate)
     int* hostMask = nullptr;     // pinned twin
@@ -1992,9 +1998,9 @@ struct Solver::Impl {
             xx = XX;
         }
         dim3 g(cdiv(P.Mf, 4));
-        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
-        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
-        else hipLaunchKernelGGL(k_amulti<4>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad);
+        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
+        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
+        else hipLaunchKernelGGL(k_amulti<4>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
         hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
     }
     // gout = G v and wout = W^-2 gout - sub; one kernel less than apply_G + winv2 on the lattice path
@@ -2216,7 +2222,16 @@ struct Solver::Impl {
                 hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
         } else {
-        gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
+        // the dense Gram products, one lane after the other (a k_gram launch fills the chip by itself: 340 us at the
+        // headline size); the lanes the host knows to be finished are skipped
+        if (g0) hipEventRecord(g0, st);
+        for (int b = 0; b < nlanes; ++b) {
+            if (nlanes > 1 && !lane_live[b]) continue;
+            const size_t off = (size_t)b * lane_bytes;
+            auto at = [&](double* p) { return reinterpret_cast<double*>(reinterpret_cast<char*>(p) + off); };
+            gram_launch(gp, at(A1), at(Dw), at(slab), at(T), tile_ij, st, nullptr, nullptr);
+        }
+        if (g1) hipEventRecord(g1, st);
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti_array(nvv, BB);
@@ -2449,10 +2464,16 @@ void Solver::test_fold(const double* w, int Mf, int fold, long* out) {
 int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
     // lock-step batches exist on the lattice path only; the extended-precision KKT solve (on by default for
     // fir_qp_cvx) and row-sharded solves run one design at a time
-    if (o.shard_size > 1 || o.dense_trig || o.ddkkt_theta > 0) return 1;
-    if (!lane_prep(Q, o)->Lt.ok) return 1;                // a grid / column set without the lattice structure: dense path
+    if (o.shard_size > 1 || o.ddkkt_theta > 0) return 1;
     const long np = round_up(Q.N(), 64);
     long cap = std::min<long>(32, 16384 / np);
+    if (o.dense_trig || !lane_prep(Q, o)->Lt.ok) {
+        // dense path (opts.dense_trig, or a grid / column set without the lattice structure): every lane materialises
+        // its trig matrix and owns a split-K slab -- at most ~2 GB of them per unit
+        const GramPlan gp = gram_plan(Q.Mf, Q.Nt, Q.quad ? 3 : 1);
+        const double per_lane = 8.0 * (double(gp.Mpad) * gp.ld + double(gp.slab_doubles) + 3.0 * gp.ld * gp.ld);
+        cap = std::min<long>(cap, std::max<long>(1, long(2.0e9 / per_lane)));
+    }
     if (const char* ev = std::getenv("MBFIR_MAX_LANES")) cap = std::atol(ev);          // (experiments: tools/sweep_lanes.sh)
     return int(std::max<long>(1, std::min<long>(MAX_LANES, cap)));
 }
@@ -2532,7 +2553,6 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.gp = gram_plan(Mf, Nt, nw);
     DProg& P = S.P;
     P.trig = Lt.ok ? 1 : 0;
-    if (nlanes > 1 && !P.trig) throw HipError("lock-step batch needs the lattice path");
     P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
     P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
     if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
@@ -2647,6 +2667,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         if (nlanes == 1) return;
         for (int b = 0; b < nlanes; ++b) {
             S.hostMask[b] = LH[b].live ? 1 : 0;
+            S.lane_live[b] = LH[b].live;
             for (int q = 1; q <= MAX_SWEEPS; ++q) S.hostMask[q * MAX_LANES + b] = (LH[b].live && LH[b].nsweep >= q) ? 1 : 0;
         }
         MBFIR_HIP(hipMemcpyAsync(S.maskT, S.hostMask, sizeof(int) * (MAX_SWEEPS + 1) * MAX_LANES, hipMemcpyHostToDevice, st));
@@ -2654,7 +2675,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     push_masks();
     P.mask = S.mask_row(0);
     // ---- build A1, norms -------------------------------------------------------------------
-    if (!P.trig) hipLaunchKernelGGL(k_build_A1, dim3(cdiv(Nt, 256), Mf), dim3(256), 0, st, P, S.A1);
+    if (!P.trig) hipLaunchKernelGGL(k_build_A1, lane_grid(dim3(cdiv(Nt, 256), Mf), nlanes), dim3(256), 0, st, P, S.A1);
     else {
         const int seed_lanes = P.seeds_shared ? 1 : nlanes;
         hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,

@@ -31,14 +31,6 @@ import numpy as np
 
 STEP = 0.99
 SIGMA_MAX = 0.25              # cap of Mehrotra's centring parameter (see solve())
-# One Gondzio centrality corrector on the LP rows (and the kappa-tau pair), see solve(): tried when the previous
-# iteration's step was short (the gate looks at the PREVIOUS step so that the device solver, which talks to its host
-# once per iteration, can take the same decision), aimed at a step CORR_DALPHA longer, the trial products pulled into
-# [CORR_BMIN, CORR_BMAX] x sigma mu, accepted when the step grows by at least CORR_ACCEPT x CORR_DALPHA.
-CORR_GATE = 0.0                # 0: off (the default until the C++ twin and the device solver carry the same step)
-CORR_DALPHA = 0.3
-CORR_BMIN, CORR_BMAX = 0.1, 10.0
-CORR_ACCEPT = 0.1
 STATUS_OPTIMAL = 0
 STATUS_PRIMAL_INFEASIBLE = 1
 STATUS_DUAL_INFEASIBLE = 2
@@ -580,8 +572,6 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
     info = {}
     best = (np.inf, None, None)
     wall = 0                  # consecutive iterations past the numerical wall (see below)
-    alpha_prev = 1.0          # step of the previous iteration (gate of the centrality corrector)
-    ncorr_tried, ncorr_used = [0], [0]
     fixes_seen = 0
     for it in range(max_iter + 1):
         rx = G.T @ z + c * tau
@@ -694,33 +684,6 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             break
         dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, dk_c, x2, z2, Gx2)
         alpha = step_of(dss, wdz, dtau, dkap, STEP)
-        if CORR_GATE > 0 and alpha_prev < CORR_GATE and cone.l > 0:
-            # Gondzio's centrality corrector (Comput. Optim. Appl. 6, 1996) on the LP rows: at the trial step
-            # at = min(1, alpha / STEP + CORR_DALPHA) the complementarity products v_i = (lam + at dss)_i (lam + at wdz)_i
-            # that leave the box [bmin, bmax] sigma mu are pulled back to it; the correction direction solves the same
-            # KKT system with that term alone on the right (no residuals), and the sum is kept if its step is longer
-            at = min(1.0, alpha / STEP + CORR_DALPHA)
-            mut = sigma * mu
-            ll_ = cone.l
-            v = (lam[:ll_] + at * dss[:ll_]) * (lam[:ll_] + at * wdz[:ll_])
-            t = np.clip(v, CORR_BMIN * mut, CORR_BMAX * mut) - v
-            t = np.maximum(t, -CORR_BMAX * mut)
-            vk = (kappa + at * dkap) * (tau + at * dtau)
-            tk = max(min(max(vk, CORR_BMIN * mut), CORR_BMAX * mut) - vk, -CORR_BMAX * mut)
-            tc = np.zeros(R)
-            tc[:ll_] = t / lam[:ll_]                          # lam \ t on the LP rows, nothing on the cones
-            try:
-                x3, z3, Gx3 = kkt_solve(Wm, H, cf, np.zeros(N), -Wm.apply(tc))
-            except FloatingPointError:
-                status = STATUS_NUMERICAL
-                break
-            dxc, dsc, dzc, dtc, dkc, dssc, wdzc = direction(1.0, tk, x3, z3, Gx3)
-            alpha_c = step_of(dss + dssc, wdz + wdzc, dtau + dtc, dkap + dkc, STEP)
-            ncorr_tried[0] += 1
-            if alpha_c >= alpha + CORR_ACCEPT * CORR_DALPHA:
-                dx, ds, dz, dtau, dkap, alpha = dx + dxc, ds + dsc, dz + dzc, dtau + dtc, dkap + dkc, alpha_c
-                ncorr_used[0] += 1
-        alpha_prev = alpha
         if sweep_log:                                         # (iterations on the extended-precision path keep the count)
             # inexact-Newton forcing term: while the iterate's own dual residual ||rx|| is large there is no point in
             # driving the linear system's residual twelve digits below it -- the controller asks for REFETA * ||rx||
@@ -742,8 +705,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         if not (np.isfinite(tau) and tau > 0 and np.all(np.isfinite(x))):
             status = STATUS_NUMERICAL
             break
-    out = dict(status=status, x=x / tau, s=s / tau, z=z / tau, chol_fixes=chol_fixes[0], correctors_tried=ncorr_tried[0],
-               correctors_used=ncorr_used[0])
+    out = dict(status=status, x=x / tau, s=s / tau, z=z / tau, chol_fixes=chol_fixes[0])
     out.update(info)
     if status in (STATUS_MAXIT, STATUS_NUMERICAL) and best[1] is not None:
         bi = best[2]

@@ -96,3 +96,21 @@ def test_single_chunk_blocks_agree_to_rounding():
     other = _batch(MBFIR_CGRP=1)
     for (h0, _, i0), (h1, _, i1) in zip(base, other):
         assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+
+
+def test_dense_path_runs_lock_step_batches_too():
+    """opts.dense_trig = 1 (the trig matrix materialised, A' D A on the fp64 matrix cores -- north_star's own route, and
+    the path of a program without the lattice structure) batches like the lattice path: every lane owns its trig matrix
+    and split-K slab, the Gram products run lane after lane, everything else with the lane as a grid dimension.  The
+    lanes' results equal the single dense solves bit for bit."""
+    jobs = [("fir_ap_cvx", (48, F6, A6, D3, 0.1, 1e-2 * (1 + 0.5 * k))) for k in range(5)]
+    ctx = mbfir.Context(0)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=5, dense_trig=1))
+        assert all(r[1] == "Solved" for r in res) and res[0][2]["lanes"] == 5 and res[0][2]["lattice"] == 0
+        for (name, args), (h, st, info) in zip(jobs, res):
+            h1, s1, i1 = mbfir.fir_ap_cvx(*args, opts=mbfir.make_opts(dense_trig=1), ctx=ctx, info=True)
+            assert s1 == "Solved" and i1["lattice"] == 0 and i1["iters"] == info["iters"]
+            assert np.array_equal(h, h1) and info["pcost"] == i1["pcost"]
+    finally:
+        ctx.close()
