@@ -12,6 +12,7 @@
 //     LDS rows padded to 144 doubles so the 4 k-slices of one ds_read_b64 hit disjoint banks.
 // Algorithmic work: Mf * Nt * (Nt + 1) flop per weight vector (lower triangle).
 #include "dev_common.h"
+#include <vector>
 
 namespace mbfir {
 
@@ -27,7 +28,12 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int 
     __shared__ double As[2][GKB][GLDP];
     __shared__ double Bs[2][GKB][GLDP];
     __shared__ double Ds[2][NW][GKB];
-    const int t = blockIdx.x, split = blockIdx.y;
+    // (tile, split) of this workgroup from the XCD-aware table behind the tile list (gram_tiles_host): workgroups are
+    // dealt round-robin over the 8 XCDs, and the table gives every XCD a compact 2 x 2 cluster of tiles with all their
+    // K slices, so the column panels a cluster shares are fetched once per XCD (its L2) instead of once per workgroup
+    const int* pair = tile_ij + 2 * ntiles + 2 * blockIdx.x;
+    const int t = pair[0], split = pair[1];
+    if (t < 0) return;
     const int ti = tile_ij[2 * t], tj = tile_ij[2 * t + 1];
     const bool diag = ti == tj;
     const int I0 = ti * GT, J0 = tj * GT;
@@ -167,10 +173,35 @@ GramPlan gram_plan(int Mf, int Nt, int nw) {
     return gp;
 }
 
+int gram_grid_blocks(const GramPlan& gp) { return 8 * cdiv((long)gp.ntiles * gp.nsplit, 8); }
+int gram_table_ints(const GramPlan& gp) { return 2 * gp.ntiles + 2 * gram_grid_blocks(gp); }
+
+// tile list (ti, tj per tile) followed by the (tile, split) pair of every workgroup of the k_gram grid.
+// Workgroup b runs on XCD b % 8 (observed dispatch; only speed depends on it): XCD c gets the c-th eighth of the pair
+// list, which walks the tiles in 2 x 2 clusters (a cluster's four tiles touch four column panels instead of eight)
+// with all K slices of a tile together.
 void gram_tiles_host(const GramPlan& gp, int* tile_ij) {
     int t = 0;
+    std::vector<std::vector<int>> index(gp.ntile, std::vector<int>(gp.ntile, -1));
     for (int i = 0; i < gp.ntile; ++i)
-        for (int j = 0; j <= i; ++j) { tile_ij[2 * t] = i; tile_ij[2 * t + 1] = j; ++t; }
+        for (int j = 0; j <= i; ++j) { tile_ij[2 * t] = i; tile_ij[2 * t + 1] = j; index[i][j] = t; ++t; }
+    std::vector<int> order;
+    for (int bi = 0; 2 * bi < gp.ntile; ++bi)
+        for (int bj = 0; bj <= bi; ++bj)
+            for (int di = 0; di < 2; ++di)
+                for (int dj = 0; dj < 2; ++dj) {
+                    const int i = 2 * bi + di, j = 2 * bj + dj;
+                    if (i < gp.ntile && j <= i) order.push_back(index[i][j]);
+                }
+    const int nblocks = gram_grid_blocks(gp), seg = nblocks / 8;
+    int* pair = tile_ij + 2 * gp.ntiles;
+    for (int b = 0; b < nblocks; ++b) { pair[2 * b] = -1; pair[2 * b + 1] = 0; }
+    long q = 0;
+    for (int tile : order)
+        for (int s = 0; s < gp.nsplit; ++s, ++q) {
+            const int c = int(q / seg), pos = int(q % seg);          // XCD c, its pos-th workgroup
+            pair[2 * (8 * pos + c)] = tile; pair[2 * (8 * pos + c) + 1] = s;
+        }
 }
 
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
@@ -178,7 +209,7 @@ void gram_launch(const GramPlan& gp, const double* A, const double* d, double* s
     // One k_gram launch per weight vector: three accumulator sets (384 VGPRs) would spill, and the
     // kernel is MFMA-bound, so re-reading A from L2/MALL costs nothing measurable.  The optional
     // events bracket the k_gram launches only (roofline timing), the split-K fold comes after.
-    dim3 grid(gp.ntiles, gp.nsplit);
+    dim3 grid(gram_grid_blocks(gp));
     const size_t per_w = (size_t)gp.nsplit * gp.ntiles * GT * GT;
     if (ev0) hipEventRecord(ev0, st);
     for (int w = 0; w < gp.nw; ++w)

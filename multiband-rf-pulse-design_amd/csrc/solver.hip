@@ -2584,7 +2584,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (S.nbR + 1 > NPART * 64) throw HipError("problem too large for the reduction buffers");
     const size_t ld = P.ld, np = P.np, LDV = P.LDV, Rp = P.Rp, Mpad = P.Mpad;
     const int lp = Q.which == DES_AP ? specfact_lp(Q.n) : 0;
-    std::vector<int> tiles(2 * S.gp.ntiles);
+    std::vector<int> tiles(gram_table_ints(S.gp));
     gram_tiles_host(S.gp, tiles.data());
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
     Arena& ar = S.ar;
@@ -2963,13 +2963,13 @@ void Solver::test_gram(int m, int nt, int nw, const double* A, const double* d, 
     MBFIR_HIP(hipSetDevice(S.device));
     GramPlan gp = gram_plan(m, nt, nw);
     const size_t ld = gp.ld, Mpad = gp.Mpad;
-    DevBuf dA(Mpad * ld * 8), dd(nw * Mpad * 8), dslab(gp.slab_doubles * 8), dT(nw * ld * ld * 8), dt(2 * gp.ntiles * 4);
+    DevBuf dA(Mpad * ld * 8), dd(nw * Mpad * 8), dslab(gp.slab_doubles * 8), dT(nw * ld * ld * 8), dt((size_t)gram_table_ints(gp) * 4);
     MBFIR_HIP(hipMemsetAsync(dA.p, 0, Mpad * ld * 8, S.st));
     MBFIR_HIP(hipMemsetAsync(dd.p, 0, nw * Mpad * 8, S.st));
     MBFIR_HIP(hipMemcpy2DAsync(dA.p, ld * 8, A, (size_t)nt * 8, (size_t)nt * 8, m, hipMemcpyHostToDevice, S.st));
     for (int w = 0; w < nw; ++w)
         MBFIR_HIP(hipMemcpyAsync(dd.as<double>() + w * Mpad, d + (size_t)w * m, (size_t)m * 8, hipMemcpyHostToDevice, S.st));
-    std::vector<int> tiles(2 * gp.ntiles);
+    std::vector<int> tiles(gram_table_ints(gp));
     gram_tiles_host(gp, tiles.data());
     MBFIR_HIP(hipMemcpyAsync(dt.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, S.st));
     gram_launch(gp, dA.as<double>(), dd.as<double>(), dslab.as<double>(), dT.as<double>(), dt.as<int>(), S.st);
@@ -3240,10 +3240,10 @@ void Solver::test_time_kernels(int n, int m, int nt, int reps, double* ms_chol, 
     }
     *ms_chol = tot / reps;
     GramPlan gp = gram_plan(m, nt, 1);
-    DevBuf dA((size_t)gp.Mpad * gp.ld * 8), dd((size_t)gp.Mpad * 8), dslab(gp.slab_doubles * 8), dT((size_t)gp.ld * gp.ld * 8), dt(2 * gp.ntiles * 4);
+    DevBuf dA((size_t)gp.Mpad * gp.ld * 8), dd((size_t)gp.Mpad * 8), dslab(gp.slab_doubles * 8), dT((size_t)gp.ld * gp.ld * 8), dt((size_t)gram_table_ints(gp) * 4);
     MBFIR_HIP(hipMemsetAsync(dA.p, 0x3c, (size_t)gp.Mpad * gp.ld * 8, S.st));      // arbitrary finite doubles
     MBFIR_HIP(hipMemsetAsync(dd.p, 0x3c, (size_t)gp.Mpad * 8, S.st));
-    std::vector<int> tiles(2 * gp.ntiles);
+    std::vector<int> tiles(gram_table_ints(gp));
     gram_tiles_host(gp, tiles.data());
     MBFIR_HIP(hipMemcpyAsync(dt.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, S.st));
     tot = 0;
