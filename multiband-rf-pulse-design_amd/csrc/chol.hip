@@ -1151,9 +1151,11 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     s.nrem = nrem;
     s.nD = k < nblk ? 1 : 0;
     s.nLA = (k >= 1 && k < nblk) ? nrem : 0;              // single tile updates of block column k + 1
-    s.nT = 0;                                             // strips over the tiles (i, j), k + 2 <= j <= i, of each row i
-    if (k >= 1 && k < nblk)
-        for (int c = 1; c < nrem; ++c) s.nT += strips_of(c);
+    s.nT = 0;                                             // strips over the tiles (i, j), k + 2 <= j <= i, of each row i:
+    if (k >= 1 && k < nblk && nrem >= 2) {                // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
+        const int m = nrem - 1, q = m / STRIP, r = m % STRIP;
+        s.nT = STRIP * q * (q + 1) / 2 + r * (q + 1);
+    }
     s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (four 16-column passes):
                                                           // row r of the inverse waits for row r - 1, so a longer strip here
                                                           // is a longer chain (measured: 16 passes per task doubled the build)

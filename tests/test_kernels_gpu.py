@@ -94,7 +94,7 @@ def test_double_double_solve_matches_the_oracles_dd_kernels(n, k):
     assert np.abs(r).max() <= 1e-10 * (np.abs(b).max() + np.abs(Hw).max() * np.abs(Xh).max() * n)
 
 
-@pytest.mark.parametrize("n", [64, 200, 449, 1023])
+@pytest.mark.parametrize("n", [64, 200, 449, 1023, 2100])
 def test_cholesky_split_step_equals_the_fused_step(n, monkeypatch):
     """Lock-step batches run the factorisation in other forms than the fused step of a single design -- the split step
     (the row blocks read the stored image of L_kk instead of repeating its 64 pivots) and the single-launch form --
