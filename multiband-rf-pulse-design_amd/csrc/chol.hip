@@ -48,8 +48,11 @@ __device__ __forceinline__ void acc_foreach(v4d acc[2][2], F f) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                f(wi * 32 + a * 16 + (lane >> 4) + 4 * r, wj * 32 + b * 16 + (lane & 15), acc[a][b][r]);
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[a][b][r];
+                f(wi * 32 + a * 16 + (lane >> 4) + 4 * r, wj * 32 + b * 16 + (lane & 15), v);
+                acc[a][b][r] = v;                         // (f may take its value by reference)
+            }
 }
 
 // ---- write-through / L1-bypassing accesses for data that passes between workgroups INSIDE one launch ---------------
@@ -876,7 +879,10 @@ __device__ __forceinline__ void wait_many(int n, F get, int* pivflag) {
 }
 
 // dst_t -= A * B_t (TRANSB: B_t')  for t < cnt, with B_t = B0 + t * bstep, dst_t = D0 + t * dstep and A (64x64 at Ag)
-// shared by the strip; tile tfirst (if any) has not been written in this factorisation yet: see tile_update
+// shared by the strip; tile tfirst (if any) has not been written in this factorisation yet: see tile_update.
+// The old tile is read and the result written straight in the accumulator layout (8-byte write-through accesses: 16 lanes
+// cover one 128-byte line of a row, so every line is still written whole by one wave instruction) -- no restaging
+// through LDS, two barriers fewer per tile than the 16-byte form of tile_update<.., true>.
 template <bool TRANSB>
 __device__ __forceinline__ void strip_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ B0, long bstep,
                                              double* __restrict__ D0, long dstep, int tfirst, int cnt, int np) {
@@ -884,7 +890,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
     double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
     const int tid = threadIdx.x;
     load_block<true>(P, Ag, np);
-    double2 bt[8], old[8];
+    double2 bt[8];
     {
         const rsrc_t rb = make_rsrc(B0);
 #pragma unroll
@@ -895,17 +901,16 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
         __syncthreads();                                  // P (first pass) and Q in place
-        const rsrc_t rd = make_rsrc(D0 + t * dstep);
+        double* dst = D0 + t * dstep;
         const bool first = t == tfirst;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                     // the tile's old content and the next operand: in flight behind the product
-            const int e = tid + 256 * u;
+        v4d old[2][2];                                    // the tile's old content (accumulator layout) and the next operand:
+        acc_foreach(old, [&](int i, int j, double& v) {   // in flight behind the product
 #ifdef CHOL_EXP_NO_RMW      /* timing experiment only (tools/exp): no read of the old tile */
-            old[u] = make_double2(0.0, 0.0);
+            v = 0.0;
 #else
-            old[u] = first ? make_double2(0.0, 0.0) : ld2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+            v = first ? 0.0 : ld_sc1(dst + (long)i * np + j);
 #endif
-        }
+        });
         if (t + 1 < cnt) {
             const rsrc_t rb = make_rsrc(B0 + (t + 1) * bstep);
 #pragma unroll
@@ -913,21 +918,16 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
         }
         v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
         mma64<TRANSB>(P, Q, 0, CB, acc);
-        __syncthreads();                                  // everybody is done reading Q
-        acc_foreach(acc, [&](int i, int j, double v) { Q[i][j] = v; });
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            const double2 pr = *reinterpret_cast<const double2*>(&Q[e >> 5][2 * (e & 31)]);
-            const double2 x = first ? make_double2(-pr.x, -pr.y) : make_double2(old[u].x - pr.x, old[u].y - pr.y);
-#ifdef CHOL_EXP_NO_RMW      /* ... and no write either (one 16-byte store per thread keeps the result alive) */
-            if (u == 0 && x.x == 1.2345e300) st2_sc1(rd, 0, x);
-#else
-            st2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8), x);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[a][b][r] = first ? -acc[a][b][r] : old[a][b][r] - acc[a][b][r];
+#ifndef CHOL_EXP_NO_RMW     /* (the timing experiment does not write either) */
+        acc_foreach(old, [&](int i, int j, double& v) { st_sc1(dst + (long)i * np + j, v); });
 #endif
-        }
-        __syncthreads();                                  // Q is free for the next operand
+        __syncthreads();                                  // everybody is done reading Q: free for the next operand
     }
 }
 

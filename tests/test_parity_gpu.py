@@ -396,3 +396,39 @@ def test_refine_option_is_clamped_to_the_sweep_limit():
     assert s2 == s8 == s20 == "Solved"
     assert np.array_equal(h8, h20) and i8["iters"] == i20["iters"]
     assert relinf(h20, h2) <= TAP_TOL
+
+
+def test_reduced_accuracy_exit_at_max_iter_returns_the_iterate_it_reports():
+    """a solve that runs into max_iter and leaves through the reduced-accuracy exit ('Inaccurate/Solved',
+    fir_ap_cvx.m:176) reports the best iterate's objective and residuals -- the returned x has to be THAT iterate, also when
+    the iterate of the last iteration is the first (or the new best) to qualify.  Single solves and lock-step lanes."""
+    fn, args = CASES["ap_c13_64"]
+    n, f, a, d, obj, peak = args
+    rc, P = mbfir.assemble_dense(0, n, f, a, d, (obj, peak), 0)
+    assert rc == 0
+    c = np.asarray(P["c"])
+    hit = 0
+    for max_iter in range(18, 34, 3):
+        o = mbfir.make_opts(max_iter=max_iter, ddkkt=-1, dense_trig=0)
+        h, status, info = mbfir.fir_ap_cvx(*args, opts=o, info=True)
+        if status != "Solved":
+            continue
+        z = mbfir.get_context().last_solution(info["n_unknowns"])
+        assert abs(c @ z - info["pcost"]) <= 1e-9 * max(1e-3, abs(info["pcost"])), (max_iter, info)
+        s = np.asarray(P["h"]) - np.asarray(P["G"]) @ z
+        assert s[:P["l"]].min() >= -1e-5 * np.abs(P["h"]).max()
+        hit += info["iters"] >= max_iter
+    assert hit >= 1                                       # at least one of them really left through the max_iter exit
+    # the same through a lock-step unit
+    jobs = [("fir_ap_cvx", (n, f, a, d, obj, peak * (1 + 0.25 * k))) for k in range(4)]
+    ctx = mbfir.Context(0)
+    try:
+        for max_iter in (24, 27):
+            res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, solutions=True, opts=mbfir.make_opts(max_iter=max_iter, ddkkt=-1, lanes=4))
+            for (_, jargs), (h, status, info, z) in zip(jobs, res):
+                if status != "Solved":
+                    continue
+                rc, Pj = mbfir.assemble_dense(0, *jargs[:4], (jargs[4], jargs[5]), 0)
+                assert abs(np.asarray(Pj["c"]) @ z - info["pcost"]) <= 1e-9 * max(1e-3, abs(info["pcost"])), (max_iter, info)
+    finally:
+        ctx.close()
