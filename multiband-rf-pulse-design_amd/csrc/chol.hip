@@ -491,7 +491,8 @@ __device__ __forceinline__ void signal_add(int* word) {
 //   rowdone[k][i]  row blocks of tile (i, k) that have stored their 16 rows of L_ik                     (complete: 4)
 //   tver[i][j]     panels applied to the trailing tile (i, j) by the tile-update blocks                  (0 .. j - 1)
 //   msdone[r][j]   16-column blocks of the inverse tile M_rj stored                                      (complete: 4)
-//   ruver[i][j]    updates applied to the inverse's tile R_ij                                            (0 .. i - j - 1)
+//   ruver[i][j]    (round-3 first form: updates applied to the inverse's tile R_ij; unused since the inverse rows
+//                  accumulate their updates themselves -- minv_strip)
 //   img[k]         1 once the image of L_kk and 1 / diag(L_kk) are in Dfac / dinvG;   ticket: the lane's task counter
 struct DagCnt {
     int *rowdone, *tver, *msdone, *ruver, *img, *ticket;
@@ -1008,10 +1009,14 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Inverse row r = k-1, tiles j0 .. j0+cnt-1: the image of L_rr is loaded once, L_r,r-1 is held in REGISTERS in the
-// matrix cores' operand layout (no LDS tile), then 2 x cnt passes of 32 columns each -- two interleaved substitutions per
-// thread.  Same arithmetic per column block as minv_block.
-__device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, double* smem) {
+// Inverse row r = k-1, tile j, LEFT-LOOKING: the task first accumulates  R_rj = - sum_{p = j}^{r-2} L_rp M_pj  in its
+// accumulator registers (operands streamed through LDS, the next pair in flight behind the current product) -- the
+// updates the per-step forms apply one panel at a time as read-modify-writes of the inverse's trailing tiles, in the
+// same order and with the same arithmetic per update (first update writes the negated product, the others subtract) --
+// and then, when row r-1 of the inverse and the image of L_rr are there, does what minv_block does: the product with
+// L_r,r-1 (held in REGISTERS in the matrix cores' operand layout), two passes of 32 columns, two interleaved
+// substitutions per thread.  No inverse-update tasks, no read-modify-write traffic on the inverse at all.
+__device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int np = a.np, r = a.k - 1;
     const long kr = (long)r * CB;
@@ -1021,15 +1026,79 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
     double* Ct = smem + R1 + 64 * 33;                                      // staging [column][row], stride YLD, 32 columns
     double* dinv = smem + R3;
     const DagCnt dc(a.cnt, a.nblk);
-    wait_many(2 + 2 * cnt, [&](int t, const int*& w, int& want) {
-        if (t == 0) { w = dc.img + r; want = 1; }
-        else if (t == 1) { w = j0 < r ? dc.at(dc.rowdone, r - 1, r) : nullptr; want = 4; }
-        else {
-            const int j = j0 + ((t - 2) >> 1);
-            if ((t & 1) == 0) { w = j < r ? dc.at(dc.msdone, r - 1, j) : nullptr; want = 4; }
-            else { w = j <= r - 2 ? dc.at(dc.ruver, r, j) : nullptr; want = r - j - 1; }
+    const int c = lane & 15;
+    double rold[2][2][4];                                 // R_rj in the layout of the two 32-column passes: [pass][half][q]
+    if (j <= r - 2) {
+        // ---- accumulate the panels j .. r-2 (their tiles of L and of the inverse were finished steps ago)
+        const int npan = r - 1 - j;
+        wait_many(min(2 * npan, 64), [&](int t, const int*& w, int& want) {
+            const int pq = j + (t >> 1);
+            w = (t & 1) ? dc.at(dc.msdone, pq, j) : dc.at(dc.rowdone, pq, r);
+            want = 4;
+        }, a.flag);
+        if (2 * npan > 64 && tid == 0)                    // (more than 32 panels: the rest one by one)
+            for (int pq = j + 32; pq <= r - 2; ++pq) { wait_flag(dc.at(dc.rowdone, pq, r), 4, a.flag); wait_flag(dc.at(dc.msdone, pq, j), 4, a.flag); }
+        __syncthreads();
+        double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);
+        double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
+        double2 at[8], bt[8];
+        auto fetch_pair = [&](int pq) {
+            const rsrc_t ra = make_rsrc(a.H + kr * np + (long)pq * CB), rb = make_rsrc(M + (long)pq * CB * np + (long)j * CB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                at[u] = ld2_sc1(ra, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+                bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+            }
+        };
+        fetch_pair(j);
+        v4d x[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+#pragma unroll 1
+        for (int pq = j; pq <= r - 2; ++pq) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                *reinterpret_cast<double2*>(&P[e >> 5][2 * (e & 31)]) = at[u];
+                *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u];
+            }
+            __syncthreads();
+            if (pq + 1 <= r - 2) fetch_pair(pq + 1);
+            v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+            mma64<false>(P, Q, 0, CB, acc);
+            const bool first = pq == j;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[aa][bb][q] = first ? -acc[aa][bb][q] : x[aa][bb][q] - acc[aa][bb][q];
+            __syncthreads();                              // everybody is done reading P and Q
         }
-    }, a.flag);
+        // accumulator layout -> the layout of the passes, through LDS
+        double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
+        acc_foreach(x, [&](int i, int jj, double& v) { X[i][jj] = v; });
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rold[ps][h][q] = X[16 * wv + (lane >> 4) + 4 * q][32 * ps + 16 * h + c];
+        __syncthreads();                                  // R0 / R1 are free for the image and the passes' staging
+    } else {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = 16 * wv + (lane >> 4) + 4 * q, cc = 32 * ps + 16 * h + c;
+                    rold[ps][h][q] = j == r ? (t == cc ? 1.0 : 0.0) : 0.0;       // identity on the diagonal tile, zero next to it
+                }
+    }
+    // ---- row r-1 of the inverse (this column), L_r,r-1 and the image of L_rr
+    if (tid == 0) wait_flags(dc.img + r, 1, j < r ? dc.at(dc.rowdone, r - 1, r) : nullptr, 4, j < r ? dc.at(dc.msdone, r - 1, j) : nullptr, 4, a.flag);
+    __syncthreads();
     {
         const rsrc_t ri = make_rsrc(a.Dfac + kr * CB);
         double2 t[8];
@@ -1043,26 +1112,17 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
     }
     if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + tid);
     double af[16];                                        // L_r,r-1: row 16 wv + (lane & 15), columns 4 q + (lane >> 4)
-    if (j0 < r) {
+    if (j < r) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) af[q] = ld_sc1(a.H + (kr + 16 * wv + (lane & 15)) * np + kr - CB + 4 * q + (lane >> 4));
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) af[q] = 0.0;
     }
-    const int c = lane & 15;
-    // operands of a pass: R_rj as the updates left it (identity / zero where no update ever reached) and 32 columns of
-    // M_r-1,j; the next pass's are in flight behind the current pass's product and substitution
-    double rnext[2][4], bnext[8];
+    // 32 columns of M_r-1,j per pass; the next pass's are in flight behind the current pass's product and substitution
+    double bnext[8];
     auto fetch = [&](int pass) {
-        const int j = j0 + (pass >> 1), c0 = 32 * (pass & 1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = 16 * wv + (lane >> 4) + 4 * q, cc = c0 + 16 * h + c;
-                rnext[h][q] = j == r ? (t == cc ? 1.0 : 0.0) : j == r - 1 ? 0.0 : ld_sc1(M + (kr + t) * np + (long)j * CB + cc);
-            }
+        const int c0 = 32 * pass;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u;
@@ -1070,9 +1130,9 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
         }
     };
     fetch(0);
-#pragma unroll 1
-    for (int pass = 0; pass < 2 * cnt; ++pass) {
-        const int j = j0 + (pass >> 1), c0 = 32 * (pass & 1);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c0 = 32 * pass;
         v4d acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if (j < r) {
 #pragma unroll
@@ -1092,9 +1152,9 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int t = 16 * wv + (lane >> 4) + 4 * q;
-                Ct[(16 * h + c) * YLD + t] = rnext[h][q] - acc[h][q];
+                Ct[(16 * h + c) * YLD + t] = rold[pass][h][q] - acc[h][q];
             }
-        if (pass + 1 < 2 * cnt) fetch(pass + 1);          // in flight behind the substitution
+        if (pass == 0) fetch(1);                          // in flight behind the substitution
         __syncthreads();
         const int rho = tid >> 4, lam = tid & 15;
         double va[4], vb[4];
@@ -1120,7 +1180,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
     }
     drain_stores();
     __syncthreads();
-    if (tid < cnt) __hip_atomic_fetch_add(dc.at(dc.msdone, r, j0 + tid), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.msdone, r, j), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =================================================================================================
@@ -1142,8 +1202,8 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j0, int cnt, d
 //  * Same arithmetic per tile, in the same order, as the multi-launch forms: the results are bit-identical
 //    (tests/test_kernels_gpu.py::test_cholesky_split_step_equals_the_fused_step).
 // Task order inside step k (per lane): D(k) | the tile updates of block column k+1 (what D(k+1) and the row blocks of
-// step k+1 wait for) | the other tile updates | inverse rows | inverse updates | row blocks of step k.
-struct DagStep { int nD, nLA, nT, nMS, nRU1, nRU, nRq, nRt, nrem, ruc; };
+// step k+1 wait for) | the other tile updates | inverse row k-1 (left-looking: its updates included) | row blocks of step k.
+struct DagStep { int nD, nLA, nT, nMS, nRq, nRt, nrem; };
 __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1) / STRIP; }
 __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     const int nrem = nblk - k - 1;
@@ -1156,17 +1216,15 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
         const int m = nrem - 1, q = m / STRIP, r = m % STRIP;
         s.nT = STRIP * q * (q + 1) / 2 + r * (q + 1);
     }
-    s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (four 16-column passes):
-                                                          // row r of the inverse waits for row r - 1, so a longer strip here
-                                                          // is a longer chain (measured: 16 passes per task doubled the build)
-    s.ruc = k >= 2 ? strips_of(k - 1) : 0;
-    s.nRU1 = (k >= 2 && k < nblk) ? k - 1 : 0;            // inverse updates of row i = k (the next inverse row waits for them): single tiles
-    s.nRU = (k >= 2 && k < nblk) ? (nblk - k - 1) * s.ruc : 0;      // rows i > k: strips
+    s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (its updates by the
+                                                          // panels before, then two 32-column passes): row r of the inverse waits
+                                                          // for row r - 1, so more tiles per task would be a longer chain (measured:
+                                                          // four tiles per task doubled the build)
     s.nRq = (k < nblk && nrem >= 1) ? 4 : 0;              // tile (k + 1, k) as four 16-row blocks (on the chain)
     s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
     return s;
 }
-__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
+__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRq + s.nRt; }
 
 #ifdef CHOL_DAG_STATS      /* tools/exp/chol_dag_exp.hip: one record per task of the unit whose H is g_dag_log_H -- kind, begin, end, ticks in polls */
 __device__ long long* g_dag_log;
@@ -1238,32 +1296,11 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     }
     t -= st.nT;
     if (t < st.nMS) {
-        minv_strip(a, t, 1, smem);
+        minv_strip(a, t, smem);
         DAG_STAT_END(2)
         return;
     }
     t -= st.nMS;
-    if (t < st.nRU1 + st.nRU) {
-        // R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
-        // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
-        int i, j0, cnt;
-        if (t < st.nRU1) { i = k; j0 = t; cnt = 1; }
-        else { t -= st.nRU1; i = k + 1 + t / st.ruc; j0 = STRIP * (t % st.ruc); cnt = min(STRIP, k - 1 - j0); }
-        const long mm = (long)(k - 2) * CB;
-        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
-            if (q == 0) { w = dc.at(dc.rowdone, k - 2, i); want = 4; }
-            else if (q & 1) { w = dc.at(dc.msdone, k - 2, j0 + (q - 1) / 2); want = 4; }
-            else { const int j = j0 + (q - 2) / 2; w = dc.at(dc.ruver, i, j); want = k - 2 - j; }
-        }, a.flag);
-        strip_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j0 * CB, CB, a.M + (long)i * CB * np + (long)j0 * CB, CB,
-                            k - 2 - j0, cnt, np);
-        drain_stores();
-        __syncthreads();
-        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DAG_STAT_END(3)
-        return;
-    }
-    t -= st.nRU1 + st.nRU;
     if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); DAG_STAT_END(4) return; }       // tile (k+1, k): four 16-row blocks
     t -= st.nRq;
     row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
