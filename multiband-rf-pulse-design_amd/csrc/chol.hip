@@ -446,6 +446,20 @@ constexpr int STEP_LDS = R3 + 336;                       // 79.4 KB
 constexpr int CHOL_SPIN_LIMIT = 1 << 21;                  // x s_sleep(4) + one L2 round trip: several seconds
 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// pause between two polls: short at first (a hand-off on the chain is noticed quickly), longer when the wait drags on --
+// hundreds of resident workgroups polling a handful of cache lines every 0.1 us slow down the very atomics they wait for
+#ifndef CHOL_BACKOFF
+#define CHOL_BACKOFF 0
+#endif
+__device__ __forceinline__ void poll_pause(int spins) {
+#if CHOL_BACKOFF
+    if (spins < 8) __builtin_amdgcn_s_sleep(4);
+    else if (spins < 32) __builtin_amdgcn_s_sleep(16);
+    else __builtin_amdgcn_s_sleep(64);
+#else
+    __builtin_amdgcn_s_sleep(4);
+#endif
+}
 
 // ONE lane polls ONE word (relaxed, agent scope: an sc1 load) until it reaches `want`; false + sentinel on expiry
 #ifdef CHOL_DAG_STATS
@@ -461,7 +475,7 @@ __device__ __forceinline__ bool wait_flag(const int* word, int want, int* pivfla
     DAG_WAIT_BEGIN
     while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         if (++spins >= CHOL_SPIN_LIMIT) { atomicAdd(pivflag, CHOL_SYNC_LOST); return false; }
-        __builtin_amdgcn_s_sleep(4);
+        poll_pause(spins);
     }
     DAG_WAIT_END
     return true;
@@ -477,7 +491,7 @@ __device__ __forceinline__ bool wait_flags(const int* w0, int want0, const int* 
         const int v2 = w2 ? __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want2;
         if (v0 >= want0 && v1 >= want1 && v2 >= want2) { DAG_WAIT_END return true; }
         if (++spins >= CHOL_SPIN_LIMIT) { atomicAdd(pivflag, CHOL_SYNC_LOST); return false; }
-        __builtin_amdgcn_s_sleep(4);
+        poll_pause(spins);
     }
 }
 // signal for the whole workgroup: every storing wave has drained its write-through stores, then ONE lane adds
@@ -872,7 +886,7 @@ __device__ __forceinline__ void wait_many(int n, F get, int* pivflag) {
             const int v = w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
             if (__all(v >= want)) break;
             if (++spins >= CHOL_SPIN_LIMIT) { if (threadIdx.x == 0) atomicAdd(pivflag, CHOL_SYNC_LOST); break; }
-            __builtin_amdgcn_s_sleep(4);
+            poll_pause(spins);
         }
         if (threadIdx.x == 0) { DAG_WAIT_END }
     }
