@@ -1391,7 +1391,10 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     // MBFIR_CHOL_SPLIT: 4 = the whole factorisation in ONE launch (k_chol_dag; default), 1 = one launch per step with
     // the row blocks waiting for their lane's diagonal block on a flag, 2 = two launches per step, 0 = fused step
     // (every row block factorises L_kk itself; one launch per step).
-    int split = nlanes >= 3 ? 4 : 0;
+    // default: the single launch for lock-step batches; one or two designs keep a launch per step -- the fused step
+    // (every row block factorises L_kk itself: lowest latency) up to np = 2048, the split step from np = 4096 on, where the
+    // 4 (nblk - k - 1) row blocks of a step repeating the 64 pivots is what fills the chip (2.41 against 2.72 ms at np = 4096)
+    int split = nlanes >= 3 ? 4 : (np >= 4096 ? 1 : 0);
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
     bool poison = false;
     if (const char* ev = std::getenv("MBFIR_POISON")) poison = std::atoi(ev) != 0;

@@ -4,11 +4,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); warnings.filterwarnings("ignore")
 import mbfir
 from conftest import c13
-for n, m in ((512, 16384), (200, 4096), (2048, 131072)):
+for n, m in ((512, 16384), (1024, 32768), (2048, 131072)):
     f, a, d = c13(n, "duration")
     o = mbfir.make_opts(grid_m=m)
-    for split in ("0", "4"):
-        os.environ["MBFIR_CHOL_SPLIT"] = split
+    for split in ("0", "1", "4", ""):
+        if split: os.environ["MBFIR_CHOL_SPLIT"] = split
+        else: os.environ.pop("MBFIR_CHOL_SPLIT", None)
         mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=o)
         ts = []
         for _ in range(3):
