@@ -505,8 +505,8 @@ __device__ __forceinline__ void signal_add(int* word) {
 //   rowdone[k][i]  row blocks of tile (i, k) that have stored their 16 rows of L_ik                     (complete: 4)
 //   tver[i][j]     panels applied to the trailing tile (i, j) by the tile-update blocks                  (0 .. j - 1)
 //   msdone[r][j]   16-column blocks of the inverse tile M_rj stored                                      (complete: 4)
-//   ruver[i][j]    (round-3 first form: updates applied to the inverse's tile R_ij; unused since the inverse rows
-//                  accumulate their updates themselves -- minv_strip)
+//   ruver[i][j]    updates applied to the inverse's tile R_ij by the inverse-update tasks  (nblk > 32 only: up to
+//                  nblk = 32 the inverse rows accumulate their updates themselves -- minv_strip)   (0 .. i - j - 1)
 //   img[k]         1 once the image of L_kk and 1 / diag(L_kk) are in Dfac / dinvG;   ticket: the lane's task counter
 struct DagCnt {
     int *rowdone, *tver, *msdone, *ruver, *img, *ticket;
@@ -518,6 +518,7 @@ struct DagCnt {
     __device__ int* at(int* arr, int a, int b) const { return arr + a * nblk + b; }
 };
 __host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4; }
+__host__ __device__ inline bool dag_ruform(int nblk) { return nblk > 32; }     // see dag_step
 
 template <bool FROM_IMAGE, bool DAG = false>
 __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* smem) {
@@ -1042,7 +1043,18 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
     const DagCnt dc(a.cnt, a.nblk);
     const int c = lane & 15;
     double rold[2][2][4];                                 // R_rj in the layout of the two 32-column passes: [pass][half][q]
-    if (j <= r - 2) {
+    if (j <= r - 2 && dag_ruform(a.nblk)) {
+        // (nblk > 32)  R_rj as the inverse-update tasks left it
+        if (tid == 0) wait_flag(dc.at(dc.ruver, r, j), r - j - 1, a.flag);
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rold[ps][h][q] = ld_sc1(M + (kr + 16 * wv + (lane >> 4) + 4 * q) * np + (long)j * CB + 32 * ps + 16 * h + c);
+    } else if (j <= r - 2) {
         // ---- accumulate the panels j .. r-2 (their tiles of L and of the inverse were finished steps ago)
         const int npan = r - 1 - j;
         wait_many(min(2 * npan, 64), [&](int t, const int*& w, int& want) {
@@ -1217,8 +1229,11 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 //    (tests/test_kernels_gpu.py::test_cholesky_split_step_equals_the_fused_step).
 // Task order inside step k (per lane): D(k) | the tile updates of block column k+1 (what D(k+1) and the row blocks of
 // step k+1 wait for) | the other tile updates | inverse row k-1 (left-looking: its updates included) | row blocks of step k.
-struct DagStep { int nD, nLA, nT, nMS, nRq, nRt, nrem; };
+struct DagStep { int nD, nLA, nT, nMS, nRU1, nRU, nRq, nRt, nrem, ruc; };
 __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1) / STRIP; }
+// ruform: the inverse's trailing updates as tasks of their own (read-modify-write strips, the form of the per-step
+// launches) instead of inside the inverse-row tasks -- for nblk > 32, where a left-looking inverse row would hold its
+// slot for up to 62 products
 __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     const int nrem = nblk - k - 1;
     DagStep s;
@@ -1234,11 +1249,15 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
                                                           // panels before, then two 32-column passes): row r of the inverse waits
                                                           // for row r - 1, so more tiles per task would be a longer chain (measured:
                                                           // four tiles per task doubled the build)
+    const bool ru = dag_ruform(nblk);
+    s.ruc = (ru && k >= 2) ? strips_of(k - 1) : 0;
+    s.nRU1 = (ru && k >= 2 && k < nblk) ? k - 1 : 0;      // inverse updates of row i = k (the next inverse row waits for them): single tiles
+    s.nRU = (ru && k >= 2 && k < nblk) ? (nblk - k - 1) * s.ruc : 0;        // rows i > k: strips
     s.nRq = (k < nblk && nrem >= 1) ? 4 : 0;              // tile (k + 1, k) as four 16-row blocks (on the chain)
     s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
     return s;
 }
-__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRq + s.nRt; }
+__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
 
 #ifdef CHOL_DAG_STATS      /* tools/exp/chol_dag_exp.hip: one record per task of the unit whose H is g_dag_log_H -- kind, begin, end, ticks in polls */
 __device__ long long* g_dag_log;
@@ -1315,6 +1334,27 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
         return;
     }
     t -= st.nMS;
+    if (t < st.nRU1 + st.nRU) {
+        // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
+        // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
+        int i, j0, cnt;
+        if (t < st.nRU1) { i = k; j0 = t; cnt = 1; }
+        else { t -= st.nRU1; i = k + 1 + t / st.ruc; j0 = STRIP * (t % st.ruc); cnt = min(STRIP, k - 1 - j0); }
+        const long mm = (long)(k - 2) * CB;
+        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
+            if (q == 0) { w = dc.at(dc.rowdone, k - 2, i); want = 4; }
+            else if (q & 1) { w = dc.at(dc.msdone, k - 2, j0 + (q - 1) / 2); want = 4; }
+            else { const int j = j0 + (q - 2) / 2; w = dc.at(dc.ruver, i, j); want = k - 2 - j; }
+        }, a.flag);
+        strip_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j0 * CB, CB, a.M + (long)i * CB * np + (long)j0 * CB, CB,
+                            k - 2 - j0, cnt, np);
+        drain_stores();
+        __syncthreads();
+        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DAG_STAT_END(3)
+        return;
+    }
+    t -= st.nRU1 + st.nRU;
     if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); DAG_STAT_END(4) return; }       // tile (k+1, k): four 16-row blocks
     t -= st.nRq;
     row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
@@ -1391,10 +1431,10 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     // MBFIR_CHOL_SPLIT: 4 = the whole factorisation in ONE launch (k_chol_dag; default), 1 = one launch per step with
     // the row blocks waiting for their lane's diagonal block on a flag, 2 = two launches per step, 0 = fused step
     // (every row block factorises L_kk itself; one launch per step).
-    // default: the single launch for lock-step batches; one or two designs keep a launch per step -- the fused step
-    // (every row block factorises L_kk itself: lowest latency) up to np = 2048, the split step from np = 4096 on, where the
-    // 4 (nblk - k - 1) row blocks of a step repeating the 64 pivots is what fills the chip (2.41 against 2.72 ms at np = 4096)
-    int split = nlanes >= 3 ? 4 : (np >= 4096 ? 1 : 0);
+    // default: the single launch for lock-step batches and, from np = 4096 on, for single designs too (1.9 ms against 2.4 for
+    // the split and 2.7 for the fused per-step form); one or two smaller designs keep the fused step, one launch per step
+    // (every row block factorises L_kk itself: lowest latency -- 350 against 375 us at np = 1024)
+    int split = (nlanes >= 3 || np >= 4096) ? 4 : 0;
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
     bool poison = false;
     if (const char* ev = std::getenv("MBFIR_POISON")) poison = std::atoi(ev) != 0;
