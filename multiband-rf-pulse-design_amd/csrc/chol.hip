@@ -443,7 +443,12 @@ constexpr int STEP_LDS = R3 + 336;                       // 79.4 KB
 
 // ---- in-launch hand-offs between workgroups (cdna_hip_programming.md guideline 16, recipe R1) -------------------
 // A pivot counter at or above CHOL_SYNC_LOST (dev_common.h) means a bounded flag poll expired: the factorisation is void.
-constexpr int CHOL_SPIN_LIMIT = 1 << 21;                  // x s_sleep(4) + one L2 round trip: several seconds
+constexpr int CHOL_SPIN_LIMIT_DEFAULT = 1 << 21;          // x s_sleep(4) + one L2 round trip: several seconds
+// test hooks (MBFIR_TEST_LOSE_FLAG, tests/test_switches_gpu.py): the poll bound, and the panel step whose diagonal block
+// "forgets" to publish its image -- the row blocks' polls must then expire and the solve must fail loudly
+__device__ int g_chol_spin_limit = CHOL_SPIN_LIMIT_DEFAULT;
+__device__ int g_chol_lose_step = -1;
+#define CHOL_SPIN_LIMIT g_chol_spin_limit
 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // pause between two polls: short at first (a hand-off on the chain is noticed quickly), longer when the wait drags on --
@@ -686,7 +691,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         if (DAG || a.phase == 1) {                        // release the row blocks (and the inverse-row blocks) of this lane
             drain_stores();                               // every storing wave: its sc1 stores have left the CU ...
             __syncthreads();                              // ... before the one lane that signals for all of them does
-            if (tid == 0) __hip_atomic_store(DAG ? dc.img + k : a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && k != g_chol_lose_step) __hip_atomic_store(DAG ? dc.img + k : a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TRACE(5)
         return;
@@ -1438,6 +1443,18 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
     bool poison = false;
     if (const char* ev = std::getenv("MBFIR_POISON")) poison = std::atoi(ev) != 0;
+    {   // test hook: lose the hand-off of one panel step (see g_chol_lose_step); the bound shrinks so that the test takes a second
+        static int lose_now = -1;
+        int lose = -1;
+        if (const char* ev = std::getenv("MBFIR_TEST_LOSE_FLAG")) lose = std::atoi(ev);
+        if (lose != lose_now) {
+            const int limit = lose >= 0 ? (1 << 14) : CHOL_SPIN_LIMIT_DEFAULT;
+            hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chol_lose_step), &lose, sizeof(int), 0, hipMemcpyHostToDevice, st);
+            hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chol_spin_limit), &limit, sizeof(int), 0, hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);
+            lose_now = lose;
+        }
+    }
     if ((long)dag_cnt_ints(nblk) * 4 > ((long)np * np - (long)np) * 8) split = split == 4 ? (nlanes >= 3 ? 1 : 0) : split;   // (W1 too small: np = 64)
     const int nsync = split == 4 ? dag_cnt_ints(nblk) : nblk + 1;
     hipLaunchKernelGGL(k_chol_init, dim3(cdiv(std::max(np, nsync), 256), nlanes), dim3(256), 0, st, H, np, W1, flag, a.sync, nsync, lane_bytes, mask,

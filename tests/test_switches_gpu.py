@@ -114,3 +114,22 @@ def test_dense_path_runs_lock_step_batches_too():
             assert np.array_equal(h, h1) and info["pcost"] == i1["pcost"]
     finally:
         ctx.close()
+
+
+def test_a_lost_in_launch_hand_off_fails_loudly(monkeypatch):
+    """when a hand-off between workgroups inside the factorisation never arrives (here: the diagonal
+    block of panel step 3 is told not to raise its flag -- a test hook), the waiting blocks' bounded polls expire, the
+    lane's pivot counter carries CHOL_SYNC_LOST, and the solve returns an internal ERROR -- it neither hangs nor goes on
+    with the previous build's image as if it were this build's.  Both forms that hand over inside a launch."""
+    jobs = [("fir_ap_cvx", (64, F6, A6, D3, 0.1, 1e-2 * (1 + 0.5 * k))) for k in range(4)]
+    for split in ("4", "1"):
+        ctx = mbfir.Context(0)
+        try:
+            with env(MBFIR_CHOL_SPLIT=split, MBFIR_TEST_LOSE_FLAG=0):
+                with pytest.raises(mbfir.MbfirError, match="hand-off"):
+                    mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=4, ddkkt=-1))
+            with env(MBFIR_CHOL_SPLIT=split, MBFIR_TEST_LOSE_FLAG=-1):       # and the same context works again afterwards
+                res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=4))
+                assert all(r[1] == "Solved" for r in res)
+        finally:
+            ctx.close()
