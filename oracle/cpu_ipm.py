@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_ref", "libcpu_ipm.so")
+_PATH = os.path.join(_HERE, "_build", "libcpu_ipm.so")
 _lib = None
 _dp = ctypes.POINTER(ctypes.c_double)
 
@@ -26,7 +26,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_PATH):
-            subprocess.run(["make", "-C", _HERE, "_ref/libcpu_ipm.so"], check=True, capture_output=True)
+            subprocess.run(["make", "-C", _HERE, "_build/libcpu_ipm.so"], check=True, capture_output=True)
         _lib = _bind(_PATH)
     return _lib
 
@@ -36,9 +36,9 @@ def use_native_build():
     instruction set the build selected, or None (and keeps the portable x86-64-v3 build) when the compiler is missing
     or the rebuilt library does not load."""
     global _lib
-    path = os.path.join(_HERE, "_ref", "libcpu_ipm_native.so")
+    path = os.path.join(_HERE, "_build", "libcpu_ipm_native.so")
     try:
-        subprocess.run(["make", "-B", "-C", _HERE, "_ref/libcpu_ipm_native.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-B", "-C", _HERE, "_build/libcpu_ipm_native.so"], check=True, capture_output=True)
         _lib = _bind(path)
         return _lib.cpu_ipm_isa().decode()
     except Exception:                                       # noqa: BLE001

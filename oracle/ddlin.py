@@ -1,6 +1,6 @@
 """ctypes binding of oracle/ddlin.c (double-double dense kernels; test infrastructure, see oracle/__init__.py).
 
-Built by `make -C oracle all` into oracle/_ref/libddlin.so (git-ignored, travels to the GPU box)."""
+Built by `make -C oracle all` into oracle/_build/libddlin.so (git-ignored, travels to the GPU box)."""
 import ctypes
 import os
 
@@ -13,9 +13,9 @@ _D = ctypes.POINTER(ctypes.c_double)
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libddlin.so")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libddlin.so")
         if not os.path.exists(path):
-            raise RuntimeError("oracle/_ref/libddlin.so missing: run `make -C oracle all`")
+            raise RuntimeError("oracle/_build/libddlin.so missing: run `make -C oracle all`")
         _LIB = ctypes.CDLL(path)
         _LIB.dd_chol.restype = ctypes.c_int
     return _LIB
