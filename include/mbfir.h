@@ -239,6 +239,11 @@ int mbfir_bloch(mbfir_ctx* ctx, int ntime, const double* b1_re, const double* b1
  *  mbfir_test_mfma_peak: measured fp64 MFMA rate, TFLOP/s (bench.py roofline peak).            */
 int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, const double* d, double* out);
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m);
+/*  mbfir_test_chol_lanes: the same for `nlanes` matrices factorised TOGETHER, the way a lock-step batch does it (lane index a
+ *  grid dimension / the single-launch form); H, out_l, out_m hold nlanes consecutive n x n blocks; mask (nlanes ints or NULL):
+ *  lanes with mask 0 are switched off (their outputs stay untouched).  form: -1 = the default of chol_inv_launch for this lane
+ *  count, otherwise the value of MBFIR_CHOL_SPLIT to use. */
+int mbfir_test_chol_lanes(mbfir_ctx* ctx, int n, int nlanes, int form, const int* mask, const double* H, double* out_l, double* out_m);
 int mbfir_test_specfact(mbfir_ctx* ctx, int n, const double* x, double* h_re, double* h_im);
 /*  mbfir_test_fold: the host-side analysis of a frequency grid w[m] for the lattice kernels (no GPU, no context): pairs
  *  +w / -w (fold != 0), cuts the folded list into equally spaced runs.  out[6]: lattice usable, folded entries, pairs,

@@ -108,6 +108,7 @@ SYMBOLS = {
     "mbfir_program_rows": (None, [C.c_void_p, _ip, _ip, _dp, _dp, _dp, _dp]),
     "mbfir_test_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "mbfir_test_chol_lanes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp]),
     "mbfir_test_specfact": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_fold": (C.c_int, [_dp, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     "mbfir_test_ddsolve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp]),
@@ -613,6 +614,19 @@ def test_chol(H, ctx=None):
     n = H.shape[0]
     L, M = np.zeros((n, n)), np.zeros((n, n))
     _check(ctx, load_library().mbfir_test_chol(ctx._h, n, _ptr(H), _ptr(L), _ptr(M)))
+    return L, M
+
+
+def test_chol_lanes(Hs, form=-1, mask=None, ctx=None):
+    """Hs: (nlanes, n, n) SPD matrices factorised together like a lock-step batch; returns (L, M) of shape (nlanes, n, n)."""
+    ctx = ctx or get_context()
+    Hs = np.ascontiguousarray(Hs, dtype=np.float64)
+    nl, n = Hs.shape[0], Hs.shape[1]
+    L, M = np.zeros((nl, n, n)), np.zeros((nl, n, n))
+    mk = None
+    if mask is not None:
+        mk = (C.c_int * nl)(*[int(v) for v in mask])
+    _check(ctx, load_library().mbfir_test_chol_lanes(ctx._h, n, nl, int(form), mk, _ptr(Hs), _ptr(L), _ptr(M)))
     return L, M
 
 

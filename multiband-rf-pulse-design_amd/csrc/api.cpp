@@ -463,6 +463,9 @@ int mbfir_test_gram(mbfir_ctx* ctx, int m, int nt, int nw, const double* A, cons
 int mbfir_test_chol(mbfir_ctx* ctx, int n, const double* H, double* out_l, double* out_m) {
     MBFIR_TRY(ctx, ctx->solver->test_chol(n, H, out_l, out_m));
 }
+int mbfir_test_chol_lanes(mbfir_ctx* ctx, int n, int nlanes, int form, const int* mask, const double* H, double* out_l, double* out_m) {
+    MBFIR_TRY(ctx, ctx->solver->test_chol_lanes(n, nlanes, form, mask, H, out_l, out_m));
+}
 int mbfir_test_ddsolve(mbfir_ctx* ctx, int n, int k, const double* H, const double* U, const double* X, int nrhs,
                        const double* bh, const double* bl, double* xh, double* xl, int* nfix, double* Lh, double* Ll) {
     if (!ctx || n < 1 || k < 0 || nrhs < 1 || nrhs > 2 || !H || !bh || !bl || !xh || !xl || !nfix) return MBFIR_E_ARG;

@@ -1407,6 +1407,18 @@ __global__ void k_extract_L(const double* __restrict__ H, int np, const double* 
     Lout[e] = v;
 }
 
+// (declared in dev_common.h for the kernel test hooks of solver.hip)
+__global__ void k_extract_L_pub(const double* __restrict__ H, int np, const double* __restrict__ Dfac,
+                                const double* __restrict__ dinvG, double* __restrict__ Lout) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)np * np) return;
+    long i = e / np, j = e - i * np;
+    double v = 0.0;
+    if (j == i) v = 1.0 / dinvG[i];
+    else if (j < i) v = ((i / CB) == (j / CB)) ? Dfac[(i / CB) * CB * CB + (j % CB) * CB + zpos(int(i % CB))] : H[e];
+    Lout[e] = v;
+}
+
 __global__ void k_transpose(const double* __restrict__ M, double* __restrict__ Mt, int np, size_t lane_bytes,
                             const int* __restrict__ mask) {
     __shared__ double tile[32][33];

@@ -93,6 +93,10 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
                     double* Lcopy = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int nlanes = 1,
                     size_t lane_bytes = 0, const int* mask = nullptr);   // on exit H is scratch; Lcopy (optional) receives L
 
+// L (np x np, clean lower triangle) from a factored H, the diagonal-block images (W1 + np) and 1 / diag(L) (W1 + 65 np)
+__global__ void k_extract_L_pub(const double* __restrict__ H, int np, const double* __restrict__ Dfac,
+                                const double* __restrict__ dinvG, double* __restrict__ Lout);
+
 // y[v] = Lo * (b[v] + b2[v]) for a row-major lower (upper=0) or upper (upper=1) triangular np x np
 // matrix; b2 may be null.
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,

@@ -67,6 +67,7 @@ public:
     // kernel test hooks
     void test_gram(int m, int nt, int nw, const double* A, const double* d, double* out);
     void test_chol(int n, const double* H, double* out_l, double* out_m);
+    void test_chol_lanes(int n, int nlanes, int form, const int* mask, const double* H, double* out_l, double* out_m);
     void test_specfact(int n, const double* x, double* h_re, double* h_im);
     void test_ddsolve(int n, int k, const double* H, const double* U, const double* X, int nrhs, const double* bh,
                       const double* bl, double* xh, double* xl, int* nfix, double* Lh_out = nullptr, double* Ll_out = nullptr);

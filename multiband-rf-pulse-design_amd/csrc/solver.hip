@@ -3016,6 +3016,61 @@ void Solver::test_chol(int n, const double* Hh, double* out_l, double* out_m) {
             if (Mh[i * np + j] != Mth[j * np + i]) throw HipError("test_chol: the stored transpose differs from the inverse factor");
 }
 
+// nlanes matrices factorised together, lanes lane_bytes apart in ONE arena like a lock-step batch's (H | M | Mt | W1 | flag)
+void Solver::test_chol_lanes(int n, int nlanes, int form, const int* mask, const double* Hh, double* out_l, double* out_m) {
+    Impl& S = *impl;
+    MBFIR_HIP(hipSetDevice(S.device));
+    if (nlanes < 1 || nlanes > MAX_LANES) throw HipError("test_chol_lanes: bad lane count");
+    const size_t np = round_up(n, 64);
+    const size_t lane_doubles = 4 * np * np + 80 * np + 64, lane_bytes = lane_doubles * 8;
+    DevBuf arena(lane_bytes * nlanes), dL(np * np * 8), dmask(sizeof(int) * MAX_LANES);
+    MBFIR_HIP(hipMemsetAsync(arena.p, 0, lane_bytes * nlanes, S.st));
+    double* base = arena.as<double>();
+    double *dH = base, *dM = base + np * np, *dMt = dM + np * np, *dW = dMt + np * np;
+    int* df = reinterpret_cast<int*>(dW + np * np + 70 * np);
+    if (mask) MBFIR_HIP(hipMemcpyAsync(dmask.p, mask, sizeof(int) * nlanes, hipMemcpyHostToDevice, S.st));
+    const char* old = std::getenv("MBFIR_CHOL_SPLIT");
+    const std::string keep = old ? old : "";
+    if (form >= 0) setenv("MBFIR_CHOL_SPLIT", std::to_string(form).c_str(), 1);
+    std::vector<double> Hp(np * np);
+    // a different matrix first (later builds find the previous build's numbers in the buffers), then the ones asked for
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int b = 0; b < nlanes; ++b) {
+            std::fill(Hp.begin(), Hp.end(), 0.0);
+            for (size_t i = 0; i < np; ++i) Hp[i * np + i] = 1.0;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) Hp[i * np + j] = Hh[((size_t)b * n + i) * n + j];
+            if (pass == 0) for (size_t i = 0; i < np; ++i) Hp[i * np + i] = 2.0 * Hp[i * np + i] + 1.0;
+            MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(dH) + b * lane_bytes, Hp.data(), np * np * 8, hipMemcpyHostToDevice, S.st));
+            MBFIR_HIP(hipStreamSynchronize(S.st));
+        }
+        chol_inv_launch(dH, dM, dMt, dW, int(np), df, S.st, nullptr, nullptr, nullptr, nlanes, lane_bytes, mask ? dmask.as<int>() : nullptr);
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+    }
+    if (form >= 0) { if (old) setenv("MBFIR_CHOL_SPLIT", keep.c_str(), 1); else unsetenv("MBFIR_CHOL_SPLIT"); }
+    MBFIR_HIP(hipGetLastError());
+    std::vector<int> fl(1);
+    for (int b = 0; b < nlanes; ++b) {
+        if (mask && !mask[b]) continue;
+        const size_t off = (size_t)b * lane_bytes;
+        auto at = [&](double* p) { return reinterpret_cast<double*>(reinterpret_cast<char*>(p) + off); };
+        MBFIR_HIP(hipMemcpyAsync(fl.data(), reinterpret_cast<char*>(df) + off, sizeof(int), hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+        if (fl[0] != 0) throw HipError("test_chol_lanes: pivots replaced or a hand-off lost (counter " + std::to_string(fl[0]) + ")");
+        hipLaunchKernelGGL(k_extract_L_pub, dim3(cdiv((long)np * np, 256)), dim3(256), 0, S.st, at(dH), int(np), at(dW) + np, at(dW) + 65 * np, dL.as<double>());
+        MBFIR_HIP(hipMemcpy2DAsync(out_l + (size_t)b * n * n, (size_t)n * 8, dL.p, np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipMemcpy2DAsync(out_m + (size_t)b * n * n, (size_t)n * 8, at(dM), np * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, S.st));
+        // the stored transpose (what the second triangular GEMV reads) against the inverse factor
+        std::vector<double> Mh(np * np), Mth(np * np);
+        MBFIR_HIP(hipMemcpyAsync(Mh.data(), at(dM), np * np * 8, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipMemcpyAsync(Mth.data(), at(dMt), np * np * 8, hipMemcpyDeviceToHost, S.st));
+        MBFIR_HIP(hipStreamSynchronize(S.st));
+        for (size_t i = 0; i < np; ++i)
+            for (size_t j = 0; j <= i; ++j)
+                if (Mh[i * np + j] != Mth[j * np + i]) throw HipError("test_chol_lanes: the stored transpose differs from the inverse factor");
+    }
+}
+
 // x = (H + U' diag(X) U)^-1 b through the double-double kernels (ddlin.hip); b and x are dd (hi, lo), nrhs <= 2
 void Solver::test_ddsolve(int n, int k, const double* Hh, const double* U, const double* X, int nrhs, const double* bh,
                           const double* bl, double* xh, double* xl, int* nfix, double* Lh_out, double* Ll_out) {

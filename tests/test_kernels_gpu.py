@@ -167,3 +167,33 @@ def test_double_double_solve_with_one_right_hand_side_equals_the_first_of_two():
     xh2, xl2, _ = mbfir.test_ddsolve(Hw, U, X, b, bl)
     xh1, xl1, _ = mbfir.test_ddsolve(Hw, U, X, b[:1], bl[:1])
     assert np.array_equal(xh1[0], xh2[0]) and np.array_equal(xl1[0], xl2[0])
+
+
+@pytest.mark.parametrize("n,nl", [(130, 3), (449, 5), (1023, 8)])
+def test_cholesky_of_a_lock_step_batch_every_form_bit_identical(n, nl):
+    """K4 as a lock-step batch runs it: `nl` different matrices factorised TOGETHER (mbfir_test_chol_lanes), in every form
+    of chol_inv_launch -- fused per-step (0), split per-step with the device flag (1), split in two launches (2), the whole
+    factorisation in ONE launch with ticket-ordered tasks (4, the default for >= 3 lanes).  Every lane's L and L^-1 are the
+    same bit for bit in all forms and equal to the single-matrix factorisation; the stored transpose equals the inverse
+    factor (checked inside the hook); a masked lane leaves the others untouched."""
+    rng = np.random.default_rng(100 * n + nl)
+    Hs = []
+    for b in range(nl):
+        B = rng.standard_normal((n + 20, n))
+        Hs.append(B.T @ B + (0.1 + 0.05 * b) * np.eye(n))
+    Hs = np.array(Hs)
+    ref = [mbfir.test_chol(H) for H in Hs]                      # one matrix at a time (fused step)
+    outs = {form: mbfir.test_chol_lanes(Hs, form=form) for form in (0, 1, 2, 4, -1)}
+    for form, (L, M) in outs.items():
+        for b in range(nl):
+            assert np.array_equal(L[b], ref[b][0]) and np.array_equal(M[b], ref[b][1]), (form, b)
+    for b in range(nl):
+        assert relinf(ref[b][0], np.linalg.cholesky(Hs[b])) <= 1e-12
+    mask = [1] * nl
+    mask[1] = 0
+    L, M = mbfir.test_chol_lanes(Hs, form=4, mask=mask)
+    for b in range(nl):
+        if mask[b]:
+            assert np.array_equal(L[b], ref[b][0]) and np.array_equal(M[b], ref[b][1])
+        else:
+            assert not L[b].any() and not M[b].any()
