@@ -4,6 +4,7 @@
 // All fp64; tile products on v_mfma_f64_16x16x4_f64.
 #include "dev_common.h"
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1542,6 +1543,110 @@ __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, i
         double s = wave_sum(acc[v]);
         if (lane == 0) y[(long)v * ldv + i] = s;
     }
+}
+
+// x = M'(M b) in ONE pass over the inverse factor:  x = sum_i m_i (m_i . b), m_i = row i of M.  A wave owns a row at a
+// time: every lane holds its 2 x U columns of the row (U = np / 128), the dot product is a wave reduction, the row -- still
+// in registers -- is added to the lane's slice of x.  Workgroup g of HS_G takes the rows g, g + HS_G, ... (the rows of a
+// triangle are unequal: dealt cyclically), reduces its four waves' slices through LDS and writes one partial vector;
+// k_hsolve_fold adds the HS_G partials in a fixed order.  M is read ONCE per application (the two triangular GEMVs read
+// M and its stored transpose: twice the bytes), and the transpose need not be stored at all.  np <= 1024 (U = ceil(np / 128) <= 8).
+constexpr int HS_G = 32;
+template <int NV, int U>
+__global__ __launch_bounds__(256) void k_hsolve(const double* __restrict__ M, int np, const double* __restrict__ b,
+                                                const double* __restrict__ b2, double* __restrict__ part, int ldv,
+                                                size_t lane_bytes, const int* __restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) double hs_lds[];      // [4 waves][NV][np]
+    if (mask && !mask[blockIdx.y]) return;
+    if (blockIdx.y) {
+        const size_t off = (size_t)blockIdx.y * lane_bytes;
+        M = lane_at(M, off); b = lane_at(b, off); part = lane_at(part, off);
+        if (b2) b2 = lane_at(b2, off);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = blockIdx.x;
+    double2 bb[NV][U], xa[NV][U];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = 2 * lane + 128 * u;
+            bb[v][u] = j < np ? *reinterpret_cast<const double2*>(b + (long)v * ldv + j) : make_double2(0.0, 0.0);
+            if (b2 && j < np) { const double2 c = *reinterpret_cast<const double2*>(b2 + (long)v * ldv + j); bb[v][u].x += c.x; bb[v][u].y += c.y; }
+            xa[v][u] = make_double2(0.0, 0.0);
+        }
+    for (int i = g + HS_G * wv; i < np; i += 4 * HS_G) {
+        const double* row = M + (long)i * np;
+        const int jhi = ((i >> 6) + 1) << 6;              // the row ends with its diagonal tile (exact zeros above the diagonal there)
+        double2 m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = 2 * lane + 128 * u;
+            m[u] = j < jhi ? *reinterpret_cast<const double2*>(row + j) : make_double2(0.0, 0.0);
+        }
+        double al[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double a = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) a += m[u].x * bb[v][u].x + m[u].y * bb[v][u].y;
+            al[v] = __shfl(wave_sum(a), 0, 64);          // (wave_sum leaves the total in lane 0)
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int u = 0; u < U; ++u) { xa[v][u].x += al[v] * m[u].x; xa[v][u].y += al[v] * m[u].y; }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<double2*>(hs_lds + ((long)wv * NV + v) * (U * 128) + 2 * lane + 128 * u) = xa[v][u];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NV * np; e += 256) {
+        const int v = e / np, j = e - v * np;
+        const long w = U * 128;
+        const double s = ((hs_lds[(0L * NV + v) * w + j] + hs_lds[(1L * NV + v) * w + j]) + hs_lds[(2L * NV + v) * w + j]) + hs_lds[(3L * NV + v) * w + j];
+        part[((long)g * NV + v) * np + j] = s;
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void k_hsolve_fold(const double* __restrict__ part, int np, double* __restrict__ out, int ldv,
+                                                     size_t lane_bytes, const int* __restrict__ mask) {
+    if (mask && !mask[blockIdx.y]) return;
+    if (blockIdx.y) { const size_t off = (size_t)blockIdx.y * lane_bytes; part = lane_at(part, off); out = lane_at(out, off); }
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= np) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double s = 0;
+        for (int g = 0; g < HS_G; ++g) s += part[((long)g * NV + v) * np + j];
+        out[(long)v * ldv + j] = s;
+    }
+}
+bool hsolve_fused_ok(int np, int nv) { return np % 64 == 0 && np <= 1024 && (nv == 1 || nv == 2); }
+size_t hsolve_part_doubles(int np) { return (size_t)HS_G * 2 * np; }
+// out = M'M (b + b2); part: hsolve_part_doubles(np) doubles of scratch per lane
+void hsolve_launch(const double* M, int np, const double* b, const double* b2, double* out, double* part, int nv, int ldv,
+                   hipStream_t st, int nlanes, size_t lane_bytes, const int* mask) {
+    if (!hsolve_fused_ok(np, nv)) throw HipError("hsolve_launch: unsupported size");
+    const dim3 grid(HS_G, nlanes), gf(cdiv(np, 256), nlanes);
+    const int U = (np + 127) / 128;
+    const size_t lds = (size_t)4 * nv * U * 128 * sizeof(double);
+#define HS_CASE(NVX, UX)                                                                                                   \
+    {                                                                                                                      \
+        static std::once_flag once;                                                                                        \
+        std::call_once(once, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hsolve<NVX, UX>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NVX * UX * 128 * 8); }); \
+        hipLaunchKernelGGL((k_hsolve<NVX, UX>), grid, dim3(256), lds, st, M, np, b, b2, part, ldv, lane_bytes, mask);     \
+    }
+    if (nv == 1) {
+        switch (U) { case 1: HS_CASE(1, 1) break; case 2: HS_CASE(1, 2) break; case 3: HS_CASE(1, 3) break; case 4: HS_CASE(1, 4) break;
+                     case 5: HS_CASE(1, 5) break; case 6: HS_CASE(1, 6) break; case 7: HS_CASE(1, 7) break; default: HS_CASE(1, 8) break; }
+        hipLaunchKernelGGL(k_hsolve_fold<1>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
+    } else {
+        switch (U) { case 1: HS_CASE(2, 1) break; case 2: HS_CASE(2, 2) break; case 3: HS_CASE(2, 3) break; case 4: HS_CASE(2, 4) break;
+                     case 5: HS_CASE(2, 5) break; case 6: HS_CASE(2, 6) break; case 7: HS_CASE(2, 7) break; default: HS_CASE(2, 8) break; }
+        hipLaunchKernelGGL(k_hsolve_fold<2>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
+    }
+#undef HS_CASE
 }
 
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,

@@ -102,6 +102,13 @@ __global__ void k_extract_L_pub(const double* __restrict__ H, int np, const doub
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,
                     hipStream_t st, const double* b2 = nullptr, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
 
+// out = M'M (b + b2) in one pass over M (np % 128 == 0, np <= 1024, nv 1 or 2: hsolve_fused_ok); part: scratch of
+// hsolve_part_doubles(np) doubles per lane
+bool hsolve_fused_ok(int np, int nv);
+size_t hsolve_part_doubles(int np);
+void hsolve_launch(const double* M, int np, const double* b, const double* b2, double* out, double* part, int nv, int ldv,
+                   hipStream_t st, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
+
 // Double-double dense kernels (ddlin.hip): H(dd) = Hh + sum_{r < *kcount} X[r] U[r] U[r]' on the lower-triangle
 // tiles; in-place dd Cholesky (L in the lower triangle of (Hh, Hl), L' in (Lth, Ltl), 1/diag(L) in (rih, ril),
 // flag[0] = replaced pivots, d0 = np doubles of work space); (L L')^-1 B for nv = 1 or 2 dd right-hand sides.

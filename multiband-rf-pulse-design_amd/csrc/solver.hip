@@ -1874,6 +1874,7 @@ struct Solver::Impl {
     long chol_launch_count = 0;  // k_chol_step launches of the current solve
     size_t lane_bytes = 0;
     bool lane_live[64] = {};     // host copy of mask row 0 (the dense Gram products are launched per lane)
+    bool fused_hsolve = false;   // x = M'(M b) in one pass over M (np <= 1024, no extended-precision solve): no stored transpose
     int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
                                  // still need CG sweep q, row MAX_SWEEPS + 1 = scratch (lanes with a new best iterate)
     int* hostMask = nullptr;     // pinned twin
@@ -2077,8 +2078,14 @@ struct Solver::Impl {
     template <int NV>
     void hsolve(const double* rhs, double* out, const double* rhs2 = nullptr) {
         if (!lead_factor() || shard_rank == 0) {
-            trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2, nlanes, lane_bytes, P.mask);
-            trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st, nullptr, nlanes, lane_bytes, P.mask);
+            if (fused_hsolve) {
+                // one pass over the inverse factor (chol.hip k_hsolve); its partial vectors borrow the moment kernels'
+                // partial buffer, which is idle between a G'v product and the next
+                hsolve_launch(M, P.np, rhs, rhs2, out, partial, NV, P.LDV, st, nlanes, lane_bytes, P.mask);
+            } else {
+                trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2, nlanes, lane_bytes, P.mask);
+                trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st, nullptr, nlanes, lane_bytes, P.mask);
+            }
         }
         if (lead_factor()) {
             if (shard_rank != 0) hipMemsetAsync(out, 0, sizeof(double) * NV * P.LDV, st);
@@ -2270,7 +2277,8 @@ struct Solver::Impl {
             dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st);
             if (c1) hipEventRecord(c1, st);
         } else if (mine) {
-            chol_launch_count += chol_inv_launch(H, M, Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
+            // (with the one-pass M'(M b) nobody reads the transpose: it is not written)
+            chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
         } else {
             if (c0) hipEventRecord(c0, st);
             if (c1) hipEventRecord(c1, st);
@@ -2587,6 +2595,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     std::vector<int> tiles(gram_table_ints(S.gp));
     gram_tiles_host(S.gp, tiles.data());
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
+    S.fused_hsolve = hsolve_fused_ok(int(np), 2);
+    if (const char* ev = std::getenv("MBFIR_HSOLVE")) S.fused_hsolve = S.fused_hsolve && std::atoi(ev) != 0;       // 0: the two triangular GEMVs
     Arena& ar = S.ar;
     char* zero_from = nullptr;
     size_t zero_bytes = 0;
@@ -2634,7 +2644,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
     S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.PPf = ar.get<double2>(6 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
-    S.partial = ar.get<double>(P.trig ? (size_t)cdiv(P.nchunk, P.cgrp) * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld);
+    S.partial = ar.get<double>(std::max(P.trig ? (size_t)cdiv(P.nchunk, P.cgrp) * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld,
+                                        hsolve_part_doubles(int(np))));         // (also the partial vectors of the one-pass M'(M b))
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     if (use_dd) {
         DDev& D = S.D;

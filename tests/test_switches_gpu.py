@@ -6,6 +6,7 @@ environment switch (read at solve time), and the switched-off form is the refere
   MBFIR_CHOL_SPLIT     4 (default for lock-step batches): the factorisation in one launch; 1: one launch per panel step with
                        the device flag; 2: the split step as two launches; 0: the fused single-design step
   MBFIR_POISON=1       NaN in the diagonal-block images before every build (a stale read shows deterministically)
+  MBFIR_HSOLVE=0       the preconditioner M'(M b) as two triangular GEMVs on M and the stored M' instead of one pass over M
   MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
 """
 import os
@@ -96,6 +97,23 @@ def test_single_chunk_blocks_agree_to_rounding():
     other = _batch(MBFIR_CGRP=1)
     for (h0, _, i0), (h1, _, i1) in zip(base, other):
         assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+
+
+def test_one_pass_preconditioner_application_agrees_with_the_two_triangular_products():
+    """x = M'(M b) in one pass over the inverse factor (x = sum_i m_i (m_i . b), the default up to np = 1024: M is read once
+    and its transpose is never stored) against the two triangular GEMVs on M and the stored M' (MBFIR_HSOLVE=0): the same
+    sums in another order -- same iteration counts, taps equal to rounding; single solves and lock-step lanes."""
+    base = _batch()
+    other = _batch(MBFIR_HSOLVE=0)
+    for (h0, _, i0), (h1, _, i1) in zip(base, other):
+        assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+    for which, args, okw in CASES[:2]:
+        fn = getattr(mbfir, which)
+        opts = mbfir.make_opts(**okw) if okw else None
+        with env(MBFIR_HSOLVE=0):
+            h0, s0, i0 = fn(*args, info=True, opts=opts)
+        h1, s1, i1 = fn(*args, info=True, opts=opts)
+        assert s0 == s1 == "Solved" and abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
 
 
 def test_dense_path_runs_lock_step_batches_too():
