@@ -1512,9 +1512,14 @@ __global__ void k_flag_share(int* flag, double* slot, int mode) {
 __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const double* __restrict__ MomB,
                                  double* __restrict__ H, double pad_diag) {
     LANES(P, Mom, MomB, H);
-    int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    // grid: (lower 64 x 64 tiles, 16 row quads of a tile): the factorisations read the lower tiles only, so only those are
+    // formed -- a block is 4 rows x 64 columns of one tile, every thread has work and a row segment is one 512-byte store
+    int ti = int((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= int(blockIdx.x)) ++ti;
+    while (ti * (ti + 1) / 2 > int(blockIdx.x)) --ti;
+    const int tk = int(blockIdx.x) - ti * (ti + 1) / 2;
+    const int j = 64 * ti + 4 * blockIdx.y + (threadIdx.x >> 6), k = 64 * tk + (threadIdx.x & 63);
     if (k >= P.np || j >= P.np) return;
-    if (k > (j | 63)) return;                             // the factorisations read the lower 64 x 64 tiles only
     double v = 0;
     const long mw = 2L * P.LDM;
     if (j < P.Nt && k < P.Nt) {
@@ -2226,7 +2231,7 @@ struct Solver::Impl {
                 }
             }
             if (!lead_factor() || shard_rank == 0)
-                hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
+                hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3((P.np / 64) * (P.np / 64 + 1) / 2, 16), nlanes), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
             if (g1) hipEventRecord(g1, st);
         } else {
         // the dense Gram products, one lane after the other (a k_gram launch fills the chip by itself: 340 us at the
