@@ -134,7 +134,7 @@ def s_lp_baseline(mbfir, ctx):
 def pmc_traffic():
     """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from this round's PMC passes (tools/rocprof_summary.py writes
     profiles/r03_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <thread>
 
@@ -331,73 +333,119 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
     const bool sharded = opts && opts->shard_size > 1;
     int lanes_cap = opts && opts->lanes != 0 ? opts->lanes : 0;              // 0 = automatic, 1 = never lock-step
     if (const char* ev = std::getenv("MBFIR_LANES")) lanes_cap = std::atoi(ev);
-    // ---- host assembly, in parallel --------------------------------------------------------------
+    // ---- host assembly, in parallel; units start as soon as their designs are assembled -------------------
+    // Round 2 assembled all jobs, then grouped, then started the units: 8 ms of a 265 ms headline batch with the GPU idle,
+    // and the unit that decides the makespan (the tight-ripple designs at the head of a sweep) started last of all.  Now the
+    // assembly threads take the jobs in order, and a coordinator (the calling thread) hands a unit to the waiting contexts
+    // the moment its designs are there.  The units are formed SPECULATIVELY from neighbours in the job list on the
+    // assumption that the batch has one shape (a sweep): the first design that differs from job 0, or fails to assemble,
+    // ends the speculation, and what has not been handed out yet is grouped by shape as before.
     std::vector<TrigProgram> progs(njobs);
     std::vector<int> arc(njobs, 0);
     std::vector<std::vector<long>> keys(njobs);
-    {
-        std::atomic<int> next(0);
-        auto asm_work = [&]() {
-            for (;;) {
-                const int q = next.fetch_add(1);
-                if (q >= njobs) break;
-                std::string e;
-                jobs[q].err[0] = 0;
-                arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
-                if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
-                else if (!(sharded || lanes_cap == 1)) {
-                    // the shape key (CSR maps, lattice analysis: a sort of the grid) here, not in the serial grouping loop:
-                    // 64 headline designs cost 40 ms there with the GPU idle; the structures stay with the program
-                    const SolveOpts so = to_opts(opts, progs[q].which);
-                    keys[q] = Solver::shape_key(progs[q], so);
-                    keys[q].push_back(Solver::max_lanes(progs[q], so));
+    std::mutex mu;
+    std::condition_variable cv_asm, cv_units;
+    std::vector<char> assembled(njobs, 0);
+    std::vector<std::vector<int>> units;
+    size_t units_taken = 0;
+    bool units_closed = false;
+    const bool trace = std::getenv("MBFIR_TRACE_BATCH") != nullptr;
+    std::atomic<int> next_asm(0);
+    auto asm_work = [&]() {
+        for (;;) {
+            const int q = next_asm.fetch_add(1);
+            if (q >= njobs) break;
+            std::string e;
+            jobs[q].err[0] = 0;
+            arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
+            if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
+            else if (!(sharded || lanes_cap == 1)) {
+                // the shape key (CSR maps, lattice analysis: a sort of the grid) here, not in the serial grouping loop:
+                // 64 headline designs cost 40 ms there with the GPU idle; the structures stay with the program
+                const SolveOpts so = to_opts(opts, progs[q].which);
+                keys[q] = Solver::shape_key(progs[q], so);
+                keys[q].push_back(Solver::max_lanes(progs[q], so));
+            }
+            { std::lock_guard<std::mutex> lk(mu); assembled[q] = 1; }
+            cv_asm.notify_all();
+        }
+    };
+    auto wait_assembled = [&](int lo, int hi) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_asm.wait(lk, [&] { for (int q = lo; q < hi; ++q) if (!assembled[q]) return false; return true; });
+    };
+    auto push_unit = [&](std::vector<int> u) {
+        { std::lock_guard<std::mutex> lk(mu); units.push_back(std::move(u)); }
+        cv_units.notify_one();
+    };
+    int order = 0;
+    if (const char* ev = std::getenv("MBFIR_UNIT_ORDER")) order = std::atoi(ev);
+    // ---- units: designs of one shape, up to `lanes` of them ------------------------------------------
+    auto coordinate = [&]() {
+        if (sharded || lanes_cap == 1) {
+            wait_assembled(0, njobs);
+            for (int q = 0; q < njobs; ++q) push_unit({q});
+            return;
+        }
+        // enough units to occupy every context, no more lanes per unit than the shape allows; an explicit request never
+        // exceeds what the shape allows
+        auto lanes_per_unit = [&](int cap, int G) {
+            int per = std::min(cap, std::max(1, (G + nctx - 1) / nctx));
+            if (lanes_cap > 1) per = std::min(std::min(lanes_cap, cap), G);
+            return std::max(1, per);
+        };
+        int handed = 0;                                            // jobs [0, handed) are in units already
+        if (njobs > 0 && order != 1) {
+            wait_assembled(0, 1);
+            if (arc[0] == 0) {
+                const int per = lanes_per_unit(int(keys[0].back()), njobs);
+                while (handed < njobs) {
+                    const int hi = std::min(njobs, handed + per);
+                    wait_assembled(handed, hi);
+                    bool same = true;
+                    for (int q = handed; q < hi && same; ++q) same = arc[q] == 0 && keys[q] == keys[0];
+                    if (!same) break;
+                    std::vector<int> u;
+                    for (int q = handed; q < hi; ++q) u.push_back(q);
+                    push_unit(std::move(u));
+                    if (trace && handed == 0) std::fprintf(stderr, "[batch] first unit handed out at %.2f ms\n", now_ms() - t0);
+                    handed = hi;
                 }
             }
-        };
-        const int nth = std::max(1, std::min(njobs, std::min(16, int(std::thread::hardware_concurrency()))));
-        std::vector<std::thread> th;
-        for (int c = 1; c < nth; ++c) th.emplace_back(asm_work);
-        asm_work();
-        for (auto& t : th) t.join();
-    }
-    // ---- units: designs of one shape, up to `lanes` of them ------------------------------------------
-    std::vector<std::vector<int>> units;
-    if (sharded || lanes_cap == 1) {
-        for (int q = 0; q < njobs; ++q) units.push_back({q});
-    } else {
+        }
+        wait_assembled(handed, njobs);
+        if (trace) std::fprintf(stderr, "[batch] %d jobs assembled at %.2f ms\n", njobs, now_ms() - t0);
         std::map<std::vector<long>, std::vector<int>> groups;
-        for (int q = 0; q < njobs; ++q) {
-            if (arc[q] != 0) { units.push_back({q}); continue; }             // the single-design path reports the assembly error
+        for (int q = handed; q < njobs; ++q) {
+            if (arc[q] != 0) { push_unit({q}); continue; }                  // the single-design path reports the assembly error
             groups[keys[q]].push_back(q);
         }
         for (auto& g : groups) {
-            const int cap = int(g.first.back()), G = int(g.second.size());
-            // enough units to occupy every context, no more lanes per unit than the shape allows
-            int per = std::min(cap, std::max(1, (G + nctx - 1) / nctx));
-            if (lanes_cap > 1) per = std::min(std::min(lanes_cap, cap), G);      // an explicit request never exceeds what the shape allows
+            const int G = int(g.second.size()), per = lanes_per_unit(int(g.first.back()), G);
             // Which designs share a unit: neighbours in the job list (a sweep's neighbours tend to need similar
             // iteration counts, so the lanes of a unit finish together) or, MBFIR_UNIT_ORDER=1, dealt round-robin over
             // the units (every unit gets its share of the slow designs: at the end of the batch all streams still
             // have live lanes instead of one stream running the slow unit alone)
             const int nunits = (G + per - 1) / per;
-            int order = 0;
-            if (const char* ev = std::getenv("MBFIR_UNIT_ORDER")) order = std::atoi(ev);
             if (order == 1 && nunits > 1) {
                 std::vector<std::vector<int>> us(nunits);
                 for (int i = 0; i < G; ++i) us[i % nunits].push_back(g.second[i]);
-                for (auto& u : us) units.push_back(u);
+                for (auto& u : us) push_unit(u);
             } else {
-                for (int i = 0; i < G; i += per) units.emplace_back(g.second.begin() + i, g.second.begin() + std::min(G, i + per));
+                for (int i = 0; i < G; i += per) push_unit(std::vector<int>(g.second.begin() + i, g.second.begin() + std::min(G, i + per)));
             }
         }
-    }
-    std::atomic<int> next(0);
+    };
     auto work = [&](int c) {
         mbfir_ctx* ctx = ctxs[c];
         for (;;) {
-            const int u = next.fetch_add(1);
-            if (u >= int(units.size())) break;
-            const std::vector<int>& U = units[u];
+            std::vector<int> U;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_units.wait(lk, [&] { return units_taken < units.size() || units_closed; });
+                if (units_taken >= units.size()) break;
+                U = units[units_taken++];
+            }
             auto finish_job = [&](int q) {
                 mbfir_job& J = jobs[q];
                 if (J.rc < 0 && !J.err[0]) std::snprintf(J.err, sizeof(J.err), "%s", ctx->err.c_str());
@@ -440,11 +488,24 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
             }
         }
     };
-    const int nthreads = std::min(nctx, int(units.size()));
     std::vector<std::thread> th;
-    for (int c = 1; c < nthreads; ++c) th.emplace_back(work, c);
-    if (nthreads > 0) work(0);
+    const int nasm = std::max(1, std::min(njobs, std::min(16, int(std::thread::hardware_concurrency()))));
+    const int nwork = std::max(1, std::min(nctx, njobs));
+    for (int c = 0; c < nasm; ++c) th.emplace_back(asm_work);
+    for (int c = 0; c < nwork; ++c) th.emplace_back(work, c);
+    std::string coord_err;
+    try { coordinate(); } catch (const std::exception& e) { coord_err = e.what(); }
+    { std::lock_guard<std::mutex> lk(mu); units_closed = true; }
+    cv_units.notify_all();
     for (auto& t : th) t.join();
+    if (trace) std::fprintf(stderr, "[batch] %zu units, all done at %.2f ms\n", units.size(), now_ms() - t0);
+    if (!coord_err.empty()) {
+        for (int q = 0; q < njobs; ++q) {                  // (host memory exhausted while forming units: nothing of the batch is reported)
+            jobs[q].rc = MBFIR_E_HIP;
+            std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", coord_err.c_str());
+        }
+        return MBFIR_E_HIP;
+    }
     int worst = 0;
     for (int q = 0; q < njobs; ++q)
         if (jobs[q].rc < worst) worst = jobs[q].rc;

@@ -30,6 +30,7 @@
 // weighted part of the normal matrix for nearly active cones (fir_qp_cvx, and the retry of any numerical failure).
 // Row-sharded solves: reductions are ncclAllReduce calls on the solver stream (run-time bound RCCL) or a host hook.
 #include "dev_common.h"
+#include <atomic>
 #include "cone_dev.h"
 #include "dd_dev.h"
 #include "program.h"
@@ -1922,55 +1923,54 @@ struct Solver::Impl {
     // The arrays are gathered in a pinned host image of the lanes' program region and go to the device in ONE copy per
     // lane (flush_uploads): ~35 arrays x 8 lanes as separate pageable copies cost ~10 ms per unit with the stream idle.
     char* stage = nullptr;       // pinned
+    // Program arrays go to the device in ONE pinned copy per lane: upload() writes every array straight into the lane's image
+    // of the arena region [stage_lo, stage_hi) -- whose extent the measuring pass of the layout has recorded (meas_lo, meas_hi)
+    // -- and flush_uploads() sends the images.  (Round 2 staged [array][lane] and re-packed to [lane][array]: three passes over
+    // 32 MB of host memory per unit of 16 headline designs, 6-9 ms with the GPU idle at the start of every batch.)
     size_t stage_cap = 0, stage_lo = 0, stage_hi = 0;      // byte range of the arena (lane 0) the staged arrays cover
+    size_t meas_lo = 0, meas_hi = 0;                       // the same range as the measuring pass saw it
     template <class T, class F>
     T* upload(F get) {
         const size_t n0 = get(0).size();
         T* p = ar.get<T>(std::max<size_t>(n0, 1));
-        if (!ar.measuring) {
-            const size_t off = size_t(reinterpret_cast<char*>(p) - ar.base), bytes = n0 * sizeof(T);
-            if (stage_hi == stage_lo) stage_lo = stage_hi = off;
-            if (off < stage_hi) throw HipError("upload: arrays out of order");
-            const size_t need = (off + bytes - stage_lo) * nlanes;
-            if (need > stage_cap) {                           // grow, keeping what is staged
-                char* nb = nullptr;
-                const size_t ncap = std::max(need * 2, size_t(1) << 22);
-                MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&nb), ncap));
-                if (stage) { std::memcpy(nb, stage, stage_cap); hipHostFree(stage); }
-                stage = nb; stage_cap = ncap;
-            }
-            stage_hi = off + bytes;
-            for (int b = 0; b < nlanes; ++b) {
-                const std::vector<T>& v = get(b);
-                if (v.size() != n0) throw HipError("lock-step batch: lanes differ in shape");
-                if (n0) std::memcpy(stage + (off - stage_lo) * nlanes + bytes * b, v.data(), bytes);
-            }
-            pend.push_back({off, bytes});
+        const size_t off = size_t(reinterpret_cast<char*>(p) - ar.base), bytes = n0 * sizeof(T);
+        if (ar.measuring) {
+            if (meas_hi == meas_lo) meas_lo = meas_hi = off;
+            meas_hi = std::max(meas_hi, off + std::max<size_t>(bytes, sizeof(T)));
+            return p;
         }
+        const size_t region = meas_hi - meas_lo;
+        if (stage_hi == stage_lo) {                           // first array of this layout pass
+            stage_lo = stage_hi = off;
+            if (off != meas_lo) throw HipError("upload: the layout differs from its measuring pass");
+            const size_t need = region * nlanes;
+            if (need > stage_cap) {
+                if (stage) hipHostFree(stage);
+                stage_cap = std::max(need * 2, size_t(1) << 22);
+                MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage), stage_cap));
+            }
+        }
+        if (off < stage_hi || off + bytes > meas_hi) throw HipError("upload: arrays out of order");
+        for (int b = 0; b < nlanes; ++b) {
+            const std::vector<T>& v = get(b);
+            if (v.size() != n0) throw HipError("lock-step batch: lanes differ in shape");
+            char* img = stage + region * b;
+            if (off > stage_hi) std::memset(img + (stage_hi - stage_lo), 0, off - stage_hi);      // alignment gap before this array
+            if (n0) std::memcpy(img + (off - stage_lo), v.data(), bytes);
+        }
+        stage_hi = off + bytes;
+        pend.push_back({off, bytes});
         return p;
     }
     struct Pend { size_t off, bytes; };
     std::vector<Pend> pend;
     void flush_uploads() {
-        // staged as [array][lane]; the device wants [lane][array]: one copy per (array, lane) would be the old count, so
-        // re-pack per lane in a second pinned stretch and send each lane's region in one piece
         if (pend.empty()) return;
-        const size_t region = stage_hi - stage_lo, packed = region * nlanes;
-        const size_t base2 = (stage_hi - stage_lo) * nlanes;
-        if (base2 + packed > stage_cap) {
-            char* nb = nullptr;
-            const size_t ncap = (base2 + packed) * 2;
-            MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&nb), ncap));
-            std::memcpy(nb, stage, base2); hipHostFree(stage);
-            stage = nb; stage_cap = ncap;
+        const size_t region = meas_hi - meas_lo, filled = stage_hi - stage_lo;
+        for (int b = 0; b < nlanes; ++b) {
+            if (region > filled) std::memset(stage + region * b + filled, 0, region - filled);
+            MBFIR_HIP(hipMemcpyAsync(ar.base + stage_lo + (size_t)b * lane_bytes, stage + region * b, region, hipMemcpyHostToDevice, st));
         }
-        char* out = stage + base2;
-        std::memset(out, 0, packed);
-        for (const Pend& q : pend)
-            for (int b = 0; b < nlanes; ++b)
-                std::memcpy(out + region * b + (q.off - stage_lo), stage + (q.off - stage_lo) * nlanes + q.bytes * b, q.bytes);
-        for (int b = 0; b < nlanes; ++b)
-            MBFIR_HIP(hipMemcpyAsync(ar.base + stage_lo + (size_t)b * lane_bytes, out + region * b, region, hipMemcpyHostToDevice, st));
         pend.clear();
         stage_lo = stage_hi = 0;
     }
@@ -2670,6 +2670,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     };
     // first pass: only add up the sizes of ONE lane; the lanes then sit lane_bytes apart in one arena
     ar.measuring = true; ar.reset();
+    S.meas_lo = S.meas_hi = 0;
     { char* keep = ar.base; ar.base = nullptr; layout(); ar.base = keep; }
     S.lane_bytes = (ar.off + 4095) & ~size_t(4095);
     ar.measuring = false;

@@ -357,6 +357,32 @@ def test_lock_step_unit_with_mixed_verdicts_equals_the_single_solves():
     ctx.close()
 
 
+def test_units_start_before_the_batch_is_assembled_and_survive_a_change_of_shape():
+    """mbfir_solve_batch hands a unit to the contexts as soon as its designs are assembled, guessing that the whole batch
+    has the shape of job 0.  Here the guess fails: after five designs of one shape (units of 2: two full units go out,
+    the third meets the change) come designs of another order and another designer, then the first shape again.  Every
+    job must equal its single-design call.  With a job that does not assemble (obj < 0, fir_ap_cvx.m:171-173) in the
+    middle of the list the batch reports that job, by its index, as the single call would."""
+    f, a, d = c13(64)
+    f2, a2, d2 = c13(48)
+    jobs = [("fir_ap_cvx", (64, f, a, d, 0.1, pk)) for pk in (1e-3, 3e-3, 1e-2, 5e-4, 2e-3)]
+    jobs += [("fir_ap_cvx", (48, f2, a2, d2, 0.1, pk)) for pk in (1e-3, 1e-2, 3e-3)]
+    jobs.append(CASES["lin_cplx32"])
+    jobs.append(("fir_ap_cvx", (64, f, a, d, 0.1, 4e-3)))                                  # the first shape again, after the change
+    ctxs = [mbfir.Context(0), mbfir.Context(0)]
+    res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=mbfir.make_opts(lanes=2))
+    assert len(res) == len(jobs)
+    for q, (job, (h, status, info)) in enumerate(zip(jobs, res)):
+        h1, s1, i1 = getattr(mbfir, job[0])(*job[1], ctx=ctxs[0], info=True)
+        assert s1 == status and i1["iters"] == info["iters"] and info["pcost"] == i1["pcost"] and np.array_equal(h, h1), q
+    assert [res[q][2]["lanes"] for q in (0, 1, 2, 3)] == [2, 2, 2, 2]
+    bad = jobs[:5] + [("fir_ap_cvx", (64, f, a, d, -0.1, 1e-3))] + jobs[5:]
+    with pytest.raises((ValueError, mbfir.MbfirError), match="job 5"):
+        mbfir.solve_batch(bad, ctxs=ctxs, info=True, opts=mbfir.make_opts(lanes=2))
+    for c in ctxs:
+        c.close()
+
+
 @pytest.mark.parametrize("which", ["fir_linprog", "fir_qprog_phs", "fir_qp_cvx"])
 def test_lock_step_units_of_every_designer_equal_the_single_solves(which):
     """Lock-step units for the other three designers (LP rows only; LP rows + the big cone; Q3 cones + the big cone --
