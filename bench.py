@@ -20,6 +20,7 @@ per iteration (strong scaling) -- `--mode shard` makes that the primary metric i
 One JSON line on stdout (rank 0).
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -287,6 +288,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # the interpreter's cyclic collector: with torch imported a full collection walks ~1e6 objects (50-80 ms, seen as
+    # single steps of 320 ms among 250 ms ones); the objects alive now go to the permanent generation, collections of
+    # what the steps allocate stay on
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     infos = [i for _ in range(args.steps) for i in step()]

@@ -325,6 +325,12 @@ static int assemble_job(const mbfir_job& J, int grid_m, TrigProgram& P, std::str
     }
 }
 
+// Assembled programs are a few MB of vectors each; giving them back to the allocator is 0.1-0.2 ms a piece (munmap).  The
+// workers do that for their unit while other units still run; the programs of the LAST unit to finish -- the one every
+// caller waits for -- are parked here and freed by the next batch's coordinator while its units run (or at unload).
+static std::mutex g_parked_mu;
+static std::vector<TrigProgram> g_parked;
+
 int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njobs, const mbfir_opts* opts) {
     if (!ctxs || nctx < 1 || (!jobs && njobs > 0) || njobs < 0) return MBFIR_E_ARG;
     for (int c = 0; c < nctx; ++c)
@@ -347,7 +353,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
     std::condition_variable cv_asm, cv_units;
     std::vector<char> assembled(njobs, 0);
     std::vector<std::vector<int>> units;
-    size_t units_taken = 0;
+    size_t units_taken = 0, units_done = 0;
     bool units_closed = false;
     const bool trace = std::getenv("MBFIR_TRACE_BATCH") != nullptr;
     std::atomic<int> next_asm(0);
@@ -454,9 +460,17 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                     std::memcpy(J.z, x.data(), sizeof(double) * std::min<size_t>(x.size(), size_t(J.z_cap)));
                 }
             };
+            auto release_programs = [&]() {
+                bool last;
+                { std::lock_guard<std::mutex> lk(mu); ++units_done; last = units_closed && units_done == units.size(); }
+                if (!last) { for (int q : U) progs[q] = TrigProgram(); return; }
+                std::lock_guard<std::mutex> lk(g_parked_mu);
+                for (int q : U) g_parked.push_back(std::move(progs[q]));
+            };
             if (U.size() == 1) {
                 jobs[U[0]].rc = one_job(ctx, jobs[U[0]], opts);
                 finish_job(U[0]);
+                release_programs();
                 continue;
             }
             try {
@@ -486,6 +500,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 ctx->err = e.what();
                 for (int q : U) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
             }
+            release_programs();
         }
     };
     std::vector<std::thread> th;
@@ -497,6 +512,10 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
     try { coordinate(); } catch (const std::exception& e) { coord_err = e.what(); }
     { std::lock_guard<std::mutex> lk(mu); units_closed = true; }
     cv_units.notify_all();
+    {
+        std::vector<TrigProgram> old;
+        { std::lock_guard<std::mutex> lk(g_parked_mu); old.swap(g_parked); }
+    }                                                                // (the previous batch's last programs, freed while the units run)
     for (auto& t : th) t.join();
     if (trace) std::fprintf(stderr, "[batch] %zu units, all done at %.2f ms\n", units.size(), now_ms() - t0);
     if (!coord_err.empty()) {

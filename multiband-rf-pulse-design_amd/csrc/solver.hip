@@ -30,7 +30,8 @@
 // weighted part of the normal matrix for nearly active cones (fir_qp_cvx, and the retry of any numerical failure).
 // Row-sharded solves: reductions are ncclAllReduce calls on the solver stream (run-time bound RCCL) or a host hook.
 #include "dev_common.h"
-#include <atomic>
+#include <functional>
+#include <thread>
 #include "cone_dev.h"
 #include "dd_dev.h"
 #include "program.h"
@@ -1939,38 +1940,49 @@ struct Solver::Impl {
             meas_hi = std::max(meas_hi, off + std::max<size_t>(bytes, sizeof(T)));
             return p;
         }
-        const size_t region = meas_hi - meas_lo;
         if (stage_hi == stage_lo) {                           // first array of this layout pass
             stage_lo = stage_hi = off;
             if (off != meas_lo) throw HipError("upload: the layout differs from its measuring pass");
-            const size_t need = region * nlanes;
-            if (need > stage_cap) {
-                if (stage) hipHostFree(stage);
-                stage_cap = std::max(need * 2, size_t(1) << 22);
-                MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage), stage_cap));
-            }
         }
         if (off < stage_hi || off + bytes > meas_hi) throw HipError("upload: arrays out of order");
-        for (int b = 0; b < nlanes; ++b) {
-            const std::vector<T>& v = get(b);
-            if (v.size() != n0) throw HipError("lock-step batch: lanes differ in shape");
-            char* img = stage + region * b;
-            if (off > stage_hi) std::memset(img + (stage_hi - stage_lo), 0, off - stage_hi);      // alignment gap before this array
-            if (n0) std::memcpy(img + (off - stage_lo), v.data(), bytes);
-        }
+        for (int b = 1; b < nlanes; ++b)
+            if (get(b).size() != n0) throw HipError("lock-step batch: lanes differ in shape");
+        pend.push_back({off, bytes, stage_hi, [get](int b) -> const void* { return get(b).data(); }});
         stage_hi = off + bytes;
-        pend.push_back({off, bytes});
         return p;
     }
-    struct Pend { size_t off, bytes; };
+    struct Pend { size_t off, bytes, prev_end; std::function<const void*(int)> src; };
     std::vector<Pend> pend;
     void flush_uploads() {
         if (pend.empty()) return;
-        const size_t region = meas_hi - meas_lo, filled = stage_hi - stage_lo;
-        for (int b = 0; b < nlanes; ++b) {
-            if (region > filled) std::memset(stage + region * b + filled, 0, region - filled);
-            MBFIR_HIP(hipMemcpyAsync(ar.base + stage_lo + (size_t)b * lane_bytes, stage + region * b, region, hipMemcpyHostToDevice, st));
+        const size_t region = meas_hi - meas_lo, need = region * nlanes;
+        if (need > stage_cap) {
+            if (stage) hipHostFree(stage);
+            stage_cap = std::max(need * 2, size_t(1) << 22);
+            MBFIR_HIP(hipHostMalloc(reinterpret_cast<void**>(&stage), stage_cap));
         }
+        // lane images filled and sent by a few threads: 32 MB for a unit of 16 headline designs, 2.5 ms on one core with
+        // the stream idle -- at the start of a batch that is time the slowest unit does not get back
+        const int nth = need >= (size_t(4) << 20) ? std::min(nlanes, 4) : 1;
+        std::vector<hipError_t> rc(nth, hipSuccess);
+        auto fill = [&](int t) {
+            if (t > 0) rc[t] = hipSetDevice(device);
+            for (int b = t; b < nlanes && rc[t] == hipSuccess; b += nth) {
+                char* img = stage + region * b;
+                for (const Pend& q : pend) {
+                    if (q.off > q.prev_end) std::memset(img + (q.prev_end - stage_lo), 0, q.off - q.prev_end);      // alignment gap before the array
+                    if (q.bytes) std::memcpy(img + (q.off - stage_lo), q.src(b), q.bytes);
+                }
+                const size_t filled = stage_hi - stage_lo;
+                if (region > filled) std::memset(img + filled, 0, region - filled);
+                rc[t] = hipMemcpyAsync(ar.base + stage_lo + (size_t)b * lane_bytes, img, region, hipMemcpyHostToDevice, st);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; ++t) th.emplace_back(fill, t);
+        fill(0);
+        for (auto& t : th) t.join();
+        for (hipError_t e : rc) MBFIR_HIP(e);
         pend.clear();
         stage_lo = stage_hi = 0;
     }
