@@ -243,16 +243,57 @@ void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount
     hipLaunchKernelGGL(k_dd_syrk, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, U, ldu, X, kcount, np, Hh, Hl);
 }
 
+// Inverses of the 64 x 64 diagonal blocks of L in double-double (one workgroup per block; (Xh, Xl): np/64 blocks of 64 x 64,
+// row-major, the strict upper triangles zero).  The triangular solves multiply by them instead of substituting: a
+// substitution is 64 dependent steps per block ON the chain of the solve, a product is one (k_dd_trsv_bi).  With the
+// conditioning of a diagonal block of L (<= sqrt(cond H) ~ 1e10) and a unit round-off of 1e-32 the product is as good
+// as the substitution to ~1e-22.  Column j of the inverse is a forward substitution of e_j: four adjacent lanes share a
+// column (the sum over k split by k mod 4, folded with two DPP-free shuffles), a thread only ever reads back the
+// entries it stored itself (k mod 4 == its part), so the 64 steps need no barrier.
+constexpr int DIB = 64;
+constexpr size_t BLOCKINV_LDS = 4 * DIB * DIB * sizeof(double);
+__global__ __launch_bounds__(256) void k_dd_blockinv(const double* __restrict__ Lh, const double* __restrict__ Ll,
+                                                     const double* __restrict__ rih, const double* __restrict__ ril, int np,
+                                                     double* __restrict__ Xh, double* __restrict__ Xl) {
+    extern __shared__ double smem[];                                // 4 x 64 x 64 doubles (BLOCKINV_LDS)
+    double (*lh)[DIB] = reinterpret_cast<double (*)[DIB]>(smem);                       // the block of L
+    double (*ll)[DIB] = reinterpret_cast<double (*)[DIB]>(smem + DIB * DIB);
+    double (*xh)[DIB] = reinterpret_cast<double (*)[DIB]>(smem + 2 * DIB * DIB);       // xh[k][j] = (L_bb^-1)_kj, written by the thread (j, k mod 4)
+    double (*xl)[DIB] = reinterpret_cast<double (*)[DIB]>(smem + 3 * DIB * DIB);
+    const int b0 = blockIdx.x * DIB, tid = threadIdx.x;
+    for (int e = tid; e < DIB * DIB; e += 256) {
+        const int r = e / DIB, c = e - r * DIB;
+        lh[r][c] = c <= r ? Lh[(long)(b0 + r) * np + b0 + c] : 0.0;
+        ll[r][c] = c <= r ? Ll[(long)(b0 + r) * np + b0 + c] : 0.0;
+    }
+    __syncthreads();
+    const int j = tid >> 2, part = tid & 3;
+    double* oh = Xh + (size_t)blockIdx.x * DIB * DIB;
+    double* ol = Xl + (size_t)blockIdx.x * DIB * DIB;
+    for (int i = 0; i < DIB; ++i) {
+        dd x = dd_make(0.0, 0.0);
+        if (i == j) x = dd_make(rih[b0 + i], ril[b0 + i]);
+        else if (i > j) {
+            dd acc = dd_make(0.0, 0.0);
+            for (int k = j + ((part - j) & 3); k < i; k += 4) acc = dd_fnma(acc, dd_make(lh[i][k], ll[i][k]), dd_make(xh[k][j], xl[k][j]));
+            acc = dd_add(acc, dd_make(__shfl_xor(acc.h, 1, 64), __shfl_xor(acc.l, 1, 64)));
+            acc = dd_add(acc, dd_make(__shfl_xor(acc.h, 2, 64), __shfl_xor(acc.l, 2, 64)));
+            x = dd_mul(acc, dd_make(rih[b0 + i], ril[b0 + i]));
+        }
+        if ((i & 3) == part) {
+            xh[i][j] = x.h; xl[i][j] = x.l;                         // (read back by this thread only)
+            oh[i * DIB + j] = x.h; ol[i * DIB + j] = x.l;
+        }
+    }
+}
+
 // In-place lower Cholesky of the dd matrix (Hh, Hl) (np x np row-major, np a multiple of 64); on exit the lower
 // triangle holds L, (Lth, Ltl) hold L' (upper triangle, row-major), (rih, ril) the reciprocals of diag(L);
 // flag[0] counts replaced pivots; d0 is a work vector of np doubles.
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
-                    double pivtol, int* flag, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update), hipFuncAttributeMaxDynamicSharedMemorySize, int(UPD_LDS));
-        attr_set = true;
-    }
+                    double pivtol, int* flag, hipStream_t st, double* dinv) {
+    static std::once_flag attr_set;                       // (mbfir_solve_batch runs its contexts on parallel host threads)
+    std::call_once(attr_set, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update), hipFuncAttributeMaxDynamicSharedMemorySize, int(UPD_LDS)); });
     hipMemsetAsync(flag, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_dd_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, Hh, np, d0);
     for (int k0 = 0; k0 < np; k0 += DNB) {
@@ -262,6 +303,11 @@ void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* ri
         hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 32)), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
         const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
         hipLaunchKernelGGL(k_ddchol_update, dim3(nt * (nt + 1) / 2), dim3(256), UPD_LDS, st, Hh, Hl, np, k0);
+    }
+    if (dinv) {
+        static std::once_flag inv_set;
+        std::call_once(inv_set, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_blockinv), hipFuncAttributeMaxDynamicSharedMemorySize, int(BLOCKINV_LDS)); });
+        hipLaunchKernelGGL(k_dd_blockinv, dim3(np / DIB), dim3(256), BLOCKINV_LDS, st, Hh, Hl, rih, ril, np, dinv, dinv + (size_t)np * DIB);
     }
 }
 
@@ -433,11 +479,104 @@ __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ L
     if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same solve on 64-row blocks with the inverses of the diagonal blocks (k_dd_blockinv): 2 np / 64 workgroups of 512
+// threads (thread = row x eighth of a block's columns).  On the chain of block b there is, after the last block it waits
+// for has been published: 8 multiply-adds per thread and right-hand side, a fold over the 8 threads of a row, the same
+// again with the inverse block (held in registers since before the wait), the stores.  34 chain steps instead of 68 at
+// np = 1088, none with a substitution in it.  Tickets, flags, hand-offs: as in k_dd_trsv_mw.
+template <int NV>
+__global__ __launch_bounds__(512) void k_dd_trsv_bi(const double* __restrict__ Lh, const double* __restrict__ Ll,
+                                                    const double* __restrict__ Lth, const double* __restrict__ Ltl,
+                                                    const double* __restrict__ Xh, const double* __restrict__ Xl, int np,
+                                                    double* Bh, double* Bl, int ldv, int* flags, int ticket_at, int epoch, int* lost) {
+    __shared__ double ysh[2][NV][DIB];
+    __shared__ int ticket;
+    const int nb = np / DIB;
+    if (threadIdx.x == 0) ticket = atomicAdd(flags + ticket_at, 1) - (epoch - 1) * int(gridDim.x);
+    __syncthreads();
+    const int g = ticket, pass = g >= nb ? 1 : 0, bb = pass ? g - nb : g;
+    if (g < 0 || g >= 2 * nb) { if (threadIdx.x == 0) atomicAdd(lost, DD_SYNC_LOST); return; }     // (a ticket word somebody else touched)
+    const int blk = pass == 0 ? bb : nb - 1 - bb, b0 = blk * DIB;
+    const double* Th = pass == 0 ? Lh : Lth;
+    const double* Tl = pass == 0 ? Ll : Ltl;
+    const int tid = threadIdx.x, r = tid >> 3, q8 = tid & 7;
+    // this thread's eight entries of the inverse block (forward: row r of it, backward: row r of its transpose)
+    dd xi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = q8 * 8 + j;
+        const size_t o = (size_t)blk * DIB * DIB + (pass == 0 ? (size_t)r * DIB + c : (size_t)c * DIB + r);
+        xi[j] = dd_make(Xh[o], Xl[o]);
+    }
+    if (pass == 1) {                                           // the rows' own right-hand side: the forward result of the same rows
+        if (tid == 0) wait_flag(flags + blk, epoch, lost);
+        __syncthreads();
+    }
+    dd acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        acc[v] = q8 == 0 ? dd_make(ld_dev(Bh + (long)v * ldv + b0 + r), ld_dev(Bl + (long)v * ldv + b0 + r)) : dd_make(0.0, 0.0);
+    const double* th = Th + (long)(b0 + r) * np + q8 * 8;
+    const double* tl = Tl + (long)(b0 + r) * np + q8 * 8;
+    for (int c = 0; c < bb; ++c) {
+        const int b0c = (pass == 0 ? c : nb - 1 - c) * DIB;
+        dd lv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lv[j] = dd_make(th[b0c + j], tl[b0c + j]);           // (the factor: read-only, in flight across the wait)
+        if (tid == 0) wait_flag(flags + pass * nb + c, epoch, lost);
+        __syncthreads();
+        if (tid < DIB * NV) {
+            const int v = tid / DIB, i = tid - v * DIB;
+            ysh[0][v][i] = ld_dev(Bh + (long)v * ldv + b0c + i);
+            ysh[1][v][i] = ld_dev(Bl + (long)v * ldv + b0c + i);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = dd_fnma(acc[v], lv[j], dd_make(ysh[0][v][q8 * 8 + j], ysh[1][v][q8 * 8 + j]));
+    }
+    __syncthreads();                                            // (ysh is reused below)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) acc[v] = dd_add(acc[v], dd_make(__shfl_xor(acc[v].h, o, 64), __shfl_xor(acc[v].l, o, 64)));
+        if (q8 == 0) { ysh[0][v][r] = acc[v].h; ysh[1][v][r] = acc[v].l; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        dd y = dd_make(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y = dd_add(y, dd_mul(xi[j], dd_make(ysh[0][v][q8 * 8 + j], ysh[1][v][q8 * 8 + j])));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) y = dd_add(y, dd_make(__shfl_xor(y.h, o, 64), __shfl_xor(y.l, o, 64)));
+        if (q8 == 0) {
+            st_dev(Bh + (long)v * ldv + b0 + r, y.h);
+            st_dev(Bl + (long)v * ldv + b0 + r, y.l);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave: its sc1 stores have left the CU ...
+    __syncthreads();                                              // ... before the one lane that signals for all of them does
+    if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// dinv: the inverses of the 64 x 64 diagonal blocks (dd_chol_launch; 2 np x 64 doubles) -> k_dd_trsv_bi; nullptr: substitution
+// on 32-row blocks (k_dd_trsv_mw).
 // flags: 2 np / 32 + 1 ints owned by the caller (zeroed once; the last one is the ticket counter), epoch: 1, 2, 3, ...
 // over the calls that use these flags (every call with the same np); lost: the counter a lost hand-off is reported in
 // (DD_SYNC_LOST, next to the replaced pivots); flags == nullptr: the single-workgroup kernel
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
-                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags, int epoch, int* lost) {
+                    const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags, int epoch, int* lost,
+                    const double* dinv) {
+    if (dinv && flags && lost && (nv == 1 || nv == 2) && np % DIB == 0) {
+        // (one solve uses one form throughout: the ticket word counts the launches of ONE grid size)
+        const dim3 grid(2 * np / DIB);
+        const double* xl = dinv + (size_t)np * DIB;
+        if (nv == 1) hipLaunchKernelGGL(k_dd_trsv_bi<1>, grid, dim3(512), 0, st, Lh, Ll, Lth, Ltl, dinv, xl, np, Bh, Bl, ldv, flags, 2 * np / DNB, epoch, lost);
+        else hipLaunchKernelGGL(k_dd_trsv_bi<2>, grid, dim3(512), 0, st, Lh, Ll, Lth, Ltl, dinv, xl, np, Bh, Bl, ldv, flags, 2 * np / DNB, epoch, lost);
+        return;
+    }
     if (flags && lost && (nv == 1 || nv == 2) && np % DNB == 0) {
         const dim3 grid(2 * np / DNB);
         if (nv == 1) hipLaunchKernelGGL(k_dd_trsv_mw<1>, grid, dim3(256), 0, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv, flags, epoch, lost);

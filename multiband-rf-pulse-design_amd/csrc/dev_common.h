@@ -115,10 +115,10 @@ void hsolve_launch(const double* M, int np, const double* b, const double* b2, d
 void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount, int np, double* Hh, double* Hl,
                     hipStream_t st);
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
-                    double pivtol, int* flag, hipStream_t st);
+                    double pivtol, int* flag, hipStream_t st, double* dinv = nullptr);     // dinv: 2 np x 64 doubles, the inverses of the 64 x 64 diagonal blocks of L
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
                     const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags = nullptr, int epoch = 0,
-                    int* lost = nullptr);
+                    int* lost = nullptr, const double* dinv = nullptr);
 // In-launch hand-offs between workgroups (chol.hip, ddlin.hip) poll with a bound; a poll that expires adds this to the
 // pivot-replacement counter of the factorisation it belongs to, and the host turns a counter at or above it into an error.
 constexpr int CHOL_SYNC_LOST = 1 << 20;

@@ -1907,7 +1907,8 @@ struct Solver::Impl {
     // The dd factor reuses the buffers of the double-precision inverse: Hl = M, L' = (Mt, W1).
     DDev D{};
     double *ddB = nullptr, *ddtS = nullptr, *ddzeta = nullptr, *ddri = nullptr, *ddd0 = nullptr;
-    int* ddflags = nullptr;      // block flags of k_dd_trsv_mw; dd_epoch: the value the current call waits for
+    double* ddinv = nullptr;     // inverses of the 64 x 64 diagonal blocks of the dd factor (k_dd_blockinv); nullptr (MBFIR_DD_BLOCKINV=0): substitution
+    int* ddflags = nullptr;      // block flags of k_dd_trsv_mw / k_dd_trsv_bi; dd_epoch: the value the current call waits for
     int dd_epoch = 0;
     int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
     int dd_iters = 0, dd_kmax_seen = 0;
@@ -2188,8 +2189,8 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
             apply_GT<NV>(wbz, tmpN2);
-            hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 256)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
-            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch, flag);
+            hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 16)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
+            dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch, flag, ddinv);
             apply_G<NV>(Bh, wpR);
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wpR, tmpR, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
@@ -2291,7 +2292,7 @@ struct Solver::Impl {
             if (c0) hipEventRecord(c0, st);
             hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
             dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
-            dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st);
+            dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st, ddinv);
             if (c1) hipEventRecord(c1, st);
         } else if (mine) {
             // (with the one-pass M'(M b) nobody reads the transpose: it is not written)
@@ -2664,6 +2665,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.partial = ar.get<double>(std::max(P.trig ? (size_t)cdiv(P.nchunk, P.cgrp) * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld,
                                         hsolve_part_doubles(int(np))));         // (also the partial vectors of the one-pass M'(M b))
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
+    S.ddinv = nullptr;
     if (use_dd) {
         DDev& D = S.D;
         D.e3 = ar.get<double>(8 * (size_t)std::max(P.nq3, 1)); D.eb = ar.get<double>(8); D.whb = ar.get<double>(std::max(P.big, 1));
@@ -2674,6 +2676,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         S.ddB = ar.get<double>(4 * LDV); S.ddtS = ar.get<double>(2 * (size_t)DD_KMAX); S.ddzeta = ar.get<double>(2 * (size_t)DD_KMAX);
         S.ddri = ar.get<double>(2 * np); S.ddd0 = ar.get<double>(np);
         S.ddflags = ar.get<int>(2 * np / 32 + 8);          // block flags of the multi-workgroup dd solve (zeroed with the arena)
+        S.ddinv = ar.get<double>(2 * np * 64);
+        if (const char* ev = std::getenv("MBFIR_DD_BLOCKINV")) { if (std::atoi(ev) == 0) S.ddinv = nullptr; }
     }
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
@@ -3123,12 +3127,15 @@ void Solver::test_ddsolve(int n, int k, const double* Hh, const double* U, const
     MBFIR_HIP(hipMemcpyAsync(dBl.p, Bl.data(), 2 * ldv * 8, hipMemcpyHostToDevice, S.st));
     MBFIR_HIP(hipMemcpyAsync(df.as<int>() + 1, &k, sizeof(int), hipMemcpyHostToDevice, S.st));
     dd_syrk_launch(dU.as<double>(), int(np), dX.as<double>(), df.as<int>() + 1, int(np), dH.as<double>(), dHl.as<double>(), S.st);
+    DevBuf dinv(2 * np * 64 * 8);
+    double* dinvp = dinv.as<double>();
+    if (const char* ev = std::getenv("MBFIR_DD_BLOCKINV")) { if (std::atoi(ev) == 0) dinvp = nullptr; }
     dd_chol_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
-                   dd0.as<double>(), int(np), 1e-28, df.as<int>(), S.st);
+                   dd0.as<double>(), int(np), 1e-28, df.as<int>(), S.st, dinvp);
     DevBuf dflags(sizeof(int) * (2 * np / 32 + 8));
     MBFIR_HIP(hipMemsetAsync(dflags.p, 0, sizeof(int) * (2 * np / 32 + 8), S.st));
     dd_trsv_launch(dH.as<double>(), dHl.as<double>(), dLt.as<double>(), dLtl.as<double>(), dri.as<double>(), dri.as<double>() + np,
-                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st, dflags.as<int>(), 1, df.as<int>());
+                   int(np), dB.as<double>(), dBl.as<double>(), nrhs, int(ldv), S.st, dflags.as<int>(), 1, df.as<int>(), dinvp);
     MBFIR_HIP(hipMemcpyAsync(B.data(), dB.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(Bl.data(), dBl.p, 2 * ldv * 8, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipMemcpyAsync(nfix, df.p, sizeof(int), hipMemcpyDeviceToHost, S.st));

@@ -152,6 +152,29 @@ def test_fp64_peak_microbenchmark_runs():
     assert 5.0 < mf < 200.0 and 5.0 < va < 200.0
 
 
+def test_double_double_solve_by_block_inverses_agrees_with_the_substitution(monkeypatch):
+    """The triangular solves of the extended-precision path multiply by the inverses of the 64 x 64 diagonal blocks of the
+    dd factor (k_dd_blockinv, k_dd_trsv_bi: 34 chain steps at np = 1088, none with a substitution in it);
+    MBFIR_DD_BLOCKINV=0 is the substitution on 32-row blocks (k_dd_trsv_mw).  Same factor, and solutions that agree far
+    below anything the refinement around them could see -- here with strong weights up to 1e14 on top of H_w."""
+    rng = np.random.default_rng(21)
+    n, k = 700, 120
+    B = rng.standard_normal((n + 30, n))
+    Hw = B.T @ B
+    Hw = 0.5 * (Hw + Hw.T)
+    U = rng.standard_normal((k, n))
+    X = 10.0 ** rng.uniform(8, 14, k)
+    b = rng.standard_normal((2, n))
+    bl = np.zeros((2, n))
+    xh1, xl1, nf1 = mbfir.test_ddsolve(Hw, U, X, b, bl)
+    monkeypatch.setenv("MBFIR_DD_BLOCKINV", "0")
+    xh0, xl0, nf0 = mbfir.test_ddsolve(Hw, U, X, b, bl)
+    assert nf0 == nf1 == 0
+    d = np.abs((xh1 - xh0) + (xl1 - xl0)).max()
+    assert d <= 1e-22 * np.abs(xh0).max() * X.max()
+    assert not np.array_equal(xl1, xl0) or np.array_equal(xh1, xh0)          # (two different orders of summation: the low words differ)
+
+
 def test_double_double_solve_with_one_right_hand_side_equals_the_first_of_two():
     """k_dd_trsv_mw<1> against k_dd_trsv_mw<2>: the blocks' sums run in the same order per right-hand side, so the
     single solve reproduces column 0 of the double solve bit for bit."""

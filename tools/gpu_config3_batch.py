@@ -18,3 +18,6 @@ for _ in range(2):
     dt = time.time() - t
     print("config 3 as written, n %d m %d: %d designs, %d streams: %.3f s = %.2f designs/s; status %s iters %s dd_iters %s" % (
         n, m, count, streams, dt, count / dt, sorted(set(r[1] for r in res)), [r[2]["iters"] for r in res], [r[2]["dd_iters"] for r in res]), flush=True)
+t = time.time()
+h, st, inf = mbfir.fir_qp_cvx(*jobs[0][1], opts=o, info=True)
+print("config 3 as written, one design alone: %.3f s, %s, %d iterations (%d extended-precision)" % (time.time() - t, st, inf["iters"], inf["dd_iters"]), flush=True)
