@@ -8,6 +8,7 @@
 // sum factorised, in dd they survive.  Everything here is fp64 VALU work with error-free transformations:
 // there is no matrix-core path for dd.
 #include "dev_common.h"
+#include <cstdlib>
 #include <mutex>
 #include "dd_dev.h"
 #include "solver.h"
@@ -21,50 +22,55 @@ constexpr int DT = 64;           // output tile of the dd rank-k kernels
 
 // ------------------------------------------------------------------------------------------------
 // H(dd, lower-triangle tiles) = Hh (as given, double) + sum_{r < *kcount} X[r] U[r][i] U[r][j]
+// Tiles of 16 PT x 16 PT, a PT x PT patch per thread.  PT = 4 (64 x 64) gives 153 workgroups at np = 1088 -- fewer than the
+// chip has CUs, each walking all k <= 588 rows with one wave per SIMD: 0.7 ms; PT = 2 (32 x 32) gives 561 of a quarter
+// the length.  An entry's sum runs over r in the same order either way: the results are the same bit for bit.
+template <int PT>
 __global__ __launch_bounds__(256) void k_dd_syrk(const double* __restrict__ U, int ldu, const double* __restrict__ X,
                                                  const int* __restrict__ kcount, int np, double* __restrict__ Hh,
                                                  double* __restrict__ Hl) {
-    __shared__ double ui[8][DT], uj[8][DT], xs[8];
+    constexpr int TS = 16 * PT;
+    __shared__ double ui[8][TS], uj[8][TS], xs[8];
     // linear block index -> (bi >= bj)
     int bi = int((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
     while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
     while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
     const int bj = blockIdx.x - bi * (bi + 1) / 2;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i0 = bi * DT + ty * 4, j0 = bj * DT + tx * 4;
-    dd acc[4][4];
+    const int i0 = bi * TS + ty * PT, j0 = bj * TS + tx * PT;
+    dd acc[PT][PT];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], 0.0);
+        for (int s = 0; s < PT; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], 0.0);
     const int k = *kcount;
     for (int r0 = 0; r0 < k; r0 += 8) {
         __syncthreads();
-        for (int e = threadIdx.x; e < 8 * DT; e += 256) {
-            const int q = e / DT, c = e - q * DT, r = r0 + q;
-            ui[q][c] = r < k ? U[(long)r * ldu + bi * DT + c] : 0.0;
-            uj[q][c] = r < k ? U[(long)r * ldu + bj * DT + c] : 0.0;
+        for (int e = threadIdx.x; e < 8 * TS; e += 256) {
+            const int q = e / TS, c = e - q * TS, r = r0 + q;
+            ui[q][c] = r < k ? U[(long)r * ldu + bi * TS + c] : 0.0;
+            uj[q][c] = r < k ? U[(long)r * ldu + bj * TS + c] : 0.0;
         }
         if (threadIdx.x < 8) xs[threadIdx.x] = r0 + threadIdx.x < k ? X[r0 + threadIdx.x] : 0.0;
         __syncthreads();
 #pragma unroll 2
         for (int q = 0; q < 8; ++q) {
             const double x = xs[q];
-            dd ax[4];
+            dd ax[PT];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) ax[p] = two_prod(ui[q][ty * 4 + p], x);
+            for (int p = 0; p < PT; ++p) ax[p] = two_prod(ui[q][ty * PT + p], x);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double b = uj[q][tx * 4 + s];
+            for (int s = 0; s < PT; ++s) {
+                const double b = uj[q][tx * PT + s];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[p][s] = dd_add(acc[p][s], dd_mul_d(ax[p], b));
+                for (int p = 0; p < PT; ++p) acc[p][s] = dd_add(acc[p][s], dd_mul_d(ax[p], b));
             }
         }
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < PT; ++s) {
             Hh[(long)(i0 + p) * np + j0 + s] = acc[p][s].h;
             Hl[(long)(i0 + p) * np + j0 + s] = acc[p][s].l;
         }
@@ -78,57 +84,64 @@ __global__ void k_dd_diag_copy(const double* __restrict__ Hh, int np, double* __
 // ------------------------------------------------------------------------------------------------
 // Cholesky, panel step k0: (1) factorise the 32 x 32 diagonal block in one workgroup
 // pivot rule of oracle/ddlin.c dd_chol: a pivot not above pivtol * d0 is replaced by d0 (counted in flag[0])
-__global__ __launch_bounds__(256) void k_ddchol_diag(double* __restrict__ Hh, double* __restrict__ Hl,
+__global__ __launch_bounds__(1024) void k_ddchol_diag(double* __restrict__ Hh, double* __restrict__ Hl,
                                                      double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
                                                      const double* __restrict__ d0, double pivtol, int* __restrict__ flag,
                                                      double* __restrict__ rih, double* __restrict__ ril) {
+    // ONE barrier per pivot: D keeps the running Schur complement UNSCALED (column j is not touched again after pivot j),
+    // every thread forms 1 / sqrt(pivot) itself and scales the two column entries its updates need on the fly -- the same
+    // products from the same operands in every thread, so the factor is what the three-barrier form (scale the column in
+    // place, barrier, update) produced, bit for bit -- and the scaled entries go to a second array nobody reads in the loop.
     __shared__ double Dh[DNB][DNB + 1], Dl[DNB][DNB + 1];
-    __shared__ double rh[DNB], rl[DNB];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < DNB * DNB; e += 256) {
-        const int i = e / DNB, c = e - i * DNB;
+    __shared__ double Fh[DNB][DNB + 1], Fl[DNB][DNB + 1];
+    __shared__ double rh[DNB], rl[DNB], d0s[DNB];
+    // one thread per entry (1024 = 32 x 32; the strict upper triangle idles): with four entries per thread their four
+    // chains of dd operations ran one after the other -- the stores to D could alias the next entry's loads -- 1.1 us a pivot
+    const int tid = threadIdx.x, i = tid / DNB, c = tid - i * DNB;
+    {
         const bool lo = c <= i;
         Dh[i][c] = lo ? Hh[(long)(k0 + i) * np + k0 + c] : 0.0;
         Dl[i][c] = lo ? Hl[(long)(k0 + i) * np + k0 + c] : 0.0;
     }
+    if (tid < DNB) d0s[tid] = d0[k0 + tid];
     for (int j = 0; j < DNB; ++j) {
-        __syncthreads();
-        // every thread forms 1 / sqrt(pivot) itself (no broadcast, one barrier less): x = 1 / sqrt(p.h) to double
-        // accuracy, then one Newton step in dd,  ri = x + x (1 - p x^2) / 2  (error 3/8 e^2, e ~ 1e-16), and r = p ri
+        __syncthreads();                                      // the updates of pivot j - 1 are in place
+        // x = 1 / sqrt(p.h) to double accuracy (the hardware's reciprocal square root, ~1e-9, and two Newton steps), then
+        // one Newton step towards dd,  ri = x + x (1 - p x^2) / 2  (error 3/8 e^2, e ~ 1e-16), and r = p ri.  The residual
+        // 1 - p x^2 is ~1e-16 and only its leading digits count: x^2 exactly as a two-term product, then three fused
+        // multiply-adds (the first, 1 - p.h t.h, is exact up to one rounding of a number that small) -- 9 dependent
+        // operations where the generic dd routines (and a correctly rounded 1 / sqrt) took 60: 15 of the block's 37 us
+        // (tools/exp/ddiag_exp.hip; the factor moves by 1e-31).
         dd p = dd_make(Dh[j][j], Dl[j][j]);
-        const double dj = d0[k0 + j];
+        const double dj = d0s[j];
         const bool bad = !(p.h > pivtol * dj);
         if (bad) p = dd_make(dj > 1e-300 ? dj : 1e-300, 0.0);
-        double x = 1.0 / sqrt(p.h);
+        double x = __builtin_amdgcn_rsq(p.h);
         x = x * (1.5 - 0.5 * p.h * x * x);
-        const dd e1 = dd_sub(dd_make(1.0), dd_mul_d(dd_mul_d(p, x), x));
-        const dd ri = dd_add_d(dd_mul_d(e1, 0.5 * x), x);
-        __syncthreads();                                      // everybody has read the pivot
-        if (tid == 0) {
+        x = x * (1.5 - 0.5 * p.h * x * x);
+        const dd t2 = two_prod(x, x);
+        double e1 = __builtin_fma(-p.h, t2.h, 1.0);
+        e1 = __builtin_fma(-p.h, t2.l, e1);
+        e1 = __builtin_fma(-p.l, t2.h, e1);
+        const dd ri = quick_two_sum(x, 0.5 * x * e1);
+        if (i == j && c == j) {
             const dd r = dd_mul(p, ri);
-            Dh[j][j] = r.h; Dl[j][j] = r.l;
+            Fh[j][j] = r.h; Fl[j][j] = r.l;
             rh[j] = ri.h; rl[j] = ri.l;
             if (bad) atomicAdd(flag, 1);
-        } else if (tid > j && tid < DNB) {
-            const dd v = dd_mul(dd_make(Dh[tid][j], Dl[tid][j]), ri);
-            Dh[tid][j] = v.h; Dl[tid][j] = v.l;
-        }
-        __syncthreads();
-        for (int e = tid; e < DNB * DNB; e += 256) {
-            const int i = e / DNB, c = e - i * DNB;
-            if (c > j && i >= c) {
-                const dd v = dd_fnma(dd_make(Dh[i][c], Dl[i][c]), dd_make(Dh[i][j], Dl[i][j]), dd_make(Dh[c][j], Dl[c][j]));
-                Dh[i][c] = v.h; Dl[i][c] = v.l;
-            }
+        } else if (c == j && i > j) {
+            const dd v = dd_mul(dd_make(Dh[i][j], Dl[i][j]), ri);
+            Fh[i][j] = v.h; Fl[i][j] = v.l;
+        } else if (c > j && i >= c) {
+            const dd li = dd_mul(dd_make(Dh[i][j], Dl[i][j]), ri), lc = dd_mul(dd_make(Dh[c][j], Dl[c][j]), ri);
+            const dd v = dd_fnma(dd_make(Dh[i][c], Dl[i][c]), li, lc);
+            Dh[i][c] = v.h; Dl[i][c] = v.l;
         }
     }
     __syncthreads();
-    for (int e = tid; e < DNB * DNB; e += 256) {
-        const int i = e / DNB, c = e - i * DNB;
-        if (c <= i) {
-            Hh[(long)(k0 + i) * np + k0 + c] = Dh[i][c]; Hl[(long)(k0 + i) * np + k0 + c] = Dl[i][c];
-            Lth[(long)(k0 + c) * np + k0 + i] = Dh[i][c]; Ltl[(long)(k0 + c) * np + k0 + i] = Dl[i][c];
-        }
+    if (c <= i) {
+        Hh[(long)(k0 + i) * np + k0 + c] = Fh[i][c]; Hl[(long)(k0 + i) * np + k0 + c] = Fl[i][c];
+        Lth[(long)(k0 + c) * np + k0 + i] = Fh[i][c]; Ltl[(long)(k0 + c) * np + k0 + i] = Fl[i][c];
     }
     if (tid < DNB) { rih[k0 + tid] = rh[tid]; ril[k0 + tid] = rl[tid]; }
 }
@@ -183,64 +196,81 @@ __global__ __launch_bounds__(256) void k_ddchol_trsm(double* __restrict__ Hh, do
     }
 }
 
-// (3) trailing update A[i][j] -= sum_c L[i][k0+c] L[j][k0+c] for i >= j >= k0 + 32, lower-triangle 64 x 64 tiles
-// on the global 64-grid (entries of a tile above k1 = k0 + 32 are skipped)
-constexpr int UPD_LD = DT + 1;                                // panel staged as [column][row], conflict-free both ways
-constexpr size_t UPD_LDS = 4 * (size_t)DNB * UPD_LD * sizeof(double);
+// (3) trailing update A[i][j] -= sum_c L[i][k0+c] L[j][k0+c] for i >= j >= k0 + 32, lower-triangle tiles of 16 PT x 16 PT
+// on the global grid of that size (entries of a tile above k1 = k0 + 32 are skipped), a PT x PT patch per thread.
+// With 64 x 64 tiles (PT = 4) the trailing matrix of np = 1088 is 153 tiles at the first step and 51 on average -- a
+// fifth of the chip, 512 dependent dd multiply-adds per thread, 48 us a step on the chain of the factorisation; 32 x 32
+// tiles (PT = 2) are four times as many of a quarter the length.  Same sums in the same order: bit-identical.
+template <int PT>
 __global__ __launch_bounds__(256) void k_ddchol_update(double* __restrict__ Hh, double* __restrict__ Hl, int np, int k0) {
+    constexpr int TS = 16 * PT, LD = TS + 1;                  // panel staged as [column][row], conflict-free both ways
     extern __shared__ double upd_sm[];
     double* Lih = upd_sm;
-    double* Lil = Lih + DNB * UPD_LD;
-    double* Ljh = Lil + DNB * UPD_LD;
-    double* Ljl = Ljh + DNB * UPD_LD;
-    const int k1 = k0 + DNB, b0 = k1 / DT;
+    double* Lil = Lih + DNB * LD;
+    double* Ljh = Lil + DNB * LD;
+    double* Ljl = Ljh + DNB * LD;
+    const int k1 = k0 + DNB, b0 = k1 / TS;
     int bi = int((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
     while ((long)(bi + 1) * (bi + 2) / 2 <= (long)blockIdx.x) ++bi;
     while ((long)bi * (bi + 1) / 2 > (long)blockIdx.x) --bi;
     const int bj = blockIdx.x - bi * (bi + 1) / 2;
-    const int ti = (b0 + bi) * DT, tj = (b0 + bj) * DT;
+    const int ti = (b0 + bi) * TS, tj = (b0 + bj) * TS;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    for (int e = threadIdx.x; e < DT * DNB; e += 256) {
+    for (int e = threadIdx.x; e < TS * DNB; e += 256) {
         const int r = e / DNB, c = e - r * DNB;
         const bool vi = ti + r >= k1, vj = tj + r >= k1;
-        Lih[c * UPD_LD + r] = vi ? Hh[(long)(ti + r) * np + k0 + c] : 0.0;
-        Lil[c * UPD_LD + r] = vi ? Hl[(long)(ti + r) * np + k0 + c] : 0.0;
-        Ljh[c * UPD_LD + r] = vj ? Hh[(long)(tj + r) * np + k0 + c] : 0.0;
-        Ljl[c * UPD_LD + r] = vj ? Hl[(long)(tj + r) * np + k0 + c] : 0.0;
+        Lih[c * LD + r] = vi ? Hh[(long)(ti + r) * np + k0 + c] : 0.0;
+        Lil[c * LD + r] = vi ? Hl[(long)(ti + r) * np + k0 + c] : 0.0;
+        Ljh[c * LD + r] = vj ? Hh[(long)(tj + r) * np + k0 + c] : 0.0;
+        Ljl[c * LD + r] = vj ? Hl[(long)(tj + r) * np + k0 + c] : 0.0;
     }
     __syncthreads();
-    const int i0 = ti + ty * 4, j0 = tj + tx * 4;
-    if (i0 + 3 < j0) return;                                  // 4 x 4 patch entirely above the diagonal
-    dd acc[4][4];
+    const int i0 = ti + ty * PT, j0 = tj + tx * PT;
+    if (i0 + PT - 1 < j0) return;                             // PT x PT patch entirely above the diagonal
+    dd acc[PT][PT];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], Hl[(long)(i0 + p) * np + j0 + s]);
+        for (int s = 0; s < PT; ++s) acc[p][s] = dd_make(Hh[(long)(i0 + p) * np + j0 + s], Hl[(long)(i0 + p) * np + j0 + s]);
     for (int c = 0; c < DNB; ++c) {
-        dd a[4], b[4];
+        dd a[PT], b[PT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) a[p] = dd_make(Lih[c * UPD_LD + ty * 4 + p], Lil[c * UPD_LD + ty * 4 + p]);
+        for (int p = 0; p < PT; ++p) a[p] = dd_make(Lih[c * LD + ty * PT + p], Lil[c * LD + ty * PT + p]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = dd_make(Ljh[c * UPD_LD + tx * 4 + s], Ljl[c * UPD_LD + tx * 4 + s]);
+        for (int s = 0; s < PT; ++s) b[s] = dd_make(Ljh[c * LD + tx * PT + s], Ljl[c * LD + tx * PT + s]);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[p][s] = dd_fnma(acc[p][s], a[p], b[s]);
+            for (int s = 0; s < PT; ++s) acc[p][s] = dd_fnma(acc[p][s], a[p], b[s]);
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < PT; ++s)
             if (i0 + p >= k1 && j0 + s >= k1 && i0 + p >= j0 + s) {
                 Hh[(long)(i0 + p) * np + j0 + s] = acc[p][s].h;
                 Hl[(long)(i0 + p) * np + j0 + s] = acc[p][s].l;
             }
 }
+template <int PT>
+constexpr size_t upd_lds() { return 4 * (size_t)DNB * (16 * PT + 1) * sizeof(double); }
+
+// tile edge of the dd rank-k kernels: 32 while that still gives at most a few thousand workgroups, 64 beyond (MBFIR_DD_TILE=64|32)
+static int dd_patch(int np) {
+    int pt = np <= 2048 ? 2 : 4;
+    if (const char* ev = std::getenv("MBFIR_DD_TILE")) pt = std::atoi(ev) == 64 ? 4 : (std::atoi(ev) == 32 ? 2 : pt);
+    return pt;
+}
 
 void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount, int np, double* Hh, double* Hl,
                     hipStream_t st) {
-    const int nt = np / DT;
-    hipLaunchKernelGGL(k_dd_syrk, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, U, ldu, X, kcount, np, Hh, Hl);
+    if (dd_patch(np) == 2) {
+        const int nt = np / 32;
+        hipLaunchKernelGGL(k_dd_syrk<2>, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, U, ldu, X, kcount, np, Hh, Hl);
+    } else {
+        const int nt = np / 64;
+        hipLaunchKernelGGL(k_dd_syrk<4>, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, U, ldu, X, kcount, np, Hh, Hl);
+    }
 }
 
 // Inverses of the 64 x 64 diagonal blocks of L in double-double (one workgroup per block; (Xh, Xl): np/64 blocks of 64 x 64,
@@ -293,16 +323,25 @@ __global__ __launch_bounds__(256) void k_dd_blockinv(const double* __restrict__ 
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
                     double pivtol, int* flag, hipStream_t st, double* dinv) {
     static std::once_flag attr_set;                       // (mbfir_solve_batch runs its contexts on parallel host threads)
-    std::call_once(attr_set, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update), hipFuncAttributeMaxDynamicSharedMemorySize, int(UPD_LDS)); });
+    std::call_once(attr_set, [] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<4>()));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<2>()));
+    });
+    const int pt = dd_patch(np);
     hipMemsetAsync(flag, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_dd_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, Hh, np, d0);
     for (int k0 = 0; k0 < np; k0 += DNB) {
-        hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
+        hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(1024), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
         const int rows = np - k0 - DNB;
         if (rows <= 0) break;
         hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 32)), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
-        const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
-        hipLaunchKernelGGL(k_ddchol_update, dim3(nt * (nt + 1) / 2), dim3(256), UPD_LDS, st, Hh, Hl, np, k0);
+        if (pt == 2) {
+            const int nt = (np - k0 - DNB) / 32;
+            hipLaunchKernelGGL(k_ddchol_update<2>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<2>(), st, Hh, Hl, np, k0);
+        } else {
+            const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
+            hipLaunchKernelGGL(k_ddchol_update<4>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<4>(), st, Hh, Hl, np, k0);
+        }
     }
     if (dinv) {
         static std::once_flag inv_set;

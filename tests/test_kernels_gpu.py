@@ -175,6 +175,28 @@ def test_double_double_solve_by_block_inverses_agrees_with_the_substitution(monk
     assert not np.array_equal(xl1, xl0) or np.array_equal(xh1, xh0)          # (two different orders of summation: the low words differ)
 
 
+def test_double_double_factorisation_is_the_same_with_32_and_64_wide_tiles(monkeypatch):
+    """The dd rank-k kernels (k_dd_syrk, k_ddchol_update) run on 32 x 32 tiles up to np = 2048 (four times the workgroups
+    of a quarter the length: the trailing matrix of np = 1088 is 51 tiles of 64 x 64 on average, a fifth of the chip) and
+    on 64 x 64 tiles beyond; MBFIR_DD_TILE forces either.  Every entry's sum runs in the same order: same factor and
+    same solution bit for bit."""
+    rng = np.random.default_rng(33)
+    n, k = 449, 70
+    B = rng.standard_normal((n + 30, n))
+    Hw = B.T @ B
+    Hw = 0.5 * (Hw + Hw.T)
+    U = rng.standard_normal((k, n))
+    X = 10.0 ** rng.uniform(8, 15, k)
+    b = rng.standard_normal((2, n))
+    bl = np.zeros((2, n))
+    out = {}
+    for tile in ("32", "64"):
+        monkeypatch.setenv("MBFIR_DD_TILE", tile)
+        out[tile] = mbfir.test_ddsolve(Hw, U, X, b, bl, factor=True)
+    for a32, a64 in zip(out["32"], out["64"]):
+        assert np.array_equal(a32, a64)
+
+
 def test_double_double_solve_with_one_right_hand_side_equals_the_first_of_two():
     """k_dd_trsv_mw<1> against k_dd_trsv_mw<2>: the blocks' sums run in the same order per right-hand side, so the
     single solve reproduces column 0 of the double solve bit for bit."""
