@@ -1,0 +1,48 @@
+"""Random lock-step batches: every seed of tests/test_fuzz_gpu.py's generator gives a base spec and variants that differ in
+ripples / spike bound / weights only (mostly the same shape: they share a lock-step unit; where the shape follows from the
+ripples the batch front end separates them).  All variants of SEVERAL seeds go through one mbfir_solve_batch call (mixed
+shapes: units are formed speculatively and regrouped); every job must equal its single-design solve bit for bit.
+    python tools/gpu_fuzz_lockstep.py lo hi [seeds per call] [lanes (0 automatic)]"""
+import os, sys, time, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); warnings.filterwarnings("ignore")
+import numpy as np
+import mbfir
+import test_fuzz_gpu as F
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+per_call = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+scales = (1.0, 1.25, 0.8, 1.6, 0.9, 1.1)
+def variants(seed):
+    which, args = F.make_case(seed)
+    out = []
+    for s in scales:
+        a = list(args)
+        a[3] = np.asarray(args[3]) * s                      # ripples
+        if which == "fir_ap_cvx": a[5] = args[5] * (2.0 - s)      # the spike bound too
+        out.append((which, tuple(a)))
+    return out
+bad, t0, njobs, lanes_seen = [], time.time(), 0, {}
+ctxs = [mbfir.Context(0) for _ in range(3)]
+for s0 in range(lo, hi, per_call):
+    jobs, tags = [], []
+    for seed in range(s0, min(hi, s0 + per_call)):
+        for v, job in enumerate(variants(seed)):
+            jobs.append(job); tags.append((seed, v))
+    # qp: the extended-precision solve runs one design at a time; without it the units form
+    opts = mbfir.make_opts(ddkkt=-1, lanes=lanes)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=opts)
+    except Exception as e:
+        bad.append((s0, "batch raised %r" % (e,))); continue
+    for (seed, v), job, (h, status, info) in zip(tags, jobs, res):
+        njobs += 1
+        lanes_seen[info["lanes"]] = lanes_seen.get(info["lanes"], 0) + 1
+        h1, s1, i1 = getattr(mbfir, job[0])(*job[1], ctx=ctxs[0], info=True, opts=opts)
+        if s1 != status or i1["iters"] != info["iters"] or (status == "Solved" and (not np.array_equal(h, h1) or info["pcost"] != i1["pcost"])):
+            bad.append((seed, v, job[0], "batch %s %d it %.17g / single %s %d it %.17g, lanes %d" % (status, info["iters"], info["pcost"], s1, i1["iters"], i1["pcost"], info["lanes"])))
+    print("seeds %d..%d: %d jobs so far, %d mismatches, %.0f s" % (lo, min(hi, s0 + per_call) - 1, njobs, len(bad), time.time() - t0), flush=True)
+print("lock-step fuzz, seeds %d..%d: %d jobs, %d mismatches; unit sizes seen %s" % (lo, hi - 1, njobs, len(bad), sorted(lanes_seen.items())))
+for b in bad:
+    print("  FAIL", b)
