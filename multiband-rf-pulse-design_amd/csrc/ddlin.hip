@@ -146,45 +146,46 @@ __global__ __launch_bounds__(1024) void k_ddchol_diag(double* __restrict__ Hh, d
     if (tid < DNB) { rih[k0 + tid] = rh[tid]; ril[k0 + tid] = rl[tid]; }
 }
 
-// (2) panel rows below the diagonal block: X D' = A by forward substitution.  Eight threads per row: thread q of a
-// row keeps the solved entries c = q (mod 8) in registers and contributes their products to every later column; the
-// eight partial sums meet by three xor-shuffles.  (One thread per row walked 496 dependent dd products: 55 us a panel.)
+// (2) panel rows below the diagonal block: X D' = A by forward substitution.  Eight threads per row; thread q OWNS the
+// columns c = q (mod 8) of its row and keeps their running values  a_c - sum_{k < c, k solved} x_k D[c][k]  in registers.
+// Step c: the owner of column c finishes it (one dd product with 1 / D[c][c]) and shuffles it to the row's other seven
+// threads, and every thread takes x_c out of the columns it still owns.  On the chain from x_c to x_c+1 are one shuffle,
+// one dd multiply-add and one dd product -- the other (up to three) multiply-adds of a thread wait for nobody.  (Round 2
+// summed the products per thread and folded eight partial sums by three shuffles for EVERY column: 29 us a panel; one thread
+// per row walked 496 dependent products: 55 us.)  The sums run over k ascending, as in the oracle's dd_chol.
 __global__ __launch_bounds__(256) void k_ddchol_trsm(double* __restrict__ Hh, double* __restrict__ Hl,
                                                      double* __restrict__ Lth, double* __restrict__ Ltl, int np, int k0,
                                                      const double* __restrict__ rih, const double* __restrict__ ril) {
     __shared__ double Dh[DNB][DNB + 1], Dl[DNB][DNB + 1];
-    __shared__ double ah[DNB][33], al[DNB][33];
     __shared__ double rh[DNB], rl[DNB];
-    const int tid = threadIdx.x, rr = tid >> 3, q8 = tid & 7;
+    const int tid = threadIdx.x, rr = tid >> 3, q8 = tid & 7, lane = tid & 63;
     const int i0 = k0 + DNB + blockIdx.x * 32, i = i0 + rr;
     for (int e = tid; e < DNB * DNB; e += 256) {
         const int r = e / DNB, c = e - r * DNB;
         Dh[r][c] = Hh[(long)(k0 + r) * np + k0 + c];
         Dl[r][c] = Hl[(long)(k0 + r) * np + k0 + c];
-        const bool lv = i0 + r < np;                          // row r of this block, column c of the panel
-        ah[c][r] = lv ? Hh[(long)(i0 + r) * np + k0 + c] : 0.0;
-        al[c][r] = lv ? Hl[(long)(i0 + r) * np + k0 + c] : 0.0;
     }
     if (tid < DNB) { rh[tid] = rih[k0 + tid]; rl[tid] = ril[k0 + tid]; }
-    __syncthreads();
     dd x[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = dd_make(0.0, 0.0);
+    for (int k = 0; k < 4; ++k) {
+        const int c = 8 * k + q8;
+        x[k] = i < np ? dd_make(Hh[(long)i * np + k0 + c], Hl[(long)i * np + k0 + c]) : dd_make(0.0, 0.0);
+    }
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < DNB; ++c) {
-        dd sum = dd_make(0.0, 0.0);
+        const int kc = c >> 3, owner = c & 7;                 // (static after unrolling)
+        if (q8 == owner) x[kc] = dd_mul(x[kc], dd_make(rh[c], rl[c]));
+        const dd xc = dd_shfl(x[kc], (lane & ~7) | owner);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int q = 8 * k + q8;
-            if (8 * k < c) {                                  // (static bound; q < c tested per lane)
-                const dd t = dd_mul(x[k], dd_make(Dh[c][q], Dl[c][q]));
-                if (q < c) sum = dd_add(sum, t);
+            const int cc = 8 * k + q8;                        // a column this thread owns
+            if (8 * k + 7 > c) {                              // (static: some column of block k lies behind c)
+                const dd v = dd_fnma(x[k], xc, dd_make(Dh[cc][c], Dl[cc][c]));
+                if (cc > c) x[k] = v;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) sum = dd_add(sum, dd_make(__shfl_xor(sum.h, o, 64), __shfl_xor(sum.l, o, 64)));
-        const dd v = dd_mul(dd_sub(dd_make(ah[c][rr], al[c][rr]), sum), dd_make(rh[c], rl[c]));
-        if ((c & 7) == q8) x[c >> 3] = v;
     }
     if (i < np) {
 #pragma unroll
