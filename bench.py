@@ -132,6 +132,43 @@ def s_lp_baseline(mbfir, ctx):
             "note": "a 1028 x 32 LP is launch-latency bound on the GPU; this leg is the reference's CPU-runnable case, not a throughput claim"}
 
 
+def other_configs(mbfir, ctxs):
+    """BASELINE configs 3 and 4 as batches, AFTER the timed region (rank 0, one GPU): not the metric, but measured in the same run
+    so that the record holds them.  Config 4: bSSFP_pulse_diff_Peak's sweep, 256 designs n=200 m=4096, lock-step units of 32 on
+    the bench's streams.  Config 3: specsat_H1_dualband through fir_qp_cvx as written (k=120, obj=1e6, n=512, m=16384; the
+    extended-precision KKT solve runs one design per stream), 8 designs whose ripples differ by 2 % steps, 8 streams."""
+    out = {}
+    jobs4 = sweep_jobs(mbfir, 200, 256)
+    o4 = mbfir.make_opts(grid_m=4096, lanes=32)
+    mbfir.solve_batch(jobs4[:64], ctxs=ctxs, opts=o4)
+    t = time.perf_counter()
+    res = mbfir.solve_batch(jobs4, ctxs=ctxs, opts=o4, info=True)
+    dt = time.perf_counter() - t
+    out["config4_sweep_256_designs_n200_m4096"] = {"designs_per_s": 256 / dt, "solved": sum(1 for r in res if r[1] == "Solved"),
+                                                   "lanes": res[0][2]["lanes"], "streams": len(ctxs),
+                                                   "ipm_iters_per_design": sum(r[2]["iters"] for r in res) / 256.0}
+    f, a, d = mbfir.spec.spec_h1_dualband(512)
+    jobs3 = [("fir_qp_cvx", (512, f, a, [x * (1.0 + 0.02 * q) for x in d], 120.0, 1e6)) for q in range(8)]
+    o3 = mbfir.make_opts(grid_m=16384)
+    pool = list(ctxs) + [mbfir.Context(ctxs[0].device) for _ in range(max(0, 8 - len(ctxs)))]
+    try:
+        mbfir.solve_batch(jobs3[:len(pool)], ctxs=pool, opts=o3)
+        t = time.perf_counter()
+        res = mbfir.solve_batch(jobs3, ctxs=pool, opts=o3, info=True)
+        dt = time.perf_counter() - t
+        t = time.perf_counter()
+        _, st1, i1 = mbfir.fir_qp_cvx(*jobs3[0][1], opts=o3, ctx=pool[0], info=True)
+        dt1 = time.perf_counter() - t
+        out["config3_fir_qp_cvx_h1_dualband_n512_m16384"] = {
+            "designs_per_s": 8 / dt, "batch": 8, "streams": len(pool), "solved": sum(1 for r in res if r[1] == "Solved"),
+            "ipm_iters": [r[2]["iters"] for r in res], "extended_precision_iters": [r[2]["dd_iters"] for r in res],
+            "one_design_alone_s": dt1, "one_design_status": st1}
+    finally:
+        for c in pool[len(ctxs):]:
+            c.close()
+    return out
+
+
 def pmc_traffic():
     """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from this round's PMC passes (tools/rocprof_summary.py writes
     profiles/r03_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
@@ -155,6 +192,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="contexts / HIP streams the units are spread over")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="cpu_baseline leg: -1 the oracle to convergence on one design "
                     "(1-3 minutes), k > 0 the first k iterations extrapolated, 0 skip")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the untimed legs for BASELINE configs 3 and 4")
     ap.add_argument("--shard-n", type=int, default=2048)
     ap.add_argument("--shard-grid-m", type=int, default=131072)
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the row-sharded config-5 leg")
@@ -425,6 +463,11 @@ def main():
             "roofline": dominant,
             "roofline_other": others,
         }
+        if world == 1 and not args.dense and not args.no_other_configs:
+            try:
+                out["other_baseline_configs"] = other_configs(mbfir, ctxs)
+            except Exception as e:                          # noqa: BLE001  (never at the cost of the metric's line)
+                out["other_baseline_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and args.cpu_iters != 0:
             cb = cpu_baseline(jobs[0], args.grid_m, infos[0]["iters"], args.cpu_iters)
             out["cpu_baseline"] = cb

@@ -32,13 +32,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    # the untimed legs for BASELINE configs 3 and 4 (full size whatever --n says: 256 designs of n=200; 8 of fir_qp_cvx n=512)
+    oc = d["other_baseline_configs"]
+    c4, c3 = oc["config4_sweep_256_designs_n200_m4096"], oc["config3_fir_qp_cvx_h1_dualband_n512_m16384"]
+    assert c4["solved"] == 256 and c4["designs_per_s"] > 100 and c4["lanes"] == 32
+    assert c3["solved"] == 8 and c3["designs_per_s"] > 1 and min(c3["extended_precision_iters"]) > 0 and c3["one_design_status"] == "Solved"
 
 
 def test_bench_full_convergence_cpu_leg_and_distinct_designs():
     """The cpu_baseline leg runs the oracle to convergence (no extrapolation) when asked to, and the timed batch holds
     distinct designs (iteration counts differ)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--n", "100", "--grid-m", "2048",
-                        "--designs", "16", "--lanes", "4", "--streams", "2", "--cpu-iters", "-1"], capture_output=True, text=True, timeout=900)
+                        "--designs", "16", "--lanes", "4", "--streams", "2", "--cpu-iters", "-1", "--no-other-configs"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
     cb = d["cpu_baseline"]
