@@ -318,6 +318,27 @@ __global__ __launch_bounds__(256) void k_dd_blockinv(const double* __restrict__ 
     }
 }
 
+// Every kernel of this file resolved once, by ONE thread, before any context launches them (called from the Solver's
+// constructor under a process-wide once_flag).  mbfir_solve_batch enters the extended-precision path from up to eight host
+// threads at the same moment; twice this round a batch of BASELINE config 3 on 8 streams died under `rocprofv3 --kernel-trace`
+// with a fault below hipLaunchKernel in dd_chol_launch on a context's FIRST build (never unprofiled, never on 4 streams).
+// The kernel-attribute calls here are all behind call_once; what remained concurrent on first use was the runtime's own
+// lazy resolution of the kernels' code objects.  This takes that window away; it does not claim to be the cause.
+void dd_warm_kernels() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        hipFuncAttributes fa;
+        const void* ks[] = {reinterpret_cast<const void*>(&k_dd_syrk<2>), reinterpret_cast<const void*>(&k_dd_syrk<4>),
+                            reinterpret_cast<const void*>(&k_dd_diag_copy), reinterpret_cast<const void*>(&k_ddchol_diag),
+                            reinterpret_cast<const void*>(&k_ddchol_trsm), reinterpret_cast<const void*>(&k_ddchol_update<2>),
+                            reinterpret_cast<const void*>(&k_ddchol_update<4>), reinterpret_cast<const void*>(&k_dd_blockinv)};
+        for (const void* k : ks) (void)hipFuncGetAttributes(&fa, k);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<4>()));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<2>()));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_blockinv), hipFuncAttributeMaxDynamicSharedMemorySize, int(BLOCKINV_LDS));
+    });
+}
+
 // In-place lower Cholesky of the dd matrix (Hh, Hl) (np x np row-major, np a multiple of 64); on exit the lower
 // triangle holds L, (Lth, Ltl) hold L' (upper triangle, row-major), (rih, ril) the reciprocals of diag(L);
 // flag[0] counts replaced pivots; d0 is a work vector of np doubles.

@@ -116,6 +116,7 @@ void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount
                     hipStream_t st);
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
                     double pivtol, int* flag, hipStream_t st, double* dinv = nullptr);     // dinv: 2 np x 64 doubles, the inverses of the 64 x 64 diagonal blocks of L
+void dd_warm_kernels();      // resolve the dd kernels once, single-threaded (ddlin.hip)
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
                     const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags = nullptr, int epoch = 0,
                     int* lost = nullptr, const double* dinv = nullptr);

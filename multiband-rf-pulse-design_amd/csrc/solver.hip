@@ -2325,6 +2325,7 @@ Solver::Solver(int device) : impl(new Impl()) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw HipError("no HIP device available");
     MBFIR_HIP(hipSetDevice(device));
+    dd_warm_kernels();
     MBFIR_HIP(hipStreamCreate(&impl->st));
     MBFIR_HIP(hipEventCreate(&impl->ev0));
     MBFIR_HIP(hipEventCreate(&impl->ev1));

@@ -9,9 +9,14 @@ mkdir -p $OUT
 UNIT="tools/gpu_lanes_one.py 512 16384 16 16 1 1"          # one lock-step unit of 16 headline designs, one stream
 # 1. the bench line itself, then the same command under the kernel trace
 python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench_trace.log 2>&1 || exit 1
+# (--no-other-configs: the kernel trace is of the metric's workload.  The untimed config-3 leg -- eight host threads entering the
+#  extended-precision path at once -- died twice this round under the profiler, profiles/README.md "Known issue"; the unprofiled
+#  bench.json above carries that leg)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 --no-other-configs > $OUT/bench_trace.log 2>&1 || exit 1
 # 2. one lock-step unit alone: kernel trace and the counter passes
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/unit_trace -o unit -- python3 $UNIT > $OUT/unit_trace.log 2>&1 || exit 1
+# (the unit of 8 designs VERDICT r2 set its bar on: <= 0.30 ms per factorisation)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/unit8_trace -o unit8 -- python3 tools/gpu_lanes_one.py 512 16384 8 8 1 1 > $OUT/unit8_trace.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/unit_pmc_busy -o unit -- python3 $UNIT > $OUT/unit_pmc_busy.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/unit_pmc_insts -o unit -- python3 $UNIT > $OUT/unit_pmc_insts.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/unit_pmc_fetch -o unit -- python3 $UNIT > $OUT/unit_pmc_fetch.log 2>&1 || exit 1

@@ -64,7 +64,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     for d, out in (("bench_trace", "r03_bench_kernel_stats.csv"), ("unit_trace", "r03_unit16_kernel_stats.csv"),
-                   ("dense_trace", "r03_dense_kernel_stats.csv")):
+                   ("unit8_trace", "r03_unit8_kernel_stats.csv"), ("dense_trace", "r03_dense_kernel_stats.csv")):
         kernel_stats(d, out)
     if os.path.exists(os.path.join(SRC, "bench.json")):
         with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, "r03_bench.json"), "w") as out:
