@@ -169,6 +169,43 @@ def other_configs(mbfir, ctxs):
     return out
 
 
+def other_configs_in_child(device, nstream, timeout_s=900):
+    """The untimed legs in a FRESH child process: a native fault there (they include the 8-context extended-precision
+    batch) cannot be caught by try/except and would take the already-measured metric line with it.  The child is started from this
+    process (subprocess: fork + exec in the child, never an exec of the GPU-initialised parent) and prints one JSON object; a
+    non-zero exit, a timeout or unparsable output becomes an "error" entry."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--other-configs-child", "--device", str(device), "--streams", str(nstream)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "the child running the untimed legs did not finish within %d s" % timeout_s}
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": "could not start the child for the untimed legs: %s: %s" % (type(e).__name__, e)}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child exit code %d" % r.returncode, "stderr_tail": r.stderr[-600:]}
+    try:
+        return json.loads(lines[-1])
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": "unparsable child output: %s" % e, "stdout_tail": r.stdout[-300:]}
+
+
+def other_configs_child(device, nstream):
+    """entry of the child process: its own contexts, the legs of other_configs, one JSON object on stdout"""
+    import mbfir
+    ctxs = [mbfir.Context(device) for _ in range(nstream)]
+    try:
+        try:
+            res = other_configs(mbfir, ctxs)
+        except Exception as e:                              # noqa: BLE001
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(res), flush=True)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def pmc_traffic():
     """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from this round's PMC passes (tools/rocprof_summary.py writes
     profiles/r03_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
@@ -203,7 +240,12 @@ def main():
                     "reductions go through the host hook instead of its own RCCL communicator)")
     ap.add_argument("--dense", action="store_true", help="materialised trig matrix + dense MFMA Gram (opts.dense_trig) "
                     "instead of the default lattice (matrix-free) mode; one design per stream")
+    ap.add_argument("--other-configs-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.other_configs_child:
+        other_configs_child(args.device, max(1, args.streams))
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -471,10 +513,7 @@ def main():
             "roofline_other": others,
         }
         if world == 1 and not args.dense and not args.no_other_configs:
-            try:
-                out["other_baseline_configs"] = other_configs(mbfir, ctxs)
-            except Exception as e:                          # noqa: BLE001  (never at the cost of the metric's line)
-                out["other_baseline_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["other_baseline_configs"] = other_configs_in_child(local_rank, nstream)
         if world == 1 and args.cpu_iters != 0:
             cb = cpu_baseline(jobs[0], args.grid_m, infos[0]["iters"], args.cpu_iters)
             out["cpu_baseline"] = cb

@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <memory>
+#include <system_error>
 #include <thread>
 
 using namespace mbfir;
@@ -186,6 +187,63 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
 
 }  // namespace
 
+// ---- fault diagnostics (MBFIR_FAULT_MAPS=<file>) ---------------------------------------------------
+// Round 3 recorded a SIGSEGV below hipLaunchKernel under `rocprofv3 --kernel-trace` whose log held bare PCs and no module map,
+// so the frames between this library and the faulting copy could not be attributed.  With MBFIR_FAULT_MAPS set, the first
+// mbfir_create installs a SIGSEGV / SIGBUS handler that writes the fault address and /proc/self/maps -- taken AT THE FAULT,
+// so that queue rings, kernarg pools and thread arenas mapped since start-up are in it -- to that file (async-signal-safe
+// calls only) and then hands the signal to whoever was installed before (the profiler's stack printer, the default action).
+#include <csignal>
+#include <fcntl.h>
+#include <unistd.h>
+namespace {
+char g_maps_path[512];
+struct sigaction g_old_segv, g_old_bus;
+void put_hex(int fd, unsigned long v) {
+    char b[19] = "0x0000000000000000";
+    for (int i = 0; i < 16; ++i) b[17 - i] = "0123456789abcdef"[(v >> (4 * i)) & 15];
+    (void)!write(fd, b, 18);
+}
+void fault_handler(int sig, siginfo_t* si, void* uc) {
+    const int out = open(g_maps_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (out >= 0) {
+        const char h1[] = "\n==== mbfir fault: signal ";
+        (void)!write(out, h1, sizeof(h1) - 1);
+        put_hex(out, (unsigned long)sig);
+        const char h2[] = " at address ";
+        (void)!write(out, h2, sizeof(h2) - 1);
+        put_hex(out, (unsigned long)si->si_addr);
+        const char h3[] = " ; /proc/self/maps at the fault:\n";
+        (void)!write(out, h3, sizeof(h3) - 1);
+        const int in = open("/proc/self/maps", O_RDONLY);
+        if (in >= 0) {
+            char buf[4096];
+            for (;;) { const ssize_t n = read(in, buf, sizeof(buf)); if (n <= 0) break; (void)!write(out, buf, size_t(n)); }
+            close(in);
+        }
+        close(out);
+    }
+    struct sigaction* old = sig == SIGBUS ? &g_old_bus : &g_old_segv;
+    sigaction(sig, old, nullptr);                          // back to the previous handler: returning re-executes the faulting access
+    (void)uc;
+}
+void install_fault_maps() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* pth = std::getenv("MBFIR_FAULT_MAPS");
+        if (!pth || !*pth) return;
+        std::snprintf(g_maps_path, sizeof(g_maps_path), "%s", pth);
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = fault_handler;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGSEGV, &sa, &g_old_segv);
+        sigaction(SIGBUS, &sa, &g_old_bus);
+    });
+}
+}  // namespace
+
 extern "C" {
 
 const char* mbfir_version(void) { return "mbfir 0.1 (gfx950)"; }
@@ -198,6 +256,7 @@ void mbfir_default_opts(mbfir_opts* o) {
 
 mbfir_ctx* mbfir_create(int device_id) {
     try {
+        install_fault_maps();                                  // (a profiler's handlers are installed at load: this one chains to them)
         mbfir_ctx* c = new mbfir_ctx();
         c->solver.reset(new Solver(device_id));
         return c;
@@ -363,15 +422,19 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
             if (q >= njobs) break;
             std::string e;
             jobs[q].err[0] = 0;
-            arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
-            if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
-            else if (!(sharded || lanes_cap == 1)) {
-                // the shape key (CSR maps, lattice analysis: a sort of the grid) here, not in the serial grouping loop:
-                // 64 headline designs cost 40 ms there with the GPU idle; the structures stay with the program
-                const SolveOpts so = to_opts(opts, progs[q].which);
-                keys[q] = Solver::shape_key(progs[q], so);
-                keys[q].push_back(Solver::max_lanes(progs[q], so));
+            try {
+                arc[q] = sharded || lanes_cap == 1 ? 0 : assemble_job(jobs[q], opts ? opts->grid_m : 0, progs[q], e);
+                if (arc[q] == 0 && !(sharded || lanes_cap == 1)) {
+                    // the shape key (CSR maps, lattice analysis: a sort of the grid) here, not in the serial grouping loop:
+                    // 64 headline designs cost 40 ms there with the GPU idle; the structures stay with the program
+                    const SolveOpts so = to_opts(opts, progs[q].which);
+                    keys[q] = Solver::shape_key(progs[q], so);
+                    keys[q].push_back(Solver::max_lanes(progs[q], so));
+                }
+            } catch (const std::exception& ex) {               // (host memory: the job is reported, the coordinator is not left waiting)
+                arc[q] = MBFIR_E_HIP; e = ex.what();
             }
+            if (arc[q] != 0) std::snprintf(jobs[q].err, sizeof(jobs[q].err), "%s", e.c_str());
             { std::lock_guard<std::mutex> lk(mu); assembled[q] = 1; }
             cv_asm.notify_all();
         }
@@ -494,20 +557,46 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                     finish_job(U[b]);
                 }
                 for (int q : redo) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
-            } catch (const std::exception& e) {
-                // the unit as a whole failed (a shape the lock-step path rejects, a device error): every design of it
-                // goes through the single-design path, which reports its own verdict or error
+            } catch (const ShapeError& e) {
+                // the lock-step path does not take these programs as one unit: every design of it goes through the
+                // single-design path, which reports its own verdict or error
                 ctx->err = e.what();
                 for (int q : U) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
+            } catch (const std::exception& e) {
+                // an internal or device error (a lost in-launch hand-off of the factorisation, a HIP error, the arena):
+                // reported for every design of the unit, NOT retried -- the single-design path takes other kernels and
+                // would hide a defect of the lock-step ones behind a slow success
+                ctx->err = e.what();
+                for (int q : U) {
+                    std::memset(&jobs[q].info, 0, sizeof(jobs[q].info));
+                    jobs[q].info.status = MBFIR_E_HIP; jobs[q].info.lanes = int(U.size());
+                    jobs[q].rc = MBFIR_E_HIP;
+                    std::snprintf(jobs[q].err, sizeof(jobs[q].err), "lock-step unit of %d: %s", int(U.size()), e.what());
+                }
             }
             release_programs();
         }
     };
+    // a worker / assembler that throws (bad_alloc while parking programs, ...) must not take the process down
+    // (std::terminate from a thread's entry function): the first message is kept and the call returns MBFIR_E_HIP
+    std::string thread_err;
+    auto guarded = [&](auto&& body) {
+        try { body(); }
+        catch (const std::exception& e) { std::lock_guard<std::mutex> lk(mu); if (thread_err.empty()) thread_err = e.what(); }
+        catch (...) { std::lock_guard<std::mutex> lk(mu); if (thread_err.empty()) thread_err = "unknown exception in a batch thread"; }
+    };
     std::vector<std::thread> th;
     const int nasm = std::max(1, std::min(njobs, std::min(16, int(std::thread::hardware_concurrency()))));
     const int nwork = std::max(1, std::min(nctx, njobs));
-    for (int c = 0; c < nasm; ++c) th.emplace_back(asm_work);
-    for (int c = 0; c < nwork; ++c) th.emplace_back(work, c);
+    // Thread creation can fail (EAGAIN: up to 16 + nctx threads per call): what was started is joined and the rest of the
+    // work is done by fewer threads -- in the limit by the calling thread alone (assembly inline, then the units one context
+    // after the other) -- instead of destroying joinable threads, which ends the process.
+    int started_asm = 0, started_work = 0;
+    try {
+        for (int c = 0; c < nasm; ++c) { th.emplace_back([&] { guarded(asm_work); }); ++started_asm; }
+        for (int c = 0; c < nwork; ++c) { th.emplace_back([&, c] { guarded([&] { work(c); }); }); ++started_work; }
+    } catch (const std::system_error&) {}
+    if (started_asm == 0) guarded(asm_work);
     std::string coord_err;
     try { coordinate(); } catch (const std::exception& e) { coord_err = e.what(); }
     { std::lock_guard<std::mutex> lk(mu); units_closed = true; }
@@ -516,7 +605,9 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
         std::vector<TrigProgram> old;
         { std::lock_guard<std::mutex> lk(g_parked_mu); old.swap(g_parked); }
     }                                                                // (the previous batch's last programs, freed while the units run)
+    if (started_work == 0) guarded([&] { work(0); });
     for (auto& t : th) t.join();
+    if (coord_err.empty() && !thread_err.empty()) coord_err = thread_err;
     if (trace) std::fprintf(stderr, "[batch] %zu units, all done at %.2f ms\n", units.size(), now_ms() - t0);
     if (!coord_err.empty()) {
         for (int q = 0; q < njobs; ++q) {                  // (host memory exhausted while forming units: nothing of the batch is reported)

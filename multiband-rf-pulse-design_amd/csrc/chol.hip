@@ -1456,16 +1456,24 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
     if (const char* ev = std::getenv("MBFIR_CHOL_SPLIT")) split = std::atoi(ev);
     bool poison = false;
     if (const char* ev = std::getenv("MBFIR_POISON")) poison = std::atoi(ev) != 0;
-    {   // test hook: lose the hand-off of one panel step (see g_chol_lose_step); the bound shrinks so that the test takes a second
-        static int lose_now = -1;
+    {   // test hook: lose the hand-off of one panel step (see g_chol_lose_step); the bound shrinks so that the test takes a second.
+        // The symbols are per device and the contexts of a batch call this from parallel host threads: the value each device
+        // holds is remembered per device, under a mutex.
+        static std::mutex lose_mu;
+        static int lose_now[64];
+        static bool lose_init = false;
         int lose = -1;
         if (const char* ev = std::getenv("MBFIR_TEST_LOSE_FLAG")) lose = std::atoi(ev);
-        if (lose != lose_now) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(lose_mu);
+        if (!lose_init) { for (int& v : lose_now) v = -1; lose_init = true; }
+        if (dev >= 0 && dev < 64 && lose != lose_now[dev]) {
             const int limit = lose >= 0 ? (1 << 14) : CHOL_SPIN_LIMIT_DEFAULT;
             hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chol_lose_step), &lose, sizeof(int), 0, hipMemcpyHostToDevice, st);
             hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chol_spin_limit), &limit, sizeof(int), 0, hipMemcpyHostToDevice, st);
             hipStreamSynchronize(st);
-            lose_now = lose;
+            lose_now[dev] = lose;
         }
     }
     if ((long)dag_cnt_ints(nblk) * 4 > ((long)np * np - (long)np) * 8) split = split == 4 ? (nlanes >= 3 ? 1 : 0) : split;   // (W1 too small: np = 64)
@@ -1632,11 +1640,7 @@ void hsolve_launch(const double* M, int np, const double* b, const double* b2, d
     const int U = (np + 127) / 128;
     const size_t lds = (size_t)4 * nv * U * 128 * sizeof(double);
 #define HS_CASE(NVX, UX)                                                                                                   \
-    {                                                                                                                      \
-        static std::once_flag once;                                                                                        \
-        std::call_once(once, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hsolve<NVX, UX>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NVX * UX * 128 * 8); }); \
-        hipLaunchKernelGGL((k_hsolve<NVX, UX>), grid, dim3(256), lds, st, M, np, b, b2, part, ldv, lane_bytes, mask);     \
-    }
+    hipLaunchKernelGGL((k_hsolve<NVX, UX>), grid, dim3(256), lds, st, M, np, b, b2, part, ldv, lane_bytes, mask);
     if (nv == 1) {
         switch (U) { case 1: HS_CASE(1, 1) break; case 2: HS_CASE(1, 2) break; case 3: HS_CASE(1, 3) break; case 4: HS_CASE(1, 4) break;
                      case 5: HS_CASE(1, 5) break; case 6: HS_CASE(1, 6) break; case 7: HS_CASE(1, 7) break; default: HS_CASE(1, 8) break; }
@@ -1647,6 +1651,18 @@ void hsolve_launch(const double* M, int np, const double* b, const double* b2, d
         hipLaunchKernelGGL(k_hsolve_fold<2>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
     }
 #undef HS_CASE
+    if (lds > 64 * 1024) MBFIR_HIP(hipGetLastError());    // (a launch above 64 KB of LDS is rejected on a device whose attribute was never set)
+}
+// Dynamic LDS above 64 KB is an attribute of the device function of the CURRENT device: set once per device (Solver's
+// constructor, under its mutex), not behind process-wide flags at the launch sites -- those only ever reached the first
+// context's device, and the 8-GPU node runs a context per device.
+template <int NVX, int UX>
+static void hsolve_attr() {
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hsolve<NVX, UX>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NVX * UX * 128 * 8));
+}
+void chol_warm_kernels() {
+    hsolve_attr<1, 1>(); hsolve_attr<1, 2>(); hsolve_attr<1, 3>(); hsolve_attr<1, 4>(); hsolve_attr<1, 5>(); hsolve_attr<1, 6>(); hsolve_attr<1, 7>(); hsolve_attr<1, 8>();
+    hsolve_attr<2, 1>(); hsolve_attr<2, 2>(); hsolve_attr<2, 3>(); hsolve_attr<2, 4>(); hsolve_attr<2, 5>(); hsolve_attr<2, 6>(); hsolve_attr<2, 7>(); hsolve_attr<2, 8>();
 }
 
 void trigemv_launch(const double* T, int np, int upper, const double* b, double* y, int nv, int ldv,

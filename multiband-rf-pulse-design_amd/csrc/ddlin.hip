@@ -318,58 +318,49 @@ __global__ __launch_bounds__(256) void k_dd_blockinv(const double* __restrict__ 
     }
 }
 
-// Every kernel of this file resolved once, by ONE thread, before any context launches them (called from the Solver's
-// constructor under a process-wide once_flag).  mbfir_solve_batch enters the extended-precision path from up to eight host
-// threads at the same moment; twice this round a batch of BASELINE config 3 on 8 streams died under `rocprofv3 --kernel-trace`
-// with a fault below hipLaunchKernel in dd_chol_launch on a context's FIRST build (never unprofiled, never on 4 streams).
-// The kernel-attribute calls here are all behind call_once; what remained concurrent on first use was the runtime's own
-// lazy resolution of the kernels' code objects.  This takes that window away; it does not claim to be the cause.
-void dd_warm_kernels() {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        hipFuncAttributes fa;
-        const void* ks[] = {reinterpret_cast<const void*>(&k_dd_syrk<2>), reinterpret_cast<const void*>(&k_dd_syrk<4>),
-                            reinterpret_cast<const void*>(&k_dd_diag_copy), reinterpret_cast<const void*>(&k_ddchol_diag),
-                            reinterpret_cast<const void*>(&k_ddchol_trsm), reinterpret_cast<const void*>(&k_ddchol_update<2>),
-                            reinterpret_cast<const void*>(&k_ddchol_update<4>), reinterpret_cast<const void*>(&k_dd_blockinv)};
-        for (const void* k : ks) (void)hipFuncGetAttributes(&fa, k);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<4>()));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<2>()));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_blockinv), hipFuncAttributeMaxDynamicSharedMemorySize, int(BLOCKINV_LDS));
-    });
+// The launch sites of the dd Cholesky, one non-inlined function each: a stack trace through hipLaunchKernel then names the
+// site (round 3's crash log showed one frame, dd_chol_launch, for all of them).
+#define DD_SITE __attribute__((noinline)) static
+DD_SITE void dd_site_diag(double* Hh, double* Hl, double* Lth, double* Ltl, int np, int k0, double* d0, double pivtol, int* flag,
+                          double* rih, double* ril, hipStream_t st) {
+    hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(1024), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
 }
+DD_SITE void dd_site_trsm(double* Hh, double* Hl, double* Lth, double* Ltl, int np, int k0, int rows, double* rih, double* ril, hipStream_t st) {
+    hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 32)), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
+}
+DD_SITE void dd_site_update(double* Hh, double* Hl, int np, int k0, int pt, hipStream_t st) {
+    if (pt == 2) {
+        const int nt = (np - k0 - DNB) / 32;
+        hipLaunchKernelGGL(k_ddchol_update<2>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<2>(), st, Hh, Hl, np, k0);
+    } else {
+        const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
+        hipLaunchKernelGGL(k_ddchol_update<4>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<4>(), st, Hh, Hl, np, k0);
+    }
+}
+DD_SITE void dd_site_blockinv(double* Hh, double* Hl, double* rih, double* ril, int np, double* dinv, hipStream_t st) {
+    hipLaunchKernelGGL(k_dd_blockinv, dim3(np / DIB), dim3(256), BLOCKINV_LDS, st, Hh, Hl, rih, ril, np, dinv, dinv + (size_t)np * DIB);
+}
+#undef DD_SITE
 
 // In-place lower Cholesky of the dd matrix (Hh, Hl) (np x np row-major, np a multiple of 64); on exit the lower
 // triangle holds L, (Lth, Ltl) hold L' (upper triangle, row-major), (rih, ril) the reciprocals of diag(L);
 // flag[0] counts replaced pivots; d0 is a work vector of np doubles.
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
                     double pivtol, int* flag, hipStream_t st, double* dinv) {
-    static std::once_flag attr_set;                       // (mbfir_solve_batch runs its contexts on parallel host threads)
-    std::call_once(attr_set, [] {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<4>()));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<2>()));
-    });
     const int pt = dd_patch(np);
     hipMemsetAsync(flag, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_dd_diag_copy, dim3(cdiv(np, 256)), dim3(256), 0, st, Hh, np, d0);
     for (int k0 = 0; k0 < np; k0 += DNB) {
-        hipLaunchKernelGGL(k_ddchol_diag, dim3(1), dim3(1024), 0, st, Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril);
+        dd_site_diag(Hh, Hl, Lth, Ltl, np, k0, d0, pivtol, flag, rih, ril, st);
         const int rows = np - k0 - DNB;
         if (rows <= 0) break;
-        hipLaunchKernelGGL(k_ddchol_trsm, dim3(cdiv(rows, 32)), dim3(256), 0, st, Hh, Hl, Lth, Ltl, np, k0, rih, ril);
-        if (pt == 2) {
-            const int nt = (np - k0 - DNB) / 32;
-            hipLaunchKernelGGL(k_ddchol_update<2>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<2>(), st, Hh, Hl, np, k0);
-        } else {
-            const int b0 = (k0 + DNB) / DT, nt = np / DT - b0;
-            hipLaunchKernelGGL(k_ddchol_update<4>, dim3(nt * (nt + 1) / 2), dim3(256), upd_lds<4>(), st, Hh, Hl, np, k0);
-        }
+        dd_site_trsm(Hh, Hl, Lth, Ltl, np, k0, rows, rih, ril, st);
+        dd_site_update(Hh, Hl, np, k0, pt, st);
     }
-    if (dinv) {
-        static std::once_flag inv_set;
-        std::call_once(inv_set, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_blockinv), hipFuncAttributeMaxDynamicSharedMemorySize, int(BLOCKINV_LDS)); });
-        hipLaunchKernelGGL(k_dd_blockinv, dim3(np / DIB), dim3(256), BLOCKINV_LDS, st, Hh, Hl, rih, ril, np, dinv, dinv + (size_t)np * DIB);
-    }
+    if (dinv) dd_site_blockinv(Hh, Hl, rih, ril, np, dinv, st);
+    // the update and block-inverse kernels need more LDS than a launch gets by default: a device whose attribute was not set
+    // rejects them, and the factor would stay whatever the buffers held
+    MBFIR_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,17 +637,28 @@ void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const
     }
     if (np > DD_NP_MAX) throw HipError("dd solve: matrix too large for the LDS-resident right-hand sides");
     const size_t sh = (2 * (size_t)nv * np + 2 * DNB * (DNB + 1)) * sizeof(double);
-    if (nv == 1) {
-        static std::once_flag set1;                       // (mbfir_solve_batch runs its contexts on parallel host threads)
-        std::call_once(set1, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
-        hipLaunchKernelGGL(k_dd_trsv<1>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
-    } else if (nv == 2) {
-        static std::once_flag set2;
-        std::call_once(set2, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); });
-        hipLaunchKernelGGL(k_dd_trsv<2>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
-    } else {
-        throw HipError("dd solve: unsupported number of right-hand sides");
-    }
+    if (nv == 1) hipLaunchKernelGGL(k_dd_trsv<1>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
+    else if (nv == 2) hipLaunchKernelGGL(k_dd_trsv<2>, dim3(1), dim3(1024), sh, st, Lh, Ll, Lth, Ltl, rih, ril, np, Bh, Bl, ldv);
+    else throw HipError("dd solve: unsupported number of right-hand sides");
+    MBFIR_HIP(hipGetLastError());                          // (up to 160 KB of LDS: rejected where the attribute is missing)
+}
+
+// Per-device preparation of this file's kernels (called from the Solver's constructor, once per device id under its
+// mutex): the code objects are resolved by ONE thread before any context launches them, and the dynamic-LDS limits above
+// 64 KB -- an attribute of the device function of the CURRENT device -- are set on every device that gets a context
+// (round 3 set them behind process-wide flags: only the first context's device ever got them).
+void dd_warm_kernels() {
+    hipFuncAttributes fa;
+    const void* ks[] = {reinterpret_cast<const void*>(&k_dd_syrk<2>), reinterpret_cast<const void*>(&k_dd_syrk<4>),
+                        reinterpret_cast<const void*>(&k_dd_diag_copy), reinterpret_cast<const void*>(&k_ddchol_diag),
+                        reinterpret_cast<const void*>(&k_ddchol_trsm), reinterpret_cast<const void*>(&k_ddchol_update<2>),
+                        reinterpret_cast<const void*>(&k_ddchol_update<4>), reinterpret_cast<const void*>(&k_dd_blockinv)};
+    for (const void* k : ks) (void)hipFuncGetAttributes(&fa, k);
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<4>())));
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ddchol_update<2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(upd_lds<2>())));
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_blockinv), hipFuncAttributeMaxDynamicSharedMemorySize, int(BLOCKINV_LDS)));
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MBFIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dd_trsv<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
 }
 
 }  // namespace mbfir

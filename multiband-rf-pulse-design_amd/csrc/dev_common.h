@@ -116,7 +116,10 @@ void dd_syrk_launch(const double* U, int ldu, const double* X, const int* kcount
                     hipStream_t st);
 void dd_chol_launch(double* Hh, double* Hl, double* Lth, double* Ltl, double* rih, double* ril, double* d0, int np,
                     double pivtol, int* flag, hipStream_t st, double* dinv = nullptr);     // dinv: 2 np x 64 doubles, the inverses of the 64 x 64 diagonal blocks of L
-void dd_warm_kernels();      // resolve the dd kernels once, single-threaded (ddlin.hip)
+// per-device kernel preparation (code objects resolved, dynamic-LDS attributes set on the CURRENT device): called by the
+// Solver's constructor once per device id, under its mutex
+void dd_warm_kernels();      // ddlin.hip
+void chol_warm_kernels();    // chol.hip
 void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const double* Ltl, const double* rih,
                     const double* ril, int np, double* Bh, double* Bl, int nv, int ldv, hipStream_t st, int* flags = nullptr, int epoch = 0,
                     int* lost = nullptr, const double* dinv = nullptr);

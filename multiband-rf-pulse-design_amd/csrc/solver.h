@@ -1,9 +1,18 @@
 // Host-visible interface of the device IPM (solver.hip).
 #pragma once
 #include "program.h"
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 namespace mbfir {
+
+// solve_lanes was handed programs the lock-step path does not take as ONE unit (too many lanes, different designers or
+// orders): the caller may run the designs one by one.  Every other exception of the solver is an internal / device error
+// and is reported as such, never retried.
+struct ShapeError : std::runtime_error {
+    explicit ShapeError(const std::string& s) : std::runtime_error(s) {}
+};
 
 enum { ST_OPTIMAL = 0, ST_PRIMAL_INFEASIBLE = 1, ST_DUAL_INFEASIBLE = 2, ST_MAXIT = 3, ST_NUMERICAL = 4,
        ST_OPTIMAL_INACCURATE = 5 };

@@ -31,6 +31,7 @@
 // Row-sharded solves: reductions are ncclAllReduce calls on the solver stream (run-time bound RCCL) or a host hook.
 #include "dev_common.h"
 #include <functional>
+#include <mutex>
 #include <thread>
 #include "cone_dev.h"
 #include "dd_dev.h"
@@ -59,11 +60,15 @@ struct RcclApi {
     bool ok = false;
     std::string err;
 };
+static void rccl_bind(RcclApi& api);
 static RcclApi& rccl() {
+    // bound once per process; two contexts may call mbfir_comm_init from different host threads at the same moment
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(api); });
+    return api;
+}
+static void rccl_bind(RcclApi& api) {
     void* h = nullptr;
     // one RCCL per process: a copy that is already loaded (torch's, when the host is Python) is preferred -- by the
     // path the host names in MBFIR_RCCL_PATH, then by the usual names -- before a fresh one is opened
@@ -80,7 +85,7 @@ static RcclApi& rccl() {
         if (h) break;
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!h) { api.err = "librccl not found"; return api; }
+    if (!h) { api.err = "librccl not found"; return; }
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -88,7 +93,6 @@ static RcclApi& rccl() {
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
     if (!api.ok) api.err = "librccl lacks the expected symbols";
-    return api;
 }
 
 enum {
@@ -2325,7 +2329,14 @@ Solver::Solver(int device) : impl(new Impl()) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw HipError("no HIP device available");
     MBFIR_HIP(hipSetDevice(device));
-    dd_warm_kernels();
+    {   // kernel attributes are per device function: once per device id, by one thread at a time
+        static std::mutex warm_mu;
+        static std::vector<char> warmed;
+        std::lock_guard<std::mutex> lk(warm_mu);
+        if (device < 0 || device >= ndev) throw HipError("no such HIP device");
+        if ((int)warmed.size() < ndev) warmed.resize(ndev, 0);
+        if (!warmed[device]) { dd_warm_kernels(); chol_warm_kernels(); warmed[device] = 1; }
+    }
     MBFIR_HIP(hipStreamCreate(&impl->st));
     MBFIR_HIP(hipEventCreate(&impl->ev0));
     MBFIR_HIP(hipEventCreate(&impl->ev1));
@@ -2521,7 +2532,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     hipStream_t st = S.st;
     const double t_begin = now_ms();
     const int nlanes = int(Qs.size());
-    if (nlanes < 1 || nlanes > MAX_LANES) throw HipError("lock-step batch: bad lane count");
+    if (nlanes < 1 || nlanes > MAX_LANES) throw ShapeError("lock-step batch: bad lane count");
     S.nlanes = nlanes;
     // ---- row sharding: this process keeps the frequencies i % size == rank (program.h) ----------
     S.shard_rank = o.shard_size > 1 ? o.shard_rank : 0;
@@ -2530,7 +2541,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (S.comm && S.shard_size > 1 && (S.comm_size != S.shard_size || S.comm_rank != S.shard_rank))
         throw HipError("row-sharded solve: shard_rank / shard_size differ from the RCCL communicator's");
     S.n_collectives = 0;
-    if (S.shard_size > 1 && nlanes > 1) throw HipError("row-sharded solves run one design at a time");
+    if (S.shard_size > 1 && nlanes > 1) throw ShapeError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
         LaneHost& L = LH[b];
@@ -2572,7 +2583,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l ||
             Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ok != Lt.ok ||
             Lb.D1 != Lt.D1 || Lb.ch_start.size() != Lt.ch_start.size() || Lb.wf.size() != Lt.wf.size() || Lb.tmin != Lt.tmin)
-            throw HipError("lock-step batch: lanes differ in shape");
+            throw ShapeError("lock-step batch: lanes differ in shape");
     }
     // ---- sizes -----------------------------------------------------------------------------
     const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;

@@ -138,16 +138,48 @@ def test_a_lost_in_launch_hand_off_fails_loudly(monkeypatch):
     """when a hand-off between workgroups inside the factorisation never arrives (here: the diagonal
     block of panel step 3 is told not to raise its flag -- a test hook), the waiting blocks' bounded polls expire, the
     lane's pivot counter carries CHOL_SYNC_LOST, and the solve returns an internal ERROR -- it neither hangs nor goes on
-    with the previous build's image as if it were this build's.  Both forms that hand over inside a launch."""
+    with the previous build's image as if it were this build's.  Both forms that hand over inside a launch, and the
+    DEFAULT form with nothing forced (the unit's failure used to be answered by re-solving every design through
+    the single-design path, whose fused per-step factorisation has no in-launch hand-offs -- rc 0 after a stall; an
+    internal error of a unit is now reported for its designs, not retried)."""
     jobs = [("fir_ap_cvx", (64, F6, A6, D3, 0.1, 1e-2 * (1 + 0.5 * k))) for k in range(4)]
-    for split in ("4", "1"):
+    for split in (None, "4", "1"):
         ctx = mbfir.Context(0)
+        forced = {} if split is None else {"MBFIR_CHOL_SPLIT": split}
         try:
-            with env(MBFIR_CHOL_SPLIT=split, MBFIR_TEST_LOSE_FLAG=0):
+            with env(MBFIR_TEST_LOSE_FLAG=0, **forced):
                 with pytest.raises(mbfir.MbfirError, match="hand-off"):
                     mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=4, ddkkt=-1))
-            with env(MBFIR_CHOL_SPLIT=split, MBFIR_TEST_LOSE_FLAG=-1):       # and the same context works again afterwards
+            with env(MBFIR_TEST_LOSE_FLAG=-1, **forced):       # and the same context works again afterwards
                 res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=4))
                 assert all(r[1] == "Solved" for r in res)
         finally:
             ctx.close()
+
+
+def test_eight_contexts_enter_the_extended_precision_path_at_once():
+    """Round 3's open defect was a SIGSEGV under `rocprofv3 --kernel-trace` with EIGHT host threads entering the extended-
+    precision (double-double) path on their contexts' FIRST builds at the same moment (profiles/README.md).
+    This is the unprofiled regression of exactly that condition: eight fresh contexts, eight fir_qp_cvx designs whose first
+    solve of the process takes the dd path on every context at once; every result must equal the same design solved alone on
+    one context afterwards.  (Kernel attributes are set per device in the Solver's constructor; every dd launch above 64 KB of
+    LDS is checked.)"""
+    f, a, d = mbfir.spec.spec_h1_dualband(96)
+    jobs = [("fir_qp_cvx", (96, f, a, [x * (1.0 + 0.03 * q) for x in d], 120.0, 1e6)) for q in range(8)]
+    opts = mbfir.make_opts(grid_m=1536, ddkkt=1)
+    ctxs = [mbfir.Context(0) for _ in range(8)]
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=opts)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert all(r[1] == "Solved" for r in res)
+    assert any(r[2]["dd_iters"] > 0 for r in res)
+    one = mbfir.Context(0)
+    try:
+        for (name, args), (h, st, info) in zip(jobs, res):
+            h1, s1, i1 = mbfir.fir_qp_cvx(*args, opts=opts, ctx=one, info=True)
+            assert s1 == "Solved" and i1["iters"] == info["iters"] and i1["dd_iters"] == info["dd_iters"]
+            assert np.array_equal(h, h1)
+    finally:
+        one.close()
