@@ -282,6 +282,18 @@ def make_opts(**kw):
     return o
 
 
+def opts_with(opts, **kw):
+    """a copy of `opts` (None: the defaults) with the given fields replaced"""
+    o = make_opts()
+    if opts is not None:
+        C.memmove(C.byref(o), C.byref(opts), C.sizeof(Opts))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError("unknown option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
 def _finish(ctx, rc, hre, him, info, want_info):
     if rc < 0:
         msg = ctx.last_error()

@@ -53,7 +53,10 @@ public:
     // launch per phase with the design index as a grid dimension; designs that finish are masked out.
     void solve_lanes(const std::vector<const TrigProgram*>& Ps, const SolveOpts& o, std::vector<std::vector<double>>& xouts,
                      std::vector<SolveInfo>& infos);
-    static std::vector<long> shape_key(const TrigProgram& P, const SolveOpts& o);   // equal keys = may share a batch
+    // equal keys = may share a lock-step unit: the program's CLASS (designer, order, unknowns, cones, lattice extent); grids,
+    // row counts and chunk lists may differ within a unit on the lattice path without a big cone (heterogeneous units), elsewhere
+    // the key also holds the exact shape
+    static std::vector<long> shape_key(const TrigProgram& P, const SolveOpts& o);
     static int max_lanes(const TrigProgram& P, const SolveOpts& o);
     // host analysis of a frequency grid (no GPU needed): out[0] lattice ok, [1] folded entries, [2] pairs, [3] runs,
     // [4] longest run, [5] entries that fail the self-check (every frequency exactly once, |w| within 1 ulp of the entry's)

@@ -115,6 +115,7 @@ constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement
 
 // ------------------------------------------------------------------------------------------------
 // device-side problem description
+struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, pad0, pad1; };
 struct DProg {
     int Nt, Ne, N, Mf, R, l, nq3, big, quad;
     int ld, Mpad, LDV, Rp, np;
@@ -150,6 +151,16 @@ struct DProg {
     // mask (not shifted; nlanes ints) switches lanes off: finished designs, refinement sweeps a lane does not need.
     size_t lane_bytes;
     const int* mask;
+    // Heterogeneous units (round 4): lanes of one designer and order whose band edges differ have different grids, row
+    // counts and chunk lists.  Every array and launch is then sized to the unit's MAXIMA (one arena layout for all lanes,
+    // shorter arrays zero-padded) and the kernel prologue replaces the dimensions that differ by the block's lane's own
+    // (dims, not lane-shifted, nlanes entries; null when all lanes have the same dimensions): a lane then does exactly
+    // the arithmetic of its single solve -- blocks past its own extent contribute neutral partials (sums 0, maxima -1e300).
+    const LaneDims* dims;
+    __device__ __forceinline__ void load_dims(int lane) {
+        const LaneDims d = dims[lane];
+        Mf = d.Mf; R = d.R; l = d.l; nyrows = d.nyrows; nfold = d.nfold; nchunk = d.nchunk;
+    }
     template <class T>
     __device__ __forceinline__ static void sh(const T*& p, size_t off) { p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + off); }
     __device__ __forceinline__ void shift(size_t off) {
@@ -169,6 +180,7 @@ __device__ __forceinline__ void lane_shift(size_t off, Ptr&... p) {
 }
 #define LANES(P, ...)                                                \
     if ((P).mask && !(P).mask[blockIdx.z]) return;                    \
+    if ((P).dims) (P).load_dims(blockIdx.z);                          \
     if (blockIdx.z) {                                                 \
         const size_t loff_ = (size_t)blockIdx.z * (P).lane_bytes;     \
         (P).shift(loff_);                                             \
@@ -359,9 +371,13 @@ __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restri
 }
 
 // fold the split partials: TT[v][j] = sum_s partial[s][v][j].  Block = 64 columns x 16 split groups.
+// dims != null (heterogeneous unit, lattice partials): the lane folds its OWN cdiv(nchunk, cgrp) partials -- the grouping of
+// the unrolled sums below depends on the count, and the lane's result has to be that of its single solve bit for bit
 __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict__ partial, int nsplit, int nvv, int ld,
-                                                        int ldo, double* __restrict__ TT, size_t lane_bytes, const int* lane_mask) {
+                                                        int ldo, double* __restrict__ TT, size_t lane_bytes, const int* lane_mask,
+                                                        const LaneDims* __restrict__ dims, int cgrp) {
     LANES_RAW(lane_bytes, lane_mask, partial, TT);
+    if (dims) nsplit = (dims[blockIdx.z].nchunk + cgrp - 1) / cgrp;
     __shared__ double sh[16][65];
     const int c = threadIdx.x, sg = threadIdx.y, j = blockIdx.x * 64 + c, v = blockIdx.y;
     double t = 0;
@@ -392,6 +408,7 @@ template <int NV>
 __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
                                                     const double* __restrict__ val, double* __restrict__ out) {
     LANES(P, partial, val, out);
+    if (P.dims && P.trig) nsplit = (P.nchunk + P.cgrp - 1) / P.cgrp;      // the lane's own partial count (see k_fold_partials)
     __shared__ double sh[2 * NV][GTG][GTC + 1];
     __shared__ double red[17];
     const int c = threadIdx.x, sg = threadIdx.y;
@@ -1889,6 +1906,8 @@ struct Solver::Impl {
     int* maskT = nullptr;        // device, MASK_ROWS x MAX_LANES ints: row 0 = live lanes, rows 1..MAX_SWEEPS = lanes that
                                  // still need CG sweep q, row MAX_SWEEPS + 1 = scratch (lanes with a new best iterate)
     int* hostMask = nullptr;     // pinned twin
+    LaneDims* dimsT = nullptr;   // device, MAX_LANES entries: the lanes' own dimensions in a heterogeneous unit (DProg::dims)
+    LaneDims* hostDims = nullptr;   // pinned twin
     const int* mask_row(int r) const { return nlanes > 1 ? maskT + (size_t)r * MAX_LANES : nullptr; }
     std::string err;
 
@@ -1937,7 +1956,9 @@ struct Solver::Impl {
     size_t meas_lo = 0, meas_hi = 0;                       // the same range as the measuring pass saw it
     template <class T, class F>
     T* upload(F get) {
-        const size_t n0 = get(0).size();
+        // (heterogeneous units: the array is as long as the longest lane's; a shorter lane's tail is zero-filled)
+        size_t n0 = 0;
+        for (int b = 0; b < nlanes; ++b) n0 = std::max(n0, get(b).size());
         T* p = ar.get<T>(std::max<size_t>(n0, 1));
         const size_t off = size_t(reinterpret_cast<char*>(p) - ar.base), bytes = n0 * sizeof(T);
         if (ar.measuring) {
@@ -1950,13 +1971,11 @@ struct Solver::Impl {
             if (off != meas_lo) throw HipError("upload: the layout differs from its measuring pass");
         }
         if (off < stage_hi || off + bytes > meas_hi) throw HipError("upload: arrays out of order");
-        for (int b = 1; b < nlanes; ++b)
-            if (get(b).size() != n0) throw HipError("lock-step batch: lanes differ in shape");
-        pend.push_back({off, bytes, stage_hi, [get](int b) -> const void* { return get(b).data(); }});
+        pend.push_back({off, bytes, stage_hi, [get](int b, size_t& nb) -> const void* { nb = get(b).size() * sizeof(T); return get(b).data(); }});
         stage_hi = off + bytes;
         return p;
     }
-    struct Pend { size_t off, bytes, prev_end; std::function<const void*(int)> src; };
+    struct Pend { size_t off, bytes, prev_end; std::function<const void*(int, size_t&)> src; };
     std::vector<Pend> pend;
     void flush_uploads() {
         if (pend.empty()) return;
@@ -1976,7 +1995,13 @@ struct Solver::Impl {
                 char* img = stage + region * b;
                 for (const Pend& q : pend) {
                     if (q.off > q.prev_end) std::memset(img + (q.prev_end - stage_lo), 0, q.off - q.prev_end);      // alignment gap before the array
-                    if (q.bytes) std::memcpy(img + (q.off - stage_lo), q.src(b), q.bytes);
+                    if (q.bytes) {
+                        size_t nb = 0;
+                        const void* src = q.src(b, nb);
+                        if (nb > q.bytes) nb = q.bytes;
+                        if (nb) std::memcpy(img + (q.off - stage_lo), src, nb);
+                        if (nb < q.bytes) std::memset(img + (q.off - stage_lo) + nb, 0, q.bytes - nb);
+                    }
                 }
                 const size_t filled = stage_hi - stage_lo;
                 if (region > filled) std::memset(img + filled, 0, region - filled);
@@ -2053,7 +2078,7 @@ struct Solver::Impl {
 #undef MOM_CASE
             default: throw HipError("moments: unsupported vector count");
         }
-        hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.LDM, 64), 2 * nv), nlanes), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, P.cgrp), 2 * nv, P.LDM, P.LDM, out, lane_bytes, P.mask);
+        hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.LDM, 64), 2 * nv), nlanes), dim3(64, 16), 0, st, partial, cdiv(P.nchunk, P.cgrp), 2 * nv, P.LDM, P.LDM, out, lane_bytes, P.mask, P.dims, P.cgrp);
     }
     void atmulti_array(int nvv, const double* pp) {
         dim3 g(P.ld / 128, nsplit_at), b(64, 4);
@@ -2264,7 +2289,7 @@ struct Solver::Impl {
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti_array(nvv, BB);
-            hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask);
+            hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask, (const LaneDims*)nullptr, 1);
         }
         hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         }
@@ -2344,6 +2369,8 @@ Solver::Solver(int device) : impl(new Impl()) {
     MBFIR_HIP(hipHostMalloc(&impl->hostFlag, sizeof(int) * 4 * MAX_LANES));
     MBFIR_HIP(hipHostMalloc(&impl->hostMask, sizeof(int) * MASK_ROWS * MAX_LANES));
     MBFIR_HIP(hipMalloc(&impl->maskT, sizeof(int) * MASK_ROWS * MAX_LANES));
+    MBFIR_HIP(hipMalloc(&impl->dimsT, sizeof(LaneDims) * MAX_LANES));
+    MBFIR_HIP(hipHostMalloc(&impl->hostDims, sizeof(LaneDims) * MAX_LANES));
     std::memset(impl->hostMask, 0, sizeof(int) * MASK_ROWS * MAX_LANES);
 }
 Solver::~Solver() {
@@ -2356,6 +2383,8 @@ Solver::~Solver() {
     if (impl->hostFlag) hipHostFree(impl->hostFlag);
     if (impl->hostMask) hipHostFree(impl->hostMask);
     if (impl->maskT) hipFree(impl->maskT);
+    if (impl->dimsT) hipFree(impl->dimsT);
+    if (impl->hostDims) hipHostFree(impl->hostDims);
     for (hipEvent_t e : impl->evpool) hipEventDestroy(e);
     if (impl->ev0) hipEventDestroy(impl->ev0);
     if (impl->ev1) hipEventDestroy(impl->ev1);
@@ -2471,9 +2500,18 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     const LatticeInfo& Lt = pr->Lt;
     long tbits = 0;
     std::memcpy(&tbits, &Lt.tmin, sizeof(double));
-    return {long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.Mf), long(Q.R), long(Q.l), long(Q.nq3), long(Q.big),
-            long(Q.quad), long(pr->f_rows.size()), long(pr->c_rows.size()), long(pr->yrows.size()), long(Lt.ok), long(Lt.D1),
-            long(Lt.ch_start.size()), long(Lt.wf.size()), tbits};
+    // the CLASS of the program: what all lanes of a unit must share (solve_lanes)
+    std::vector<long> key{long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.nq3), long(Q.big), long(Q.quad), long(pr->c_rows.size()),
+                          long(Lt.ok), long(Lt.D1), tbits};
+    // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path, big cone; MBFIR_HETERO=0:
+    // round 3's rule everywhere), the exact shape: grid, rows, chunks
+    bool exact = !Lt.ok || o.dense_trig || Q.big;
+    if (const char* ev = std::getenv("MBFIR_HETERO")) exact = exact || std::atoi(ev) == 0;
+    if (exact) {
+        const long more[] = {long(Q.Mf), long(Q.R), long(Q.l), long(pr->f_rows.size()), long(pr->yrows.size()), long(Lt.ch_start.size()), long(Lt.wf.size())};
+        key.insert(key.end(), std::begin(more), std::end(more));
+    }
+    return key;
 }
 void Solver::test_fold(const double* w, int Mf, int fold, long* out) {
     TrigProgram Q;
@@ -2577,16 +2615,31 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         MBFIR_HIP(hipStreamSynchronize(st));
         if (S.hostSc[0] > -0.5) LH[0].Lt = LatticeInfo();      // somebody lacks it: dense path everywhere
     }
+    // ---- the unit: one CLASS (designer, order, unknowns, cones, lattice extent); within it the lanes' grids, row counts and
+    // chunk lists may differ (designs of one order with different band edges: the probes of fir_ap.m:63-106, sweeps over
+    // specs) -- arrays and launches are then sized to the unit's maxima and every lane carries its own dimensions (DProg::dims)
+    int Mf_max = Q.Mf, R_max = Q.R, l_max = Q.l, nyrows_max = int(LH[0].yrows.size());
+    size_t nchunk_max = Lt.ch_start.size(), nfold_max = Lt.wf.size();
+    bool hetero = false;
     for (int b = 1; b < nlanes; ++b) {
         const TrigProgram& Qb = *LH[b].Q;
         const LatticeInfo& Lb = LH[b].Lt;
-        if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l ||
-            Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ok != Lt.ok ||
-            Lb.D1 != Lt.D1 || Lb.ch_start.size() != Lt.ch_start.size() || Lb.wf.size() != Lt.wf.size() || Lb.tmin != Lt.tmin)
-            throw ShapeError("lock-step batch: lanes differ in shape");
+        if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad ||
+            Lb.ok != Lt.ok || Lb.D1 != Lt.D1 || Lb.tmin != Lt.tmin || LH[b].c_rows.size() != LH[0].c_rows.size())
+            throw ShapeError("lock-step batch: lanes differ in class (designer, order, cone structure or lattice extent)");
+        if (Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ch_start.size() != Lt.ch_start.size() ||
+            Lb.wf.size() != Lt.wf.size())
+            hetero = true;
+        Mf_max = std::max(Mf_max, Qb.Mf); R_max = std::max(R_max, Qb.R); l_max = std::max(l_max, Qb.l);
+        nyrows_max = std::max(nyrows_max, int(LH[b].yrows.size()));
+        nchunk_max = std::max(nchunk_max, Lb.ch_start.size()); nfold_max = std::max(nfold_max, Lb.wf.size());
     }
+    // what the per-lane dimensions do not cover: the dense path (its kernels take Mf from the launch), and the big cone,
+    // whose partial row sits behind the block partials (its position in the fold would move with the unit's maxima)
+    if (hetero && (!Lt.ok || o.dense_trig || Q.big)) throw ShapeError("lock-step batch: lanes differ in shape (dense path / big cone)");
+    if (std::getenv("MBFIR_HETERO") && std::atoi(std::getenv("MBFIR_HETERO")) == 0 && hetero) throw ShapeError("lock-step batch: lanes differ in shape (MBFIR_HETERO=0)");
     // ---- sizes -----------------------------------------------------------------------------
-    const int R = Q.R, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Q.Mf;
+    const int R = R_max, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Mf_max;
     const int nw = Q.quad ? 3 : 1;
     S.gp = gram_plan(Mf, Nt, nw);
     DProg& P = S.P;
@@ -2595,7 +2648,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
     if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
     P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
-    P.nchunk = int(Lt.ch_start.size()); P.nfold = int(Lt.wf.size());
+    P.nchunk = int(nchunk_max); P.nfold = int(nfold_max);
     P.seeds_shared = 0;
     if (nlanes > 1 && Lt.ok) {                               // sweeps over Peak / ripple keep the grid: one seed table serves the unit
         bool same = true;
@@ -2611,11 +2664,19 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                          // 3 TB/s through HBM, and that, not the recurrences, is what the moment kernels then wait for
     if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
     P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
-    P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = Q.l; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
+    P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = l_max; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
-    P.nyrows = int(LH[0].yrows.size());
-    P.mask = nullptr; P.lane_bytes = 0;
+    P.nyrows = nyrows_max;
+    P.mask = nullptr; P.lane_bytes = 0; P.dims = nullptr;
+    if (hetero) {
+        for (int b = 0; b < nlanes; ++b) {
+            const TrigProgram& Qb = *LH[b].Q;
+            S.hostDims[b] = LaneDims{Qb.Mf, Qb.R, Qb.l, int(LH[b].yrows.size()), int(LH[b].Lt.wf.size()), int(LH[b].Lt.ch_start.size()), 0, 0};
+        }
+        MBFIR_HIP(hipMemcpyAsync(S.dimsT, S.hostDims, sizeof(LaneDims) * nlanes, hipMemcpyHostToDevice, st));
+        P.dims = S.dimsT;
+    }
     S.nsplit_at = cdiv(P.Mpad, AT_ROWS);
     const int ncone = P.l + P.nq3;
     S.nbR = cdiv(R, 256); S.nbN = cdiv(N, 256); S.nbC = cdiv(ncone, 256);
@@ -2951,14 +3012,14 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.ms_assemble = t_assembled - t_begin;
         info.ms_solve = t_end - t_assembled;                  // of the whole lock-step batch
         info.ms_gram = ms_gram; info.ms_chol = ms_chol; info.h_builds = builds;
-        info.n_freq = Mf; info.n_rows = R; info.n_unknowns = N;
+        info.n_freq = LH[b].Q->Mf; info.n_rows = LH[b].Q->R; info.n_unknowns = N;
         info.lattice = P.trig;
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
         info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
         info.chol_launches = int(S.chol_launch_count);
         info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
-        info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
+        info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(LH[b].Q->Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency
                                 : double(nw) * double(Mf) * double(Nt) * double(Nt + 1);
     }
     S.nlanes_last = nlanes; S.taps_valid = false;

@@ -3,8 +3,9 @@ ss/fir_min_order_linprog.m and ss/fir_min_order_qprog_phs.m.
 
 fir_ap(n, f, a, d, Peak, min_order, min_tran, ...) reproduces the reference's two bisections
 (fir_ap.m:63-106 transition widening, :143-176 order) probe for probe when `probes == 1`.  With
-`probes > 1` every round hands that many interior points to mbfir.solve_batch at once (one HIP stream
-each), which shrinks the bracket by (probes + 1) per round instead of 2; for a feasibility predicate
+`probes > 1` every round hands that many interior points to mbfir.solve_batch at once -- the probes of a
+transition-width round (one order, different band edges) as ONE lock-step unit, the probes of an order round one per
+HIP stream --, which shrinks the bracket by (probes + 1) per round instead of 2; for a feasibility predicate
 that is monotone in the searched parameter -- what a bisection assumes anyway -- the bracket ends at
 the same threshold.
 """
@@ -23,9 +24,10 @@ def _widen(f, f_add):
     return fn
 
 
-def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *, probes=1, opts=None, log=None):
+def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *, probes=1, opts=None, log=None, unit_probes=True):
     """Returns (h, status, n_op, f_op) like fir_ap.m.  probes: candidates evaluated concurrently per
-    search round (1 = the reference's bisection).  log: optional list receiving (kind, value, status)."""
+    search round (1 = the reference's bisection).  log: optional list receiving (kind, value, status).
+    unit_probes: the probes of a round that share the order run as one lock-step unit (False: one design per stream)."""
     import mbfir
     if n is None or f is None or a is None or d is None:
         raise ValueError("not enough input")
@@ -41,8 +43,12 @@ def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *,
         if len(jobs) == 1:
             nn, ff = jobs[0]
             return [mbfir.fir_ap_cvx(nn, ff, a, d, LAMBDA, Peak, opts=opts)]
-        return mbfir.solve_batch([("fir_ap_cvx", (nn, ff, a, d, LAMBDA, Peak)) for nn, ff in jobs], opts=opts,
-                                 streams=min(len(jobs), 4))
+        batch = [("fir_ap_cvx", (nn, ff, a, d, LAMBDA, Peak)) for nn, ff in jobs]
+        if unit_probes and len({nn for nn, _ in jobs}) == 1:
+            # one order, different band edges (the probes of a transition-width round): ONE lock-step unit on one stream --
+            # every launch carries all probes (heterogeneous unit) instead of one design per stream
+            return mbfir.solve_batch(batch, opts=mbfir.opts_with(opts, lanes=len(batch)), streams=1)
+        return mbfir.solve_batch(batch, opts=opts, streams=min(len(jobs), 4))
 
     n_op, f_op = n, f
     h1, status1 = design([(n, f)])[0]                                   # fir_ap.m:51

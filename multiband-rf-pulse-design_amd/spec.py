@@ -143,3 +143,28 @@ def spec_h1_dualband(n=260, T=26.0):
     ref = sum(bands[2]) / 2
     cf = [((lo - ref) * B0 * 42.577e-3, (hi - ref) * B0 * 42.577e-3) for lo, hi in bands]
     return band_spec(n, dt, cf, [0.01] * 3, [120, 0, 90], [0.05, 0.001, 0.05], "sat", shift_f=1)
+
+
+def spec_rand(n, seed, kmin=2, kmax=8):
+    """S-RAND (SURVEY.md 8(d); no reference script -- the robustness / heterogeneous-batch workload): k in {kmin..kmax}
+    non-overlapping bands on [-1, 1], widths U(0.01, 0.1), gaps >= 8 / n, |B_N| amplitudes 0 or U(0.2, 0.9) (at least one
+    pass band), ripples U(0.002, 0.02); NumPy default_rng(12345 + seed).  Returns (f, a, d) as the FIR designers take them;
+    feasibility at a given order is for the caller to establish (the designers return 'Failed' on an infeasible draw)."""
+    rng = np.random.default_rng(12345 + int(seed))
+    k = int(rng.integers(kmin, kmax + 1))
+    widths = rng.uniform(0.01, 0.1, k)
+    gmin = 8.0 / n
+    slack = 2.0 - widths.sum() - (k + 1) * gmin
+    if slack <= 0:
+        raise ValueError("spec_rand: %d bands with gaps of 8 / n do not fit at n = %d" % (k, n))
+    cuts = np.sort(rng.uniform(0.0, slack, k + 1))
+    extra = np.diff(np.concatenate([[0.0], cuts]))           # the free room dealt over the k + 1 gaps (the rest stays at the right end)
+    f, x = np.zeros(2 * k), -1.0
+    for i in range(k):
+        x += gmin + extra[i]
+        f[2 * i], f[2 * i + 1] = x, x + widths[i]
+        x += widths[i]
+    amp = np.where(rng.random(k) < 0.5, 0.0, rng.uniform(0.2, 0.9, k))
+    if not np.any(amp > 0):
+        amp[int(rng.integers(0, k))] = 0.6
+    return f, np.repeat(amp, 2), rng.uniform(0.002, 0.02, k)

@@ -383,6 +383,66 @@ def test_units_start_before_the_batch_is_assembled_and_survive_a_change_of_shape
         c.close()
 
 
+def _widened(f, dfw):
+    """band edges moved outwards by dfw each -- what one probe of the transition-width bisection does to them (fir_ap.m:63-106)"""
+    f = np.asarray(f, float).copy()
+    f[0::2] -= dfw
+    f[1::2] += dfw
+    return list(f)
+
+
+def test_heterogeneous_units_designs_of_one_order_with_different_band_edges():
+    """a lock-step unit takes designs of one designer and one order whose BAND EDGES differ -- the probes of
+    the reference's transition-width bisection (fir_ap.m:63-106: same n, bands widened by f_add on every probe) and sweeps over
+    specs with different numbers of bands.  Their grids (m = 30 n + 2 k points, reordered [bands, transition]), row counts
+    (|idx_stop|), folded-frequency and chunk lists all differ; the unit is sized to the maxima and every lane carries its own
+    dimensions.  Every lane must equal its single-design solve BIT FOR BIT, verdict, iteration count, objective and taps; an
+    infeasible probe in the unit (half of a bisection's probes are) keeps its verdict."""
+    n = 64
+    f, a, d = c13(n)
+    jobs = [("fir_ap_cvx", (n, _widened(f, 1e-3 * q), a, d, 0.1, 1e-3)) for q in range(5)]       # bisection-like probes
+    for seed in (0, 1, 3, 4, 6, 9):                                                                 # other band counts (k = 2..8)
+        fr, ar, dr = mbfir.spec.spec_rand(n, seed)
+        jobs.append(("fir_ap_cvx", (n, list(fr), list(ar * 0.5), list(dr), 0.1, 1e-2)))
+    jobs.insert(3, ("fir_ap_cvx", (n, _widened(f, 0.03), a, [x * 0.02 for x in d], 0.1, 1e-3)))   # far too tight: infeasible
+    ctxs = [mbfir.Context(0), mbfir.Context(0)]
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=mbfir.make_opts(lanes=6))
+        shapes = set()
+        for q, (job, (h, status, info)) in enumerate(zip(jobs, res)):
+            h1, s1, i1 = getattr(mbfir, job[0])(*job[1], ctx=ctxs[0], info=True)
+            assert s1 == status and i1["iters"] == info["iters"], (q, status, s1, info["iters"], i1["iters"])
+            assert info["n_rows"] == i1["n_rows"] and info["n_freq"] == i1["n_freq"]
+            if status == "Solved":
+                assert info["pcost"] == i1["pcost"] and np.array_equal(h, h1), q
+            shapes.add((info["n_rows"], info["n_freq"]))
+        assert all(r[2]["lanes"] == 6 for r in res), [r[2]["lanes"] for r in res]                 # 12 jobs: two units of six
+        assert len(shapes) >= 6                                                                     # the unit really was heterogeneous
+        assert res[3][1] == "Failed"
+        assert sum(1 for r in res if r[1] == "Solved") >= 8
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_heterogeneous_unit_of_linear_phase_designs():
+    """The same for fir_linprog (LP rows only, one-sided grid for real filters): pass-band edges moved per design."""
+    base = CASES["lin_real64"][1]
+    jobs = []
+    for q in range(5):
+        f = list(base[1]); f[1] += 0.004 * q; f[2] += 0.006 * q
+        jobs.append(("fir_linprog", (base[0], f, base[2], base[3])))
+    ctx = mbfir.Context(0)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=5))
+        assert all(r[2]["lanes"] == 5 for r in res)
+        for job, (h, status, info) in zip(jobs, res):
+            h1, s1, i1 = mbfir.fir_linprog(*job[1], ctx=ctx, info=True)
+            assert s1 == status == "Solved" and i1["iters"] == info["iters"] and info["pcost"] == i1["pcost"] and np.array_equal(h, h1)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("which", ["fir_linprog", "fir_qprog_phs", "fir_qp_cvx"])
 def test_lock_step_units_of_every_designer_equal_the_single_solves(which):
     """Lock-step units for the other three designers (LP rows only; LP rows + the big cone; Q3 cones + the big cone --

@@ -164,22 +164,23 @@ def test_eight_contexts_enter_the_extended_precision_path_at_once():
     solve of the process takes the dd path on every context at once; every result must equal the same design solved alone on
     one context afterwards.  (Kernel attributes are set per device in the Solver's constructor; every dd launch above 64 KB of
     LDS is checked.)"""
-    f, a, d = mbfir.spec.spec_h1_dualband(96)
-    jobs = [("fir_qp_cvx", (96, f, a, [x * (1.0 + 0.03 * q) for x in d], 120.0, 1e6)) for q in range(8)]
-    opts = mbfir.make_opts(grid_m=1536, ddkkt=1)
+    # fir_qp_cvx the way dzrf_mb calls it (k = 120, obj = 1e6: dzrf_mb.m:210-213) on narrow bands around DC: the regime in which
+    # nearly active cones carry NT weights far above the rest and the extended-precision solve takes over (DESIGN.md 2b)
+    f, a = [-0.3, -0.18, -0.06, 0.06, 0.18, 0.3], [0, 0, 0.8, 0.8, 0, 0]
+    jobs = [("fir_qp_cvx", (64, f, a, [0.02 * (1 + 0.05 * q), 0.03 * (1 + 0.05 * q), 0.02 * (1 + 0.05 * q)], 120.0, 1e6)) for q in range(8)]
+    opts = mbfir.make_opts(ddkkt=1)
     ctxs = [mbfir.Context(0) for _ in range(8)]
     try:
         res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=opts)
     finally:
         for c in ctxs:
             c.close()
-    assert all(r[1] == "Solved" for r in res)
-    assert any(r[2]["dd_iters"] > 0 for r in res)
+    assert sum(1 for r in res if r[2]["dd_iters"] > 0) >= 4, [(r[1], r[2]["iters"], r[2]["dd_iters"]) for r in res]
     one = mbfir.Context(0)
     try:
         for (name, args), (h, st, info) in zip(jobs, res):
             h1, s1, i1 = mbfir.fir_qp_cvx(*args, opts=opts, ctx=one, info=True)
-            assert s1 == "Solved" and i1["iters"] == info["iters"] and i1["dd_iters"] == info["dd_iters"]
+            assert s1 == st and i1["iters"] == info["iters"] and i1["dd_iters"] == info["dd_iters"]
             assert np.array_equal(h, h1)
     finally:
         one.close()

@@ -2,7 +2,9 @@
 ripples / spike bound / weights only (mostly the same shape: they share a lock-step unit; where the shape follows from the
 ripples the batch front end separates them).  All variants of SEVERAL seeds go through one mbfir_solve_batch call (mixed
 shapes: units are formed speculatively and regrouped); every job must equal its single-design solve bit for bit.
-    python tools/gpu_fuzz_lockstep.py lo hi [seeds per call] [lanes (0 automatic)]"""
+    python tools/gpu_fuzz_lockstep.py lo hi [seeds per call] [lanes (0 automatic)] [edges]
+With `edges` the variants of a seed also differ in their band edges (scaled towards DC): designs of one order whose grids, row
+counts and chunk lists differ share HETEROGENEOUS units (round 4) and must still equal their single solves bit for bit."""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); warnings.filterwarnings("ignore")
@@ -13,14 +15,17 @@ import test_fuzz_gpu as F
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 per_call = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+edges = len(sys.argv) > 5 and sys.argv[5] == "edges"       # round 4: the variants also differ in their BAND EDGES (heterogeneous units)
 scales = (1.0, 1.25, 0.8, 1.6, 0.9, 1.1)
+fscale = (1.0, 0.97, 0.99, 0.93, 0.985, 0.95)              # edges scaled towards DC: grids, row counts and chunk lists all move
 def variants(seed):
     which, args = F.make_case(seed)
     out = []
-    for s in scales:
+    for q, s in enumerate(scales):
         a = list(args)
         a[3] = np.asarray(args[3]) * s                      # ripples
         if which == "fir_ap_cvx": a[5] = args[5] * (2.0 - s)      # the spike bound too
+        if edges: a[1] = np.asarray(args[1]) * fscale[q]
         out.append((which, tuple(a)))
     return out
 bad, t0, njobs, lanes_seen = [], time.time(), 0, {}
