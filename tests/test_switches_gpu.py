@@ -166,8 +166,10 @@ def test_eight_contexts_enter_the_extended_precision_path_at_once():
     LDS is checked.)"""
     # fir_qp_cvx the way dzrf_mb calls it (k = 120, obj = 1e6: dzrf_mb.m:210-213) on narrow bands around DC: the regime in which
     # nearly active cones carry NT weights far above the rest and the extended-precision solve takes over (DESIGN.md 2b)
-    f, a = [-0.3, -0.18, -0.06, 0.06, 0.18, 0.3], [0, 0, 0.8, 0.8, 0, 0]
-    jobs = [("fir_qp_cvx", (64, f, a, [0.02 * (1 + 0.05 * q), 0.03 * (1 + 0.05 * q), 0.02 * (1 + 0.05 * q)], 120.0, 1e6)) for q in range(8)]
+    # (seed 1 of tests/test_fuzz_gpu.py's large-weight generator: the oracle solves it and its loosened variants in 23-28 iterations)
+    f, a = [-0.13531530807246703, -0.055981529031701, 0.003511847329634643, 0.06198453304672341], [0.0, 0.0, 0.8, 0.8]
+    d0 = [0.03450611451870719, 0.015199726365129066]
+    jobs = [("fir_qp_cvx", (116, f, a, [x * (1.0 + 0.03 * q) for x in d0], 124.04990661153212, 639631.6986321354)) for q in range(8)]
     opts = mbfir.make_opts(ddkkt=1)
     ctxs = [mbfir.Context(0) for _ in range(8)]
     try:
@@ -175,7 +177,7 @@ def test_eight_contexts_enter_the_extended_precision_path_at_once():
     finally:
         for c in ctxs:
             c.close()
-    assert sum(1 for r in res if r[2]["dd_iters"] > 0) >= 4, [(r[1], r[2]["iters"], r[2]["dd_iters"]) for r in res]
+    assert all(r[1] == "Solved" for r in res) and sum(1 for r in res if r[2]["dd_iters"] > 0) >= 4, [(r[1], r[2]["iters"], r[2]["dd_iters"]) for r in res]
     one = mbfir.Context(0)
     try:
         for (name, args), (h, st, info) in zip(jobs, res):
