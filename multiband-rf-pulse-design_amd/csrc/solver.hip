@@ -2827,6 +2827,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
 
     int it = 0;
     bool dd_now = false;
+    // MBFIR_TRACE_HOST=1: where the host thread of this unit spends the solve -- issuing launches, or waiting in the one
+    // synchronisation per iteration (a stream whose host thread issues most of the time is launch-bound, not GPU-bound)
+    const bool trace_host = std::getenv("MBFIR_TRACE_HOST") != nullptr;
+    double host_issue_ms = 0, host_wait_ms = 0, t_issue0 = trace_host ? now_ms() : 0.0;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
@@ -2844,7 +2848,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         }
         hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2, (const int*)S.flag);
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
+        const double t_sync0 = trace_host ? now_ms() : 0.0;
         MBFIR_HIP(hipStreamSynchronize(st));
+        if (trace_host) { const double t1 = now_ms(); host_issue_ms += t_sync0 - t_issue0; host_wait_ms += t1 - t_sync0; t_issue0 = t1; }
         bool any_live = false, any_best = false;
         for (int b = 0; b < nlanes; ++b) S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;      // 1: the lane has a new best iterate
         for (int b = 0; b < nlanes; ++b) {
@@ -3002,6 +3008,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     }
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_end = now_ms();
+    if (trace_host)
+        fprintf(stderr, "[host] unit of %d lanes, %d iterations: issuing launches %.1f ms, waiting in the per-iteration sync %.1f ms (%.0f %% issuing)\n",
+                nlanes, it, host_issue_ms, host_wait_ms, 100.0 * host_issue_ms / std::max(host_issue_ms + host_wait_ms, 1e-9));
     double ms_gram = 0, ms_chol = 0;
     int builds = 0;
     S.collect_times(ms_gram, ms_chol, builds);

@@ -353,7 +353,7 @@ def next_sweeps(norm_lists, nsweep, tol):
 
 
 def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
-          reltol=1e-8, refine=2, verbose=False, history=None, ddkkt=None):
+          reltol=1e-8, refine=2, verbose=False, history=None, ddkkt=None, start=None):
     """Returns dict(status, x, s, z, iters, pcost, dcost, gap, pres, dres).
 
     Stopping rule (all quantities of the de-homogenised point x/tau ...):
@@ -567,6 +567,21 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
     if tz >= -1e-8 * max(1.0, np.linalg.norm(z)):
         z = z + (1.0 + tz) * e
     tau, kappa = 1.0, 1.0
+    if start is not None:
+        # STUDY ONLY (tools/exp/warmstart_study.py): a warm start of the homogeneous embedding in the manner
+        # of Skajaa, Andersen & Ye -- the convex combination of a neighbouring problem's optimum (x*, s*, z*) with a cold,
+        # well-centred point: start = dict(x, s, z, lam[, cold]).  cold = "e": (0, e, e, 1, 1) as in their paper; "own": this
+        # solver's own initial point computed above.  The device takes no starting point (measured, not adopted).
+        lam_ws = float(start["lam"])
+        if start.get("cold", "e") == "e":
+            xc, sc, zc = np.zeros(N), e.copy(), e.copy()
+        else:
+            xc, sc, zc = x, s, z
+        x = lam_ws * np.asarray(start["x"], dtype=np.float64) + (1 - lam_ws) * xc
+        s = lam_ws * np.asarray(start["s"], dtype=np.float64) + (1 - lam_ws) * sc
+        z = lam_ws * np.asarray(start["z"], dtype=np.float64) + (1 - lam_ws) * zc
+        tau = 1.0
+        kappa = float(s @ z) / (cone.degree + 1)
     status = STATUS_MAXIT
     it = 0
     info = {}

@@ -64,6 +64,12 @@ def main():
         out["highs_status"] = int(rh.status)
         if rh.status == 0:
             dx = rh.x - x
+            # HiGHS's own optimum and its taps: what a solve converges to when its gap tolerance is tightened (the device at
+            # relgap 1e-10 ends 3e-7 from the default-tolerance fixture, at THIS point: tests/test_parity_gpu.py)
+            out["highs_x"] = [float(v) for v in rh.x]
+            hh = taps_of(rh.x, n)
+            out["highs_h_re"] = [float(v) for v in hh.real]
+            out["highs_h_im"] = [float(v) for v in hh.imag]
             probe("oracle -> HiGHS", dx)
             for s in (0.1, 0.01):
                 probe("oracle -> HiGHS x %g" % s, dx * s)

@@ -49,6 +49,7 @@ def _run_sharded(fn, args, size, dense=0, grid_m=0):
         opts = mbfir.make_opts(shard_rank=rank, shard_size=size, dense_trig=dense, grid_m=grid_m)
         try:
             results[rank] = getattr(mbfir, fn)(*args, opts=opts, ctx=ctxs[rank], info=True)
+            results[rank][2]["_z"] = ctxs[rank].last_solution(results[rank][2]["n_unknowns"])      # the rank's conic solution
         except Exception as e:                      # noqa: BLE001
             results[rank] = e
             barrier.abort()
@@ -128,6 +129,25 @@ def test_row_sharded_solve_on_a_tiny_grid_where_shards_disagree_about_the_lattic
             assert relinf(h, h0) <= 1e-6 and np.array_equal(h, res[0][0])
 
 
+def _tap_tolerance(n, z_ref, z_other, h_ref):
+    """(relative ||dx||, tap tolerance it supports, measured amplification): finite differences of fmp2 (the device's own,
+    mbfir.test_specfact) at z_ref along eight random directions whose size is the achieved ||z_other - z_ref||; the tolerance is
+    north_star's 1e-6 when the amplification allows it, else 3 x the largest tap change those perturbations produced."""
+    m = 2 * n - 1
+    x0 = np.asarray(z_ref)[:m]
+    dx = np.abs(np.asarray(z_other)[:m] - x0).max()
+    dx_rel = dx / np.abs(x0).max()
+    if dx == 0.0:
+        return 0.0, 1e-6, 0.0
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(8):
+        v = rng.standard_normal(m)
+        v *= dx / np.abs(v).max()
+        worst = max(worst, relinf(mbfir.test_specfact(x0 + v, n), h_ref))
+    return dx_rel, max(1e-6, 3.0 * worst), worst / dx_rel
+
+
 def test_config5_row_sharded_at_full_size_in_loop_back():
     """BASELINE config 5 AT SIZE in its row-sharded form (n=2048 taps, 131072 grid points, N=4096 unknowns), two
     contexts on one GPU with the loop-back all-reduce: the same verdict, objective and taps as the unsharded solve, the
@@ -149,9 +169,13 @@ def test_config5_row_sharded_at_full_size_in_loop_back():
         assert abs(info["pcost"] - i0["pcost"]) <= 1e-8 * max(1.0, abs(i0["pcost"]))
         assert info["pres"] <= 1e-8 and info["dres"] <= 1e-8 and (info["gap"] <= 1e-10 or info["relgap"] <= 1e-8)
         assert np.array_equal(h, res[0][0])                       # every rank returns the same taps, bit for bit
-        # the taps are the minimum-phase factor of a spectrum whose stop bands sit 1e-10 deep (fir_ap_cvx.m:264-304): two
-        # solves that agree to 1e-8 in the objective differ by ~1e-3 in the taps at this size (measured 1.5e-3)
-        assert relinf(h, h0) <= 5e-3
+        # The taps are the minimum-phase factor of a spectrum whose stop bands sit 1e-10 deep (fir_ap_cvx.m:264-304): fmp2
+        # amplifies a difference in x by 1e5 ... 1e6 at this size.  VERDICT r3 item 7: no bare literal -- the taps are held at
+        # what the ACHIEVED ||dx|| (sharded vs unsharded solution) supports, with the amplification measured here, at this
+        # optimum, by finite differences through the device's own fmp2 along eight random directions of that size.
+        dx_rel, tap_tol, amp = _tap_tolerance(n, z0, info["_z"], h0)
+        assert relinf(h, h0) <= tap_tol, (relinf(h, h0), dx_rel, amp, tap_tol)
+        assert tap_tol <= 2e-2, (dx_rel, amp, tap_tol)            # (and the two solutions are close enough for that to mean something)
         assert abs(info["iters"] - i0["iters"]) <= 2
         assert 0 < info["collectives"] <= 40 * (info["iters"] + 1)
     assert sum(i["n_freq"] for _, _, i in res) == m + 10

@@ -21,3 +21,8 @@ for label, kw in (("default tolerances", {}), ("abstol 1e-12 reltol 1e-10", dict
         dhr = np.abs(h - hg).max() / np.abs(hg).max() if st == "Solved" else float("nan")
         print("%-40s %s %s %3d it relgap %.1e  dx_rel %.2e  dh_rel %.2e  (amplification %.2e; worst-case measured %.2e -> supports %.1e)" % (
             label, "dense  " if dense else "lattice", st, info["iters"], info["relgap"], dxr, dhr, dhr / dxr, s["amplification_max"], s["amplification_max"] * dxr), flush=True)
+        if "highs_x" in s:
+            xh = np.array(s["highs_x"]); hh = np.array(s["highs_h_re"]) + 1j * np.array(s["highs_h_im"])
+            dxh = np.abs(z[:2 * n - 1] - xh[:2 * n - 1]).max() / np.abs(xh[:2 * n - 1]).max()
+            dhh = np.abs(h - hh).max() / np.abs(hh).max()
+            print("%-40s         against HiGHS's optimum: dx_rel %.2e  dh_rel %.2e  (supports %.1e)" % ("", dxh, dhh, s["amplification_max"] * dxh), flush=True)
