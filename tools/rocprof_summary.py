@@ -10,7 +10,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r03")
+ROUND = os.environ.get("MBFIR_ROUND", "r04")
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.environ.get("MBFIR_PROFILE_DST", os.path.join(ROOT, "profiles"))
 
 
@@ -63,17 +64,18 @@ def counter_sums(d):
 def main():
     os.makedirs(DST, exist_ok=True)
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    for d, out in (("bench_trace", "r03_bench_kernel_stats.csv"), ("unit_trace", "r03_unit16_kernel_stats.csv"),
-                   ("unit8_trace", "r03_unit8_kernel_stats.csv"), ("dense_trace", "r03_dense_kernel_stats.csv")):
+    for d, out in (("bench_trace", ROUND + "_bench_kernel_stats.csv"), ("unit_trace", ROUND + "_unit16_kernel_stats.csv"),
+                   ("unit8_trace", ROUND + "_unit8_kernel_stats.csv"), ("dense_trace", ROUND + "_dense_kernel_stats.csv"),
+                   ("hetero_trace", ROUND + "_hetero64_kernel_stats.csv"), ("c3_trace", ROUND + "_c3_batch8_kernel_stats.csv")):
         kernel_stats(d, out)
     if os.path.exists(os.path.join(SRC, "bench.json")):
-        with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, "r03_bench.json"), "w") as out:
+        with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, ROUND + "_bench.json"), "w") as out:
             out.write(fh.read())
     report = {"commit": commit}
     for tag, lanes in (("unit", 16), ("dense", 1)):
         busy, insts = counter_sums(tag + "_pmc_busy"), counter_sums(tag + "_pmc_insts")
         fetch, write = counter_sums(tag + "_pmc_fetch"), counter_sums(tag + "_pmc_write")
-        with open(os.path.join(DST, "r03_pmc_mfma_%s.csv" % tag), "w") as fh:
+        with open(os.path.join(DST, ROUND + "_pmc_mfma_%s.csv" % tag), "w") as fh:
             fh.write("kernel,calls,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,GRBM_GUI_ACTIVE,mfma_busy_over_sq_busy,"
                      "SQ_INSTS_VALU_MFMA_MOPS_F64,SQ_INSTS_VALU_MFMA_F64,SQ_INSTS_VALU,FETCH_SIZE_per_launch,WRITE_SIZE_per_launch\n")
             for k in sorted(busy, key=lambda kk: -busy[kk].get("SQ_BUSY_CYCLES", 0)):
@@ -93,7 +95,7 @@ def finalize(dst, commit):
     (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 1024)."""
     report = {"commit": commit}
     for tag, kern, key, lanes in (("unit", "k_chol_dag", "k_chol", 16), ("dense", "k_gram", "k_gram", 1)):
-        path = os.path.join(dst, "r03_pmc_mfma_%s.csv" % tag)
+        path = os.path.join(dst, ROUND + "_pmc_mfma_%s.csv" % tag)
         if not os.path.exists(path):
             continue
         with open(path) as fh:
@@ -112,7 +114,7 @@ def finalize(dst, commit):
                     if key == "k_chol":
                         report["lanes"] = lanes
                     break
-    with open(os.path.join(dst, "r03_pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(dst, ROUND + "_pmc_traffic.json"), "w") as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report, indent=1))
 
@@ -121,9 +123,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "finalize":
         # local step: copy the box's summaries (gpurun_out/r03_profiles) into profiles/ and stamp the commit
         import shutil
-        src = os.path.join(ROOT, "gpurun_out", "r03_profiles")
+        src = os.path.join(ROOT, "gpurun_out", ROUND + "_profiles")
         dst = os.path.join(ROOT, "profiles")
-        for f in glob.glob(os.path.join(src, "r03_*")):
+        for f in glob.glob(os.path.join(src, ROUND + "_*")):
             shutil.copy(f, dst)
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         finalize(dst, commit)
