@@ -192,6 +192,8 @@ void mbfir_program_dims(const mbfir_program* p, int* dims);
 void mbfir_program_trig(const mbfir_program* p, double* w, int* col_kind, double* col_tau,
                         double* col_scale, int* pcol, double* psign, double* c);
 /* per row: freq (or -1), col (or -1), alpha, beta, ey[3], h                                     */
+/* rep[r] = 1 for the rows a row-sharded solve holds on EVERY rank (rows / cones without a frequency, the big cone): R ints */
+void mbfir_program_replicated(const mbfir_program* p, int* rep);
 void mbfir_program_rows(const mbfir_program* p, int* freq, int* col, double* alpha, double* beta,
                         double* ey, double* h);
 

@@ -106,6 +106,7 @@ SYMBOLS = {
     "mbfir_program_dims": (None, [C.c_void_p, _ip]),
     "mbfir_program_trig": (None, [C.c_void_p, _dp, _ip, _dp, _dp, _ip, _dp, _dp]),
     "mbfir_program_rows": (None, [C.c_void_p, _ip, _ip, _dp, _dp, _dp, _dp]),
+    "mbfir_program_replicated": (None, [C.c_void_p, _ip]),
     "mbfir_test_gram": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_chol": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "mbfir_test_chol_lanes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp]),
@@ -580,11 +581,13 @@ def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None, rows=
         al, be, ey, h = np.zeros(R), np.zeros(R), np.zeros((R, 3)), np.zeros(R)
         lib.mbfir_program_rows(out, freq.ctypes.data_as(_ip), col.ctypes.data_as(_ip), _ptr(al), _ptr(be),
                                _ptr(ey), _ptr(h))
+        rep = np.zeros(R, dtype=np.int32)
+        lib.mbfir_program_replicated(out, rep.ctypes.data_as(_ip))
     finally:
         lib.mbfir_program_free(out)
     if rows is not None:
         rows = np.asarray(rows, dtype=np.int64)
-        freq, col, al, be, ey, h = freq[rows], col[rows], al[rows], be[rows], ey[rows], h[rows]
+        freq, col, al, be, ey, h, rep = freq[rows], col[rows], al[rows], be[rows], ey[rows], h[rows], rep[rows]
         used, inv = np.unique(freq[freq >= 0], return_inverse=True)
         wsub = w[used]
         fmap = np.full(len(freq), -1, dtype=np.int64)
@@ -600,7 +603,7 @@ def assemble_dense(which, n, f, a, d, params=(0.0,), grid_m=0, shard=None, rows=
     idr = np.nonzero(col >= 0)[0]
     G[idr, col[idr]] += al[idr]
     G[:, Nt:] = ey[:, :Ne]
-    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad, freq=freq, R=R)
+    return 0, dict(c=c, G=G, h=h, l=l, nq3=nq3, big=big, w=w, Mf=Mf, Nt=Nt, Ne=Ne, quad=quad, freq=freq, R=R, rep=rep)
 
 
 # ---- device kernel test hooks --------------------------------------------------------------------

@@ -76,4 +76,9 @@ void mbfir_program_rows(const mbfir_program* p, int* freq, int* col, double* alp
     std::memcpy(h, P.h.data(), sizeof(double) * P.R);
 }
 
+void mbfir_program_replicated(const mbfir_program* p, int* rep) {
+    const std::vector<int> r = replicated_rows(p->P);
+    std::memcpy(rep, r.data(), sizeof(int) * r.size());
+}
+
 }  // extern "C"

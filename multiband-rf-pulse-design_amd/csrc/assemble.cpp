@@ -363,6 +363,20 @@ int assemble_qprog_phs(int n, int nband, const double* f, const double* ac_re, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// 1 for the rows that a row-sharded solve REPLICATES on every rank: LP rows without a frequency, the rows of Q3 cones none of
+// whose rows has one, the big cone.  (Sums over the rows count them on rank 0 only.)
+std::vector<int> replicated_rows(const TrigProgram& Q) {
+    std::vector<int> rep(Q.R, 0);
+    for (int r = 0; r < Q.l; ++r) rep[r] = Q.freq[r] < 0 ? 1 : 0;
+    for (int c = 0; c < Q.nq3; ++c) {
+        const int r0 = Q.l + 3 * c;
+        const int v = (Q.freq[r0] < 0 && Q.freq[r0 + 1] < 0 && Q.freq[r0 + 2] < 0) ? 1 : 0;
+        rep[r0] = rep[r0 + 1] = rep[r0 + 2] = v;
+    }
+    for (int r = Q.l + 3 * Q.nq3; r < Q.R; ++r) rep[r] = 1;
+    return rep;
+}
+
 TrigProgram shard_program(const TrigProgram& Q, int rank, int size) {
     if (size <= 1) return Q;
     TrigProgram P;
@@ -373,22 +387,26 @@ TrigProgram shard_program(const TrigProgram& Q, int rank, int size) {
     for (int i = 0; i < Q.Mf; ++i)
         if (i % size == rank) { fmap[i] = int(P.w.size()); P.w.push_back(Q.w[i]); }
     P.Mf = int(P.w.size());
-    auto owner_of_freq = [&](int f) { return f < 0 ? 0 : f % size; };
+    // rows / cones with a frequency go to the rank that holds it; those WITHOUT one (identity rows, spike / per-tap cones, the
+    // big cone) are REPLICATED on every rank (round 4): x and y are replicated, so every rank computes them identically, holds
+    // their scaling and can assemble and factorise the whole normal matrix itself; their contributions to sums over the rows
+    // are counted on rank 0 only (DProg::rep / own in solver.hip)
+    auto mine = [&](int f) { return f < 0 || f % size == rank; };
     auto copy_row = [&](int r) {
         int f = Q.freq[r];
         P.add_row(f < 0 ? -1 : fmap[f], Q.col[r], Q.alpha[r], Q.beta[r], Q.ey[3 * r], Q.ey[3 * r + 1], Q.ey[3 * r + 2], Q.h[r]);
     };
     for (int r = 0; r < Q.l; ++r)
-        if (owner_of_freq(Q.freq[r]) == rank) copy_row(r);
+        if (mine(Q.freq[r])) copy_row(r);
     P.l = int(P.h.size());
     for (int c = 0; c < Q.nq3; ++c) {
         int r0 = Q.l + 3 * c, f = -1;
         for (int a = 0; a < 3; ++a) if (Q.freq[r0 + a] >= 0) f = Q.freq[r0 + a];
-        if (owner_of_freq(f) != rank) continue;
+        if (!mine(f)) continue;
         for (int a = 0; a < 3; ++a) copy_row(r0 + a);
         P.nq3++;
     }
-    if (Q.big && rank == 0) {
+    if (Q.big) {
         for (int r = Q.l + 3 * Q.nq3; r < Q.R; ++r) copy_row(r);
         P.big = Q.big;
     }

@@ -54,9 +54,11 @@ struct TrigProgram {
 // Row sharding for one process per GPU: rank r keeps the frequencies i with
 // i % size == r (interleaved, so every rank gets the same band/transition mix) together with every
 // row / cone attached to them; rows and cones with no frequency (identity rows, spike / per-tap
-// cones, the big cone) all go to rank 0.  x and y stay replicated.  The union of the shards is the
-// original program, no row appears twice.
+// cones, the big cone) are REPLICATED on every rank (x and y are replicated, so every rank computes
+// them identically and can factorise the whole normal matrix itself); sums over the rows count them
+// on rank 0 only.  The union of the shards' frequency rows is the original program's, none appears twice.
 TrigProgram shard_program(const TrigProgram& Q, int rank, int size);
+std::vector<int> replicated_rows(const TrigProgram& Q);     // 1: the row is one of those a row-sharded solve holds on every rank
 
 // Return 0 ok, 3 early-fail (reference returns 'Failed' before solving), -1 argument error.
 int assemble_ap(int n, int nband, const double* f, const double* a, const double* d,

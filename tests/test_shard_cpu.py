@@ -33,21 +33,27 @@ def test_shards_partition_the_rows(name, size):
     rows = 0
     cones = 0
     freqs = 0
+    nrep = int(full["rep"].sum())
+    rep_cones = int(full["rep"][:full["l"]].sum()) + int(full["rep"][full["l"]:full["l"] + 3 * full["nq3"]].sum()) // 3 + (1 if full["big"] else 0)
     for r in range(size):
         rc, S = mbfir.assemble_dense(WHICH[fn], args[0], args[1], args[2], args[3], _params(fn, args), shard=(r, size))
         assert rc == 0
         assert np.array_equal(S["c"], full["c"])               # x, y (and c) are replicated
-        HtH += S["G"].T @ S["G"]
-        gth += S["G"].T @ S["h"]
-        rows += S["G"].shape[0]
-        cones += S["l"] + S["nq3"] + (1 if S["big"] else 0)
+        # rows / cones WITHOUT a frequency (identity rows, spike / per-tap cones, the big cone) are replicated on every rank --
+        # the same rows, in the same order -- so that every rank can assemble and factorise the whole normal matrix (round 4);
+        # sums over the rows count them once (on rank 0)
+        own = np.ones(S["G"].shape[0]) if r == 0 else 1.0 - S["rep"]
+        assert int(S["rep"].sum()) == nrep and S["big"] == full["big"]
+        assert np.array_equal(S["G"][S["rep"] == 1], full["G"][full["rep"] == 1]) and np.array_equal(S["h"][S["rep"] == 1], full["h"][full["rep"] == 1])
+        HtH += S["G"].T @ (own[:, None] * S["G"])
+        gth += S["G"].T @ (own * S["h"])
+        rows += int(own.sum())
+        cones += S["l"] + S["nq3"] + (1 if S["big"] else 0) - (rep_cones if r > 0 else 0)
         freqs += S["Mf"]
-        if r > 0:
-            assert S["big"] == 0 and np.all(S["freq"] >= 0) or S["nq3"] > 0      # frequency-less rows live on rank 0
         assert abs(S["Mf"] - full["Mf"] / size) <= 1                                # balanced interleave
     assert rows == full["G"].shape[0] and freqs == full["Mf"]
     assert cones == full["l"] + full["nq3"] + (1 if full["big"] else 0)
-    # the sum over shards of G'G and G'h is the full one: what the per-iteration all-reduce relies on
+    # the sum over shards of G'G and G'h (replicated rows counted once) is the full one: what the per-iteration all-reduce relies on
     assert np.abs(HtH - full["G"].T @ full["G"]).max() <= 1e-10 * np.abs(HtH).max()
     assert np.abs(gth - full["G"].T @ full["h"]).max() <= 1e-10 * max(1.0, np.abs(gth).max())
 
@@ -79,6 +85,8 @@ def _worker(rank, size, port, name, q):
     fn, args = CS[name]
     rc, S = mb.assemble_dense(WH[fn], args[0], args[1], args[2], args[3], _params(fn, args), shard=(rank, size))
     d = 1.0 / (1.0 + np.arange(S["G"].shape[0]) % 7)             # some positive row weights
+    if rank > 0:
+        d = d * (1.0 - S["rep"])                                 # replicated rows count on rank 0 only
     H = np.ascontiguousarray(S["G"].T @ (d[:, None] * S["G"]))   # this rank's share of G' D G
     g = np.ascontiguousarray(S["G"].T @ (d * S["h"]))
     m = np.array([float(rank), -float(rank)])
@@ -113,6 +121,8 @@ def test_allreduce_hook_world_size_2_gloo():
     for r in range(size):
         rc, S = mbfir.assemble_dense(WHICH[fn], args[0], args[1], args[2], args[3], _params(fn, args), shard=(r, size))
         d = 1.0 / (1.0 + np.arange(S["G"].shape[0]) % 7)
+        if r > 0:
+            d = d * (1.0 - S["rep"])
         Hexp += S["G"].T @ (d[:, None] * S["G"])
         gexp += S["G"].T @ (d * S["h"])
     for rank, H, g, m in out:
