@@ -168,6 +168,12 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
         };
         auto wants_retry = [&]() { return status_to_rc(st) == MBFIR_NUMERICAL || st == ST_OPTIMAL_INACCURATE; };
         if (wants_retry() && so.shard_size <= 1 && !(so.ddkkt_theta > 0) && !(opts && opts->ddkkt < 0)) retry(false);
+        // the extended-precision retry does not exist row-sharded (its double-double factorisation works on the whole normal
+        // matrix of ONE context): the verdict stands, with the reason on record for the caller
+        if (wants_retry() && so.shard_size > 1)
+            ctx->err = st == ST_OPTIMAL_INACCURATE
+                           ? "row-sharded solve met the reduced tolerances only ('Inaccurate/Solved'); the extended-precision retry runs unsharded only"
+                           : "row-sharded solve ended 'numerical'; the extended-precision retry (opts.ddkkt) runs unsharded only -- solve this design on one GPU";
         if (wants_retry() && si.lattice && !so.dense_trig && so.shard_size <= 1 && (double)P.Mf * P.N() <= 6e8) retry(true);
         // fir_ap_cvx extracts its taps on the device from the solution the LAST solve left there; after a retry the
         // winner may be an earlier attempt: put the returned solution there

@@ -126,6 +126,10 @@ struct DProg {
     const int *f_ptr, *f_rows;        // frequency -> rows
     const int *c_ptr, *c_rows;        // column   -> identity rows
     const int *yrows; int nyrows;     // rows with a non-zero ey
+    // Row-sharded solves: rep[r] = 1 for the rows every rank holds (no frequency: identity rows, spike / per-tap cones, the big
+    // cone; program.h); own = 1 on the rank whose copy of them counts in the sums over the rows (rank 0; 1 when not sharded)
+    const int* rep; int own;
+    __device__ __forceinline__ double row_weight(int r) const { return (own || !rep[r]) ? 1.0 : 0.0; }
     // Lattice ("matrix-free") mode: every trig column is scale * cos|sin(w (tmin + m)) with m on an
     // integer lattice 0..D1-1 and the frequency grid splits into chunks of equally spaced points, so
     // A1 is never formed: products with A1 / A1' and the Gram matrices A1' D A1 come from rotation
@@ -166,7 +170,7 @@ struct DProg {
     __device__ __forceinline__ void shift(size_t off) {
         sh(w, off); sh(col_tau, off); sh(col_scale, off); sh(psign, off); sh(c, off); sh(col_kind, off); sh(pcol, off);
         sh(freq, off); sh(col, off); sh(alpha, off); sh(beta, off); sh(ey, off); sh(h, off);
-        sh(f_ptr, off); sh(f_rows, off); sh(c_ptr, off); sh(c_rows, off); sh(yrows, off);
+        sh(f_ptr, off); sh(f_rows, off); sh(c_ptr, off); sh(c_rows, off); sh(yrows, off); sh(rep, off);
         sh(lat, off); sh(lat_col, off); sh(lat_qcol, off); sh(lat_scale, off); sh(lat_qscale, off);
         sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off); sh(fold_pos, off); sh(fold_neg, off); sh(wf, off);
         if (!seeds_shared) { sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off); }
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* 
                 double a = 0;
                 for (int q = tid; q < P.nyrows; q += GTC * GTG) {
                     const int r = P.yrows[q];
-                    a += P.ey[3 * r + e] * val[(long)v * P.Rp + r];
+                    a += P.row_weight(r) * (P.ey[3 * r + e] * val[(long)v * P.Rp + r]);      // (replicated rows: once over the ranks)
                 }
                 a = wave_sum(a);
                 __syncthreads();
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* 
 #pragma unroll
             for (int q = 0; q < GTG; ++q) { t1 += sh[v][q][c]; t2 += sh[NV + v][q][c]; }
             double g = t1 + (P.quad ? P.psign[j] * t2 : 0.0);
+            if (P.own)                                               // identity rows are replicated rows: summed over the ranks once
             for (int q = P.c_ptr[j]; q < P.c_ptr[j + 1]; ++q) {
                 const int r = P.c_rows[q];
                 g += P.alpha[r] * val[(long)v * P.Rp + r];
@@ -910,7 +915,8 @@ __global__ __launch_bounds__(256) void k_resid_rows(DProg P, const double* __res
         rz[r] = res;
         bz2[r] = hv;
         bz2[P.Rp + r] = sv - res;
-        v[0] = res * res; v[1] = sv * zv; v[2] = hv * zv; v[3] = (gx + sv) * (gx + sv);
+        const double wr = P.row_weight(r);
+        v[0] = wr * (res * res); v[1] = wr * (sv * zv); v[2] = wr * (hv * zv); v[3] = wr * ((gx + sv) * (gx + sv));
     }
     block_partials<4>(v, part, false);
 }
@@ -1107,12 +1113,14 @@ __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restric
         v[0] = P.h[t] * z1[t]; v[1] = P.h[t] * z2[t];
         double wz = wl[t] * z1[t];
         v[2] = wz * wz;
+        if (!P.own && P.rep[t]) v[0] = v[1] = v[2] = 0.0;
     } else if (t < P.l + P.nq3) {
         int c = t - P.l, r = P.l + 3 * c;
         Soc3 W = load_w3(w3, c);
         double zz[3] = {z1[r], z1[r + 1], z1[r + 2]}, wz[3];
         soc3_apply(W, zz, wz, false);
         for (int a = 0; a < 3; ++a) { v[0] += P.h[r + a] * z1[r + a]; v[1] += P.h[r + a] * z2[r + a]; v[2] += wz[a] * wz[a]; }
+        if (!P.own && P.rep[r]) v[0] = v[1] = v[2] = 0.0;
     }
     block_partials<3>(v, part, false);
 }
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __rest
     double b = big_dot(P.h + ob, z2 + ob, P.big, sh);
     big_apply(P.big, wbb, Sc[S_ETAB], z1 + ob, scratch, false, sh);
     double c = big_dot(scratch, scratch, P.big, sh);
-    if (threadIdx.x == 0) { part_row[0] = a; part_row[1] = b; part_row[2] = c; }
+    if (threadIdx.x == 0) { const double wo = P.own ? 1.0 : 0.0; part_row[0] = wo * a; part_row[1] = wo * b; part_row[2] = wo * c; }   // (the big cone is replicated)
 }
 
 // dtau for the affine (mode 0) or the combined (mode 1) direction.  One workgroup: the N-space dots
@@ -1568,13 +1576,17 @@ __global__ void k_assemble_H_lat(DProg P, const double* __restrict__ Mom, const 
     H[(long)j * P.np + k] = v;
 }
 // identity rows: thread j owns row j of H (and the mirrored border entries)
+// wsum: the result is summed over the ranks of a row-sharded solve afterwards (replicated rows then count on the owner only)
 __device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c);
+                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c, bool wsum);
 // yy_too: one more block at the end of the grid adds the y-y block (k_H_yy's work; 256 threads)
 __global__ __launch_bounds__(256) void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                                    double* __restrict__ H, const double* __restrict__ m3c, int yy_too) {
+                                                    double* __restrict__ H, const double* __restrict__ m3c, int yy_too, int summed) {
     LANES(P, dl, w3, H, m3c);
-    if (yy_too && blockIdx.x == gridDim.x - 1) { h_yy_block(P, dl, w3, H, (long)P.np, (long)P.Nt, m3c); return; }
+    // summed: the matrix is summed over the ranks afterwards (dense row-sharded path): the y-y block weights the replicated
+    // rows, and the identity rows -- all of them replicated -- are added by the owner only
+    if (yy_too && blockIdx.x == gridDim.x - 1) { h_yy_block(P, dl, w3, H, (long)P.np, (long)P.Nt, m3c, summed != 0); return; }
+    if (summed && !P.own) return;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.Nt) return;
     const long np = P.np;
@@ -1609,11 +1621,12 @@ __global__ __launch_bounds__(256) void k_H_identity(DProg P, const double* __res
 // y-y block: sum over rows with a non-zero ey (LP rows and Q3 cones); one block
 // out[(base + e) * ld + base + f] += ... : (H, np, Nt), or a 3 x 3 scratch (ld 3, base 0) that the lead-factor mode all-reduces
 __device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restrict__ dl, const double* __restrict__ w3,
-                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
+                                           double* __restrict__ H, long ld, long base, const double* __restrict__ m3c, bool wsum) {
     __shared__ double sh[17];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = threadIdx.x; q < P.nyrows; q += blockDim.x) {
         int r = P.yrows[q];
+        if (wsum && !P.own && P.rep[r]) continue;            // summed over the ranks afterwards: replicated rows once
         if (r < P.l) {
             double d = dl[r];
             for (int e = 0; e < P.Ne; ++e)
@@ -1637,7 +1650,7 @@ __device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restr
 __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                                               double* __restrict__ H, long ld, long base, const double* __restrict__ m3c) {
     LANES(P, dl, w3, H, m3c);
-    h_yy_block(P, dl, w3, H, ld, base, m3c);
+    h_yy_block(P, dl, w3, H, ld, base, m3c, true);
 }
 __global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
     LANES(P, yy, H);
@@ -1678,11 +1691,11 @@ __global__ __launch_bounds__(256) void k_cone_resid(DProg P, const double* __res
     LANES(P, v, part);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     double a[2] = {-1e300, 0};
-    if (t < P.l) { a[0] = -v[t]; a[1] = v[t] * v[t]; }
+    if (t < P.l) { a[0] = -v[t]; a[1] = P.row_weight(t) * (v[t] * v[t]); }
     else if (t < P.l + P.nq3) {
         int r = P.l + 3 * (t - P.l);
         a[0] = sqrt(v[r + 1] * v[r + 1] + v[r + 2] * v[r + 2]) - v[r];
-        a[1] = v[r] * v[r] + v[r + 1] * v[r + 1] + v[r + 2] * v[r + 2];
+        a[1] = P.row_weight(r) * (v[r] * v[r] + v[r + 1] * v[r + 1] + v[r + 2] * v[r + 2]);
     }
     __shared__ double sh[17];
     double m = block_max(a[0], sh), s = block_sum(a[1], sh);
@@ -1693,7 +1706,7 @@ __global__ __launch_bounds__(1024) void k_big_cone_resid(DProg P, const double* 
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
     double n1 = big_dot(v + ob + 1, v + ob + 1, P.big - 1, sh);
-    if (threadIdx.x == 0) { part_row[0] = sqrt(n1) - v[ob]; part_row[1] = n1 + v[ob] * v[ob]; }
+    if (threadIdx.x == 0) { part_row[0] = sqrt(n1) - v[ob]; part_row[1] = P.own ? n1 + v[ob] * v[ob] : 0.0; }
 }
 // fold the cone-residual partials: RB[0] = max (distance outside), RB[1] = sum ||v||^2
 __global__ __launch_bounds__(256) void k_cone_fold(const double* __restrict__ part, int nb, double* __restrict__ RB, size_t lane_bytes, const int* lane_mask) {
@@ -2091,8 +2104,10 @@ struct Solver::Impl {
             default: throw HipError("atmulti: unsupported vector count");
         }
     }
+    // tail: that many scalars directly behind the NV * LDV entries of `out` ride in the same all-reduce (row-sharded solves: a
+    // scalar mailbox packed into the vector reduction that follows it -- one latency-bound collective less)
     template <int NV>
-    void apply_GT(const double* val, double* out) {
+    void apply_GT(const double* val, double* out, int tail = 0) {
         if (P.trig) {
             dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, P.cgrp)), b(256);
             const dim3 gf(cdiv(P.nfold, 256));
@@ -2109,7 +2124,7 @@ struct Solver::Impl {
             else hipLaunchKernelGGL((k_atmulti<NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
         }
         hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, P.cgrp) : nsplit_at, val, out);
-        allreduce(out, (long)NV * P.LDV, 0);              // sum the shards' G'v (N-space vectors are replicated)
+        allreduce(out, (long)NV * P.LDV + tail, 0);       // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
     void winv2(const double* in, const double* sub, double* out, int mode) {
@@ -2117,26 +2132,22 @@ struct Solver::Impl {
         if (P.big) hipLaunchKernelGGL(k_big_winv2<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, in, sub, out, mode);
     }
     // Row-sharded solves on the lattice path: the normal matrix is a linear function of ~100 KB of trigonometric
-    // moments, so the ranks all-reduce the MOMENTS, rank 0 alone assembles and factorises H (it also owns every
-    // non-frequency row) and shares each preconditioner application M'(M b) -- N doubles -- instead of every rank
-    // receiving H (np^2 doubles) and repeating the factorisation.  The other ranks wait in the collective meanwhile.
+    // moments, so the ranks all-reduce the MOMENTS (and the 3 x 3 y-y block); every rank holds the non-frequency rows
+    // (replicated, program.h) and their scaling, so EVERY rank assembles and factorises the same H itself (round 4;
+    // before, rank 0 alone did and shared each preconditioner application M'(M b) through a collective -- ~6 latency-bound
+    // all-reduces per iteration): the factors are bit-identical across the ranks (same moments, same deterministic
+    // assembly and factorisation), the solves with them are local.
     bool lead_factor() const { return shard_size > 1 && P.trig; }
     // out = M' M (rhs + rhs2)
     template <int NV>
     void hsolve(const double* rhs, double* out, const double* rhs2 = nullptr) {
-        if (!lead_factor() || shard_rank == 0) {
-            if (fused_hsolve) {
-                // one pass over the inverse factor (chol.hip k_hsolve); its partial vectors borrow the moment kernels'
-                // partial buffer, which is idle between a G'v product and the next
-                hsolve_launch(M, P.np, rhs, rhs2, out, partial, NV, P.LDV, st, nlanes, lane_bytes, P.mask);
-            } else {
-                trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2, nlanes, lane_bytes, P.mask);
-                trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st, nullptr, nlanes, lane_bytes, P.mask);
-            }
-        }
-        if (lead_factor()) {
-            if (shard_rank != 0) hipMemsetAsync(out, 0, sizeof(double) * NV * P.LDV, st);
-            allreduce(out, (long)NV * P.LDV, 0);
+        if (fused_hsolve) {
+            // one pass over the inverse factor (chol.hip k_hsolve); its partial vectors borrow the moment kernels'
+            // partial buffer, which is idle between a G'v product and the next
+            hsolve_launch(M, P.np, rhs, rhs2, out, partial, NV, P.LDV, st, nlanes, lane_bytes, P.mask);
+        } else {
+            trigemv_launch(M, P.np, 0, rhs, yN, NV, P.LDV, st, rhs2, nlanes, lane_bytes, P.mask);
+            trigemv_launch(Mt, P.np, 1, yN, out, NV, P.LDV, st, nullptr, nlanes, lane_bytes, P.mask);
         }
     }
     // [0 G'; G -W^2][dx; dz] = [bx; bz]; gdx = G dx.  The Cholesky solve is refined by `nsweep`
@@ -2245,6 +2256,7 @@ struct Solver::Impl {
     // ddk > 0: this iteration runs the extended-precision solve -- H_w from the capped weights (D.dlc, D.m3c),
     // then H = H_w + U'XU and its Cholesky factor in double-double
     void build_H(int ddk = 0) {
+        double* yy_sum = nullptr;
         const double* dlw = ddk > 0 ? D.dlc : dl;
         const double* m3c = ddk > 0 ? D.m3c : nullptr;
         const int nwv = P.quad ? 3 : 1, nvb = P.quad ? 2 * P.Ne : P.Ne;
@@ -2265,15 +2277,25 @@ struct Solver::Impl {
                 if (P.Ne > 0) moments_array(nvb, BB, P.seed_tau, P.D1, 0, MomB);
             }
             if (lead_factor()) {
+                // the 3 x 3 y-y block -- terms of the (sharded) frequency rows' rho / delta columns and of replicated rows, the
+                // latter counted on their owner -- is summed over the ranks too: in the tail of the moment buffer when the
+                // moments go in one piece (one collective for both), else in its own small all-reduce
+                yy_sum = nullptr;
                 if (momb == MomB) {
                     allreduce(Mom, 2L * nwv * P.LDM, 0);
                     if (P.Ne > 0) allreduce(MomB, 2L * nvb * P.LDM, 0);
                 } else {
-                    allreduce(Mom, 2L * (nwv + nvb) * P.LDM, 0);
+                    long cnt = 2L * (nwv + nvb) * P.LDM;
+                    if (P.Ne > 0 && cnt + 16 <= 18L * P.LDM) {
+                        yy_sum = Mom + cnt;
+                        hipMemsetAsync(yy_sum, 0, sizeof(double) * 9, st);
+                        if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, yy_sum, 3L, 0L, m3c);
+                        cnt += 9;
+                    }
+                    allreduce(Mom, cnt, 0);
                 }
             }
-            if (!lead_factor() || shard_rank == 0)
-                hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3((P.np / 64) * (P.np / 64 + 1) / 2, 16), nlanes), dim3(256), 0, st, P, Mom, momb, H, shard_rank == 0 ? 1.0 : 0.0);
+            hipLaunchKernelGGL(k_assemble_H_lat, lane_grid(dim3((P.np / 64) * (P.np / 64 + 1) / 2, 16), nlanes), dim3(256), 0, st, P, Mom, momb, H, 1.0);
             if (g1) hipEventRecord(g1, st);
         } else {
         // the dense Gram products, one lane after the other (a k_gram launch fills the chip by itself: 340 us at the
@@ -2293,18 +2315,24 @@ struct Solver::Impl {
         }
         hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         }
-        const bool mine = !lead_factor() || shard_rank == 0;     // lead mode: only rank 0 holds H
+        const bool summed = shard_size > 1 && !lead_factor();     // dense row-sharded path: H is summed over the ranks below
         if (lead_factor() && P.Ne > 0) {
-            // the y-y block also gets terms from frequency rows (rho, delta columns), which live on every rank
-            hipMemsetAsync(RB, 0, sizeof(double) * 9, st);
-            if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, RB, 3L, 0L, m3c);
-            allreduce(RB, 9, 0);
-            if (mine) hipLaunchKernelGGL(k_H_yy_add, lane_grid(dim3(1), nlanes), dim3(16), 0, st, P, RB, H);
+            // (summed over the ranks -- with the moments above, or here -- then added by every rank to its own H)
+            const double* yy = yy_sum;
+            if (!yy) {
+                hipMemsetAsync(RB, 0, sizeof(double) * 9, st);
+                if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, RB, 3L, 0L, m3c);
+                allreduce(RB, 9, 0);
+                yy = RB;
+            }
+            hipLaunchKernelGGL(k_H_yy_add, lane_grid(dim3(1), nlanes), dim3(16), 0, st, P, yy, H);
         }
-        if (mine) {
+        {
+            // identity rows (all of them replicated rows): every rank adds them to its own H; where H is summed over the ranks
+            // afterwards (dense path) the owner alone does, and the y-y block (last block of the grid) weights the replicated rows
             const int yy_too = (!lead_factor() && P.Ne > 0 && P.nyrows > 0) ? 1 : 0;
-            hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256) + yy_too), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c, yy_too);
-            if (P.big) {
+            hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256) + yy_too), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c, yy_too, summed ? 1 : 0);
+            if (P.big && (!summed || shard_rank == 0)) {
                 memset_lanes(qv, sizeof(double) * 3 * P.LDV);
                 if (ddk > 0) {
                     hipLaunchKernelGGL(k_big_q_dd, lane_grid(dim3(cdiv(P.big, 256)), nlanes), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV);
@@ -2323,17 +2351,9 @@ struct Solver::Impl {
             dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
             dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st, ddinv);
             if (c1) hipEventRecord(c1, st);
-        } else if (mine) {
+        } else {
             // (with the one-pass M'(M b) nobody reads the transpose: it is not written)
             chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, c1, nlanes, lane_bytes, P.mask);
-        } else {
-            if (c0) hipEventRecord(c0, st);
-            if (c1) hipEventRecord(c1, st);
-        }
-        if (lead_factor()) {                                      // everybody needs the pivot-replacement count (wall exit)
-            hipLaunchKernelGGL(k_flag_share, lane_grid(dim3(1), nlanes), dim3(1), 0, st, flag, RB + 9, shard_rank == 0 ? 1 : 0);
-            allreduce(RB + 9, 1, 0);
-            hipLaunchKernelGGL(k_flag_share, lane_grid(dim3(1), nlanes), dim3(1), 0, st, flag, RB + 9, 2);
         }
     }
     // events are recorded as (gram begin, gram end, chol begin, chol end) per build_H
@@ -2439,7 +2459,7 @@ static double now_ms() {
 struct LaneHost {
     const TrigProgram* Q = nullptr;
     TrigProgram local;                       // the row shard (sharded solves have one lane)
-    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows;
+    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows, rep;
     LatticeInfo Lt;
     double nrm_h = 1, nrm_c = 1, degree = 0;
     // IPM state
@@ -2477,7 +2497,7 @@ static void index_structures(const TrigProgram& Q, LaneHost& L) {
 // front end can compute them in its parallel assembly threads and the solve does not repeat them
 struct LanePrep {
     bool fold = true, dense = false;
-    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows;
+    std::vector<int> f_ptr, f_rows, c_ptr, c_rows, yrows, rep;
     LatticeInfo Lt;
 };
 static std::shared_ptr<LanePrep> lane_prep(const TrigProgram& Q, const SolveOpts& o) {
@@ -2491,6 +2511,7 @@ static std::shared_ptr<LanePrep> lane_prep(const TrigProgram& Q, const SolveOpts
     LaneHost L;
     index_structures(Q, L);
     pr->f_ptr.swap(L.f_ptr); pr->f_rows.swap(L.f_rows); pr->c_ptr.swap(L.c_ptr); pr->c_rows.swap(L.c_rows); pr->yrows.swap(L.yrows);
+    pr->rep = replicated_rows(Q);
     if (!dense) pr->Lt = analyse_lattice(Q, fold);
     Q.prep = pr;
     return pr;
@@ -2596,7 +2617,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         // on its own so that the lattice operator and those rows see the same grid to the old 2 ulp)
         {
             const std::shared_ptr<LanePrep> pr = lane_prep(*L.Q, o);
-            L.f_ptr = pr->f_ptr; L.f_rows = pr->f_rows; L.c_ptr = pr->c_ptr; L.c_rows = pr->c_rows; L.yrows = pr->yrows;
+            L.f_ptr = pr->f_ptr; L.f_rows = pr->f_rows; L.c_ptr = pr->c_ptr; L.c_rows = pr->c_rows; L.yrows = pr->yrows; L.rep = pr->rep;
             L.Lt = pr->Lt;
         }
         L.nsweep = o.refine;
@@ -2669,6 +2690,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
     P.nyrows = nyrows_max;
     P.mask = nullptr; P.lane_bytes = 0; P.dims = nullptr;
+    P.own = S.shard_rank == 0 ? 1 : 0;                        // (1 when not sharded)
     if (hetero) {
         for (int b = 0; b < nlanes; ++b) {
             const TrigProgram& Qb = *LH[b].Q;
@@ -2700,7 +2722,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.c = UPQ(double, c); P.freq = UPQ(int, freq); P.col = UPQ(int, col); P.alpha = UPQ(double, alpha);
     P.beta = UPQ(double, beta); P.ey = UPQ(double, ey); P.h = UPQ(double, h);
     P.f_ptr = UPL(int, f_ptr); P.f_rows = UPL(int, f_rows); P.c_ptr = UPL(int, c_ptr); P.c_rows = UPL(int, c_rows);
-    P.yrows = UPL(int, yrows);
+    P.yrows = UPL(int, yrows); P.rep = UPL(int, rep);
     S.tile_ij = S.upload<int>([&](int) -> const std::vector<int>& { return tiles; });
     P.lat = UPL(int, Lt.lat); P.lat_col = UPL(int, Lt.lat_col); P.lat_qcol = UPL(int, Lt.lat_qcol);
     P.lat_scale = UPL(double, Lt.lat_scale); P.lat_qscale = UPL(double, Lt.lat_qscale);
@@ -2724,7 +2746,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
     S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.pN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
-    S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV);
+    S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV + 16);        /* + the mailbox of the residual sums, packed behind G'z */
     S.bxc = ar.get<double>(LDV); S.dxc = ar.get<double>(LDV); S.qv = ar.get<double>(3 * LDV);
     S.XX = ar.get<double>(4 * LDV); S.TT = ar.get<double>(6 * LDV); S.TT2 = ar.get<double>(4 * LDV); S.xout = ar.get<double>(LDV);
     S.s = ar.get<double>(Rp); S.z = ar.get<double>(Rp); S.lam = ar.get<double>(Rp); S.dl = ar.get<double>(Rp);
@@ -2833,20 +2855,19 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     double host_issue_ms = 0, host_wait_ms = 0, t_issue0 = trace_host ? now_ms() : 0.0;
     for (it = 0; it <= o.max_iter; ++it) {
         // residuals
+        // row-sharded: the four row sums (||rz||^2, s'z, h'z, ||Gx + s||^2) are folded into a mailbox directly behind G'z and
+        // summed over the ranks by the same all-reduce (they do not depend on G'z)
+        double* rmail = sharded ? S.GTz + LDV : S.RB;
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
             hipLaunchKernelGGL(k_trig_eval<1>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, S.x, S.UU);
-            S.apply_GT<1>(S.z, S.GTz);
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
         } else {
             S.apply_G<1>(S.x, S.Gx);
-            S.apply_GT<1>(S.z, S.GTz);
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
         }
-        if (sharded) {
-            hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, 0, (const int*)nullptr);
-            S.allreduce(S.RB, 4, 0);
-        }
-        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, S.RB, sharded ? 1 : 2, (const int*)S.flag);
+        if (sharded) hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, rmail, 0, (const int*)nullptr);
+        S.apply_GT<1>(S.z, S.GTz, sharded ? 4 : 0);
+        hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, rmail, sharded ? 1 : 2, (const int*)S.flag);
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
         const double t_sync0 = trace_host ? now_ms() : 0.0;
         MBFIR_HIP(hipStreamSynchronize(st));

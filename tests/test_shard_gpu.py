@@ -181,6 +181,8 @@ def test_config5_row_sharded_at_full_size_in_loop_back():
         # 1.5e-3 (round 3 asserted the bare literal 5e-3, which the conditioning does not support).  Not vacuous:
         assert tap_tol < 0.5 and dx_rel <= 1e-6, (dx_rel, amp, tap_tol)
         assert abs(info["iters"] - i0["iters"]) <= 2
-        assert 0 < info["collectives"] <= 40 * (info["iters"] + 1)
+        # round 4: every rank factorises (non-frequency rows replicated), the y-y block rides with the moments and the residual
+        # sums with G'z: 10 + 2 x (refinement sweeps per solve) collectives per iteration -- VERDICT r3's bar is <= 14
+        assert 0 < info["collectives"] <= 14 * (info["iters"] + 1), (info["collectives"], info["iters"])
     assert sum(i["n_freq"] for _, _, i in res) == m + 10
     assert abs(res[0][2]["pcost"] - (np.asarray(mbfir.assemble_dense(0, n, f, a, d, (0.1, 1e-3), m, rows=[0])[1]["c"]) @ z0)) <= 1e-9
