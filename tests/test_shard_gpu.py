@@ -93,7 +93,10 @@ def test_row_sharded_dense_path_all_reduces_the_normal_matrix(name):
     for h, s, info in res:
         assert s == s0 == "Solved" and info["lattice"] == 0 and relinf(h, h0) <= 1e-6
         assert np.array_equal(h, res[0][0])
-    assert sum(i["n_rows"] for _, _, i in res) == i0["n_rows"]
+    # the frequency rows partition; the rows without a frequency (identity rows, spike cones) are replicated on every rank
+    assert sum(i["n_freq"] for _, _, i in res) == i0["n_freq"]
+    nrep = res[0][2]["n_rows"] + res[1][2]["n_rows"] - i0["n_rows"]
+    assert 0 < nrep < i0["n_rows"] - 2 * i0["n_freq"] + 8
 
 
 def test_native_rccl_communicator_single_rank():
