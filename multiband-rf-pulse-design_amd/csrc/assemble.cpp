@@ -383,15 +383,39 @@ TrigProgram shard_program(const TrigProgram& Q, int rank, int size) {
     P.which = Q.which; P.n = Q.n; P.Nt = Q.Nt; P.Ne = Q.Ne; P.quad = Q.quad;
     P.col_kind = Q.col_kind; P.col_tau = Q.col_tau; P.col_scale = Q.col_scale; P.pcol = Q.pcol; P.psign = Q.psign;
     P.c = Q.c; P.nhalf = Q.nhalf; P.real_filter = Q.real_filter; P.odd_filter = Q.odd_filter;
+    // The frequencies are dealt out by FOLDED PAIRS (round 4): +w and -w share cos(w t) and differ in the sign of sin(w t), and
+    // the lattice kernels run one recurrence for both (solver.hip analyse_lattice) -- but only when both sit on the same rank;
+    // dealing single frequencies i % size put the partners on different ranks and doubled every rank's recurrence work.
+    // Entries of the list sorted by |w| -- a pair within 2 ulp of each other with opposite signs, or a single frequency (band
+    // edges, one-sided grids) -- go to the ranks in turn, so every rank gets the same band / transition mix.
+    std::vector<int> owner(Q.Mf, 0);
+    {
+        std::vector<int> order(Q.Mf);
+        for (int i = 0; i < Q.Mf; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(Q.w[a]) < std::fabs(Q.w[b]); });
+        double wmax = 1.0;
+        for (double w : Q.w) wmax = std::max(wmax, std::fabs(w));
+        const double tol = 2 * 2.2204460492503131e-16 * wmax;
+        int entry = 0;
+        for (int q = 0; q < Q.Mf; ++entry) {
+            const int i = order[q];
+            owner[i] = entry % size;
+            if (q + 1 < Q.Mf) {
+                const int j = order[q + 1];
+                if (std::fabs(Q.w[j]) - std::fabs(Q.w[i]) <= tol && (Q.w[i] < 0.0) != (Q.w[j] < 0.0)) { owner[j] = entry % size; q += 2; continue; }
+            }
+            q += 1;
+        }
+    }
     std::vector<int> fmap(Q.Mf, -1);
     for (int i = 0; i < Q.Mf; ++i)
-        if (i % size == rank) { fmap[i] = int(P.w.size()); P.w.push_back(Q.w[i]); }
+        if (owner[i] == rank) { fmap[i] = int(P.w.size()); P.w.push_back(Q.w[i]); }
     P.Mf = int(P.w.size());
     // rows / cones with a frequency go to the rank that holds it; those WITHOUT one (identity rows, spike / per-tap cones, the
     // big cone) are REPLICATED on every rank (round 4): x and y are replicated, so every rank computes them identically, holds
     // their scaling and can assemble and factorise the whole normal matrix itself; their contributions to sums over the rows
     // are counted on rank 0 only (DProg::rep / own in solver.hip)
-    auto mine = [&](int f) { return f < 0 || f % size == rank; };
+    auto mine = [&](int f) { return f < 0 || owner[f] == rank; };
     auto copy_row = [&](int r) {
         int f = Q.freq[r];
         P.add_row(f < 0 ? -1 : fmap[f], Q.col[r], Q.alpha[r], Q.beta[r], Q.ey[3 * r], Q.ey[3 * r + 1], Q.ey[3 * r + 2], Q.h[r]);
