@@ -1,0 +1,206 @@
+// Capacitance (saddle-point) form of the extended-precision KKT solve, plain double precision on the fp64 matrix cores
+// (round 4; oracle/conic_ipm.py factor_dd with ddkkt["form"] == "cap" is the same algorithm, step for step).
+//
+// The normal matrix of an iterate with nearly active cones is  H = H_w + U' X U : H_w from the CAPPED scaling (every eigenvalue
+// of W^-2 at most cap = 1e6 x the typical weight), U one row G'e per strong eigen-direction (k rows), X = diag(excess weights,
+// up to 1e16 x the typical one).  Round 2 / 3 accumulated and factorised H in double-double (ddlin.hip: fp64 VALU with
+// error-free transformations, 34 panel steps x 3 launches, 2.7 ms per factorisation at np = 1088).  Here the strong directions
+// stay what they are -- nearly-equality constraints --
+//        [ H_w   U'   ] [ dx   ]   [ rhs_w ]
+//        [ U   -X^-1  ] [ zeta ] = [   t   ]        zeta = X (U dx - t)
+// and the system is solved by block elimination on H_w: no number of the size of X ever meets one of the size of H_w, so double
+// precision is enough (measured in the oracle: BASELINE config 3's family, n = 384, 60 iterations -- the same count, the same
+// objective to 13 digits and the taps to 4e-8 of the double-double form):
+//        H_w = L L'  (the ordinary double-precision factorisation, chol.hip; M = L^-1)
+//        Yt  = U M'              (k x np)        Zt = Yt M = U H_w^-1     (k x np)
+//        S   = X^-1 + Yt Yt'     (k x k, factorised by the same chol.hip routine: k <= 1024 instead of a dd one of np)
+//        y = H_w^-1 rhs_w ;  zeta = S^-1 (U y - t) ;  dx = y - Zt' zeta
+// Kernels: one 64 x 64-tile fp64 MFMA product kernel in three modes (the two products with the triangular M touch only the tiles
+// of its lower triangle and mask the diagonal tile -- the storage above the diagonal of M is never written), and three small
+// vector kernels.
+#include "dev_common.h"
+
+namespace mbfir {
+
+namespace {
+constexpr int TB = 64, TLD = 66;
+
+// acc[a][b] += A(64 x 64 tile in As) * op(B tile in Bs): each of the 4 waves owns a 32 x 32 quadrant (2 x 2 MFMA blocks);
+// v_mfma_f64_16x16x4_f64 operand layout: a = A[i = lane % 16][k = lane / 16], b = B[k = lane / 16][j = lane % 16],
+// c[q] = C[4 (lane / 16) + q][lane % 16]
+template <bool TRANSB>
+__device__ __forceinline__ void mma_tile(const double (*As)[TLD], const double (*Bs)[TLD], v4d acc[2][2]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wi = wv >> 1, wj = wv & 1;
+#pragma unroll 4
+    for (int k0 = 0; k0 < TB; k0 += 4) {
+        const int k = k0 + (lane >> 4);
+        double af[2], bf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = As[wi * 32 + a * 16 + (lane & 15)][k];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = wj * 32 + b * 16 + (lane & 15);
+            bf[b] = TRANSB ? Bs[j][k] : Bs[k][j];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+}
+// 64 x 64 tile -> LDS (256 threads, 16-byte loads); keep: 0 everything, 1 the lower triangle (col <= row), 2 the upper
+// triangle of the TRANSPOSED view, i.e. entries with row >= col -- the same set; both triangular products keep col <= row of M
+template <int KEEP_LOWER>
+__device__ __forceinline__ void load_tile(double (*S)[TLD], const double* __restrict__ src, long ld) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u, r = e >> 5, c = 2 * (e & 31);
+        double2 t = *reinterpret_cast<const double2*>(src + (long)r * ld + c);
+        if (KEEP_LOWER) { if (c > r) t.x = 0.0; if (c + 1 > r) t.y = 0.0; }
+        *reinterpret_cast<double2*>(&S[r][c]) = t;
+    }
+}
+
+// MODE 0:  C = A B',  B = M lower-triangular (np x np):  C[r][i] = sum_{j <= i} A[r][j] M[i][j]        (Yt = U M')
+// MODE 1:  C = A B ,  B = M lower-triangular:            C[r][i] = sum_{j >= i} A[r][j] M[j][i]        (Zt = Yt M)
+// MODE 2:  C = A A' + diag (lower tiles only):           C[r][q] = sum_j A[r][j] A[q][j]               (S = Yt Yt' + X^-1)
+//          diag: 1 / X[r] for r < k, 1 for the padding rows r >= k (whose rows of A are zero)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int np, int ldc,
+                                                  const double* __restrict__ X, int k) {
+    __shared__ __attribute__((aligned(16))) double As[TB][TLD];
+    __shared__ __attribute__((aligned(16))) double Bs[TB][TLD];
+    int rb, cb;
+    if (MODE == 2) {                                          // lower tiles of the k x k result, one per block
+        int t = blockIdx.x;
+        rb = int((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((rb + 1) * (rb + 2) / 2 <= t) ++rb;
+        while (rb * (rb + 1) / 2 > t) --rb;
+        cb = t - rb * (rb + 1) / 2;
+    } else {
+        rb = blockIdx.y; cb = blockIdx.x;
+    }
+    const int nblk = np / TB;
+    const int j0 = MODE == 1 ? cb : 0, j1 = MODE == 0 ? cb + 1 : nblk;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int jb = j0; jb < j1; ++jb) {
+        __syncthreads();
+        load_tile<0>(As, A + (long)rb * TB * np + (long)jb * TB, np);
+        if (MODE == 0) {                                      // tile (cb, jb) of M, rows = i, columns = j
+            if (jb == cb) load_tile<1>(Bs, B + (long)cb * TB * np + (long)jb * TB, np);
+            else load_tile<0>(Bs, B + (long)cb * TB * np + (long)jb * TB, np);
+        } else if (MODE == 1) {                               // tile (jb, cb) of M, rows = j, columns = i
+            if (jb == cb) load_tile<1>(Bs, B + (long)jb * TB * np + (long)cb * TB, np);
+            else load_tile<0>(Bs, B + (long)jb * TB * np + (long)cb * TB, np);
+        } else {
+            load_tile<0>(Bs, A + (long)cb * TB * np + (long)jb * TB, np);
+        }
+        __syncthreads();
+        if (MODE == 1) mma_tile<false>(As, Bs, acc);
+        else mma_tile<true>(As, Bs, acc);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wi = wv >> 1, wj = wv & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb * TB + wi * 32 + a * 16 + (lane >> 4) + 4 * q, c = cb * TB + wj * 32 + b * 16 + (lane & 15);
+                double v = acc[a][b][q];
+                if (MODE == 2 && r == c) v += r < k ? 1.0 / X[r] : 1.0;
+                C[(long)r * ldc + c] = v;
+            }
+}
+
+// rw = a + b  (NV vectors of np entries, stride ldv; entries past n are zeroed)
+template <int NV>
+__global__ void k_cap_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n, int np, int ldv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[(long)v * ldv + j] = j < n ? a[(long)v * ldv + j] + b[(long)v * ldv + j] : 0.0;
+}
+// w[v][r] = U[r] . y[v] - t[v][r]  for r < k (one wave per strong direction), 0 for the padding r in [k, kp)
+template <int NV>
+__global__ __launch_bounds__(256) void k_cap_uy(const double* __restrict__ U, int k, int kp, int n, int np, const double* __restrict__ y, int ldv,
+                                                const double* __restrict__ t, double* __restrict__ w, int ldk) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= kp) return;
+    if (r >= k) {
+        if (lane == 0)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) w[(long)v * ldk + r] = 0.0;
+        return;
+    }
+    const double* u = U + (long)r * np;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        const double uj = u[j];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] += uj * y[(long)v * ldv + j];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const double s = wave_sum(acc[v]);
+        if (lane == 0) w[(long)v * ldk + r] = s - t[(long)v * ldk + r];
+    }
+}
+// dx[v][i] = y[v][i] - sum_{r < k} Zt[r][i] zeta[v][r] : 64 columns x 4 row groups per block, folded in a fixed order
+template <int NV>
+__global__ __launch_bounds__(256) void k_cap_dx(const double* __restrict__ Zt, int k, int n, int np, const double* __restrict__ zeta, int ldk,
+                                                const double* __restrict__ y, double* __restrict__ dx, int ldv) {
+    __shared__ double part[NV][4][65];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    if (i < n)
+        for (int r = g; r < k; r += 4) {
+            const double z = Zt[(long)r * np + i];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += z * zeta[(long)v * ldk + r];
+        }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) part[v][g][c] = acc[v];
+    __syncthreads();
+    if (g == 0 && i < np) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            dx[(long)v * ldv + i] = i < n ? y[(long)v * ldv + i] - (((part[v][0][c] + part[v][1][c]) + part[v][2][c]) + part[v][3][c]) : 0.0;
+    }
+}
+__global__ void k_cap_flag_add(int* __restrict__ flag, const int* __restrict__ more) { flag[0] += more[0]; }
+}  // namespace
+
+// Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1 (lower tiles; padding rows k .. kp-1 get a unit diagonal).  U: kp x np with zero rows from k on;
+// M: the inverse Cholesky factor of H_w (lower triangle valid); S: kp x kp.
+void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, hipStream_t st) {
+    const dim3 g(np / TB, kp / TB);
+    hipLaunchKernelGGL(k_cap_gemm<0>, g, dim3(256), 0, st, U, M, Yt, np, np, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, Zt, np, np, (const double*)nullptr, 0);
+    const int kb = kp / TB;
+    hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2), dim3(256), 0, st, Yt, (const double*)nullptr, S, np, kp, X, k);
+}
+void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st) {
+    if (nv == 1) hipLaunchKernelGGL(k_cap_add<1>, dim3(cdiv(np, 256)), dim3(256), 0, st, a, b, out, n, np, ldv);
+    else hipLaunchKernelGGL(k_cap_add<2>, dim3(cdiv(np, 256)), dim3(256), 0, st, a, b, out, n, np, ldv);
+}
+void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st) {
+    if (nv == 1) hipLaunchKernelGGL(k_cap_uy<1>, dim3(cdiv(kp, 4)), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk);
+    else hipLaunchKernelGGL(k_cap_uy<2>, dim3(cdiv(kp, 4)), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk);
+}
+void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st) {
+    if (nv == 1) hipLaunchKernelGGL(k_cap_dx<1>, dim3(np / 64), dim3(256), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
+    else hipLaunchKernelGGL(k_cap_dx<2>, dim3(np / 64), dim3(256), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
+}
+void cap_flag_add_launch(int* flag, const int* more, hipStream_t st) { hipLaunchKernelGGL(k_cap_flag_add, dim3(1), dim3(1), 0, st, flag, more); }
+
+}  // namespace mbfir

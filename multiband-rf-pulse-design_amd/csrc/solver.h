@@ -25,6 +25,8 @@ struct SolveOpts {
     int shard_rank = 0, shard_size = 1;     // frequency-row sharding (one process per GPU)
     bool dense_trig = false; // keep the materialised trig matrix and the dense MFMA Gram even when the lattice structure is there
     double ddkkt_theta = 0; // > 0: extended-precision (double-double) KKT solve for every NT weight above theta x the typical weight
+    int dd_form = 0;        // the extended-precision solve: 0 its capacitance (saddle-point) form in plain double on the matrix cores
+                            // (capkkt.hip), 1 the double-double factorisation of the whole normal matrix (ddlin.hip)
     bool timing = true;     // HIP-event timing of the k_gram launches and the Cholesky phase (events read at the end)
 };
 

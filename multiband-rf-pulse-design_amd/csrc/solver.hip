@@ -109,6 +109,7 @@ constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding kernels (a 1024-thread block has to wait for a
                               // whole CU when other units share the chip)
 constexpr int MAX_SWEEPS = 8;
+constexpr int CAP_KMAX = 1024;   // strong directions the capacitance form of the extended-precision solve takes (S is CAP_KMAX^2; the one-pass M'(M b) goes to np = 1024)
 constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
 constexpr int WALL_ITERS = 3;
 constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement, oracle/conic_ipm.py */, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
@@ -1946,6 +1947,12 @@ struct Solver::Impl {
     double* ddinv = nullptr;     // inverses of the 64 x 64 diagonal blocks of the dd factor (k_dd_blockinv); nullptr (MBFIR_DD_BLOCKINV=0): substitution
     int* ddflags = nullptr;      // block flags of k_dd_trsv_mw / k_dd_trsv_bi; dd_epoch: the value the current call waits for
     int dd_epoch = 0;
+    // capacitance form of that solve (capkkt.hip; the default): Yt = U M', Zt = Yt M (k x np each), S = Yt Yt' + X^-1 and its
+    // inverse Cholesky factor Ms (kp x kp, kp = k rounded up to 64, at most CAP_KMAX), W1s / flagS the workspace and pivot
+    // counter of that factorisation, capw the right-hand side of the S solve
+    bool cap_form = true;
+    double *capYt = nullptr, *capZt = nullptr, *capS = nullptr, *capMs = nullptr, *capW1 = nullptr, *capw = nullptr;
+    int* capflag = nullptr;
     int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
     int dd_iters = 0, dd_kmax_seen = 0;
 
@@ -2205,8 +2212,8 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_dd_order, dim3(1), dim3(1024), 0, st, P, D);
             MBFIR_HIP(hipMemcpyAsync(hostFlag + 1, D.kcnt, sizeof(int), hipMemcpyDeviceToHost, st));
             MBFIR_HIP(hipStreamSynchronize(st));
-            if (hostFlag[1] <= DD_KMAX) return hostFlag[1];
-            theta *= 100.0;                                   // more strong directions than U has rows: raise the cap
+            if (hostFlag[1] <= (cap_form ? CAP_KMAX : DD_KMAX)) return hostFlag[1];
+            theta *= 100.0;                                   // more strong directions than U has rows (or than S takes): raise the cap
         }
         throw HipError("extended-precision solve: strong set does not fit");
     }
@@ -2229,12 +2236,24 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, tmpR, (const double*)nullptr, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, tmpR, (const double*)nullptr, wbz, scratch);
             apply_GT<NV>(wbz, tmpN2);
+            if (cap_form) {
+                // y = H_w^-1 rhs_w ; zeta = S^-1 (U y - t) ; dx = y - Zt' zeta   (all double; zeta are the strong directions'
+                // multipliers X (U dx - t) themselves)
+                const int kp = int(round_up(k, 64));
+                cap_add_launch(rhsN, tmpN2, Bl, P.N, P.np, P.LDV, NV, st);                       // rhs_w
+                double* yv = tmpN2;                                                              // (free from here on; yN is hsolve's own intermediate)
+                hsolve<NV>(Bl, yv);                                                              // y
+                cap_uy_launch(D.U, k, kp, P.N, P.np, yv, P.LDV, ddtS, capw, DD_KMAX, NV, st);
+                hsolve_launch(capMs, kp, capw, nullptr, ddzeta, partial, NV, DD_KMAX, st);       // zeta
+                cap_dx_launch(capZt, k, P.N, P.np, ddzeta, DD_KMAX, yv, Bh, P.LDV, NV, st);      // the correction of this pass
+            } else {
             hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 16)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
             dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch, flag, ddinv);
+            }
             apply_G<NV>(Bh, wpR);
             hipLaunchKernelGGL(k_dd_winv2c<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wpR, tmpR, wbz);
             if (P.big) hipLaunchKernelGGL(k_dd_winv2c_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wpR, tmpR, wbz, scratch);
-            hipLaunchKernelGGL(k_dd_zeta<NV>, lane_grid(dim3(k), nlanes), dim3(64), 0, st, P, D, Bh, Bl, ddtS, ddzeta);
+            if (!cap_form) hipLaunchKernelGGL(k_dd_zeta<NV>, lane_grid(dim3(k), nlanes), dim3(64), 0, st, P, D, Bh, Bl, ddtS, ddzeta);
             hipLaunchKernelGGL(k_dd_accum<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
             if (P.big) hipLaunchKernelGGL(k_dd_accum_big<NV>, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D, wbz, wpR, ddzeta, dz, gdx);
             hipLaunchKernelGGL(k_dd_accum_x<NV>, lane_grid(dim3(nbN), nlanes), b256, 0, st, P, Bh, dx);
@@ -2345,7 +2364,17 @@ struct Solver::Impl {
         }
         if (!lead_factor()) allreduce(H, (long)P.np * P.np, 0);   // dense path: sum the shards' normal matrices
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
-        if (ddk > 0) {
+        if (ddk > 0 && cap_form) {
+            // capacitance form: the ordinary double-precision factorisation of H_w, then Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1
+            // on the matrix cores and the same factorisation routine on S (kp x kp)
+            const int kp = int(round_up(ddk, 64));
+            chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, 1, 0, nullptr);
+            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
+            if (kp > ddk) hipMemsetAsync(D.U + (size_t)ddk * P.np, 0, sizeof(double) * (size_t)(kp - ddk) * P.np, st);
+            cap_build_launch(D.U, ddk, kp, P.np, M, D.sX, capYt, capZt, capS, st);
+            chol_inv_launch(capS, capMs, nullptr, capW1, kp, capflag, st, nullptr, nullptr, c1, 1, 0, nullptr);
+            cap_flag_add_launch(flag, capflag, st);           // pivots replaced in either factorisation count (oracle: chol_fixes += nfs)
+        } else if (ddk > 0) {
             if (c0) hipEventRecord(c0, st);
             hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
             dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
@@ -2708,6 +2737,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     std::vector<int> tiles(gram_table_ints(S.gp));
     gram_tiles_host(S.gp, tiles.data());
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
+    S.cap_form = o.dd_form == 0;                              // its capacitance form in plain double (capkkt.hip) or the double-double one
+    if (const char* ev = std::getenv("MBFIR_DDFORM")) S.cap_form = std::strcmp(ev, "dd") != 0;
     S.fused_hsolve = hsolve_fused_ok(int(np), 2);
     if (const char* ev = std::getenv("MBFIR_HSOLVE")) S.fused_hsolve = S.fused_hsolve && std::atoi(ev) != 0;       // 0: the two triangular GEMVs
     Arena& ar = S.ar;
@@ -2758,7 +2789,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
     S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.PPf = ar.get<double2>(6 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(std::max(P.trig ? (size_t)cdiv(P.nchunk, P.cgrp) * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld,
-                                        hsolve_part_doubles(int(np))));         // (also the partial vectors of the one-pass M'(M b))
+                                        std::max(hsolve_part_doubles(int(np)), hsolve_part_doubles(CAP_KMAX))));   // (also the partial vectors of the one-pass M'(M b), of H and of the capacitance matrix)
     S.partR = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partR2 = ar.get<double>(4 * (size_t)(S.nbR + 2)); S.partN = ar.get<double>(4 * (size_t)(S.nbN + 2));
     S.ddinv = nullptr;
     if (use_dd) {
@@ -2773,6 +2804,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         S.ddflags = ar.get<int>(2 * np / 32 + 8);          // block flags of the multi-workgroup dd solve (zeroed with the arena)
         S.ddinv = ar.get<double>(2 * np * 64);
         if (const char* ev = std::getenv("MBFIR_DD_BLOCKINV")) { if (std::atoi(ev) == 0) S.ddinv = nullptr; }
+        if (S.cap_form) {
+            S.capYt = ar.get<double>((size_t)CAP_KMAX * np); S.capZt = ar.get<double>((size_t)CAP_KMAX * np);
+            S.capS = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX); S.capMs = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX);
+            S.capW1 = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX + 65 * (size_t)CAP_KMAX); S.capw = ar.get<double>(2 * (size_t)DD_KMAX);
+            S.capflag = ar.get<int>(4);
+        }
     }
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));

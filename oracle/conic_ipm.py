@@ -435,13 +435,32 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         Hw = 0.5 * (Hw + Hw.T)
         if not np.all(np.isfinite(Hw)):
             raise FloatingPointError("non-finite normal matrix")
+        if ddkkt.get("form") == "cap":
+            # CAPACITANCE (saddle-point) form, plain double precision (round 4): the strong directions are kept as nearly-equality
+            # constraints instead of being folded into the matrix --
+            #     [H_w  U'; U  -X^-1] [dx; zeta] = [rhs_w; t],   zeta = X (U dx - t)
+            # -- so no number of the size of X ever meets one of the size of H_w: H_w = L L' in double, Y = L^-1 U' (N x k),
+            # S = X^-1 + Y'Y (k x k: a Cholesky of k <= 588 instead of a double-double one of np = 1088), zeta = S^-1 (U y - t),
+            # dx = H_w^-1 (rhs_w - U' zeta).  The refinement on the augmented system around it is unchanged.
+            Lw, nfix = chol_piv(Hw)
+            chol_fixes[0] += nfix
+            Mw = np.linalg.inv(Lw)
+            Y = Mw @ U.T                                        # N x k
+            S = Y.T @ Y + np.diag(1.0 / X)
+            S = 0.5 * (S + S.T)
+            Ls, nfs = chol_piv(S)
+            chol_fixes[0] += nfs
+            st = dict(Wm=Wm, cap=cap, U=U, X=X, k=len(X), nfix=nfix + nfs, Mw=Mw, Ms=np.linalg.inv(Ls), Y=Y, form="cap")
+        else:
+            st = None
         Hh = np.ascontiguousarray(Hw)
         Hl = np.zeros_like(Hh)
-        if len(X):
+        if len(X) and st is None:
             ddlin.rank_k(U, X, Hh, Hl)
-        d0 = np.ascontiguousarray(np.diag(Hh)).copy()
-        nfix = ddlin.chol(Hh, Hl, ddkkt.get("pivtol", 1e-28), d0)
-        chol_fixes[0] += nfix
+        if st is None:
+            d0 = np.ascontiguousarray(np.diag(Hh)).copy()
+            nfix = ddlin.chol(Hh, Hl, ddkkt.get("pivtol", 1e-28), d0)
+            chol_fixes[0] += nfix
 
         def comp(V):                                           # e' V_cone for the strong directions
             out = []
@@ -468,6 +487,9 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
                     o[cone.ob:] += ev[0][:, None] * Z[k0][None, :]
                 k0 = k1
             return o
+        if st is not None:
+            st.update(comp=comp, spread=spread)
+            return st
         return dict(Wm=Wm, cap=cap, U=U, X=X, Lh=Hh, Ll=Hl, comp=comp, spread=spread, k=len(X), nfix=nfix)
 
     dd_log = []
@@ -490,6 +512,16 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             if it == ddkkt.get("nref", 2):
                 break
             t = np.ascontiguousarray(st["comp"](r2))                         # k x ncol
+            if st.get("form") == "cap":
+                rw = r1 + G.T @ Wm.eig_apply(r2, -1, cap)                    # rhs_w: the capped scaling only
+                Mw, Ms, Y = st["Mw"], st["Ms"], st["Y"]
+                v = Mw @ rw                                                  # L^-1 rhs_w
+                zeta = Ms.T @ (Ms @ (Y.T @ v - t))                           # S^-1 (U H_w^-1 rhs_w - t)
+                dxh = Mw.T @ (v - Y @ zeta)                                  # H_w^-1 (rhs_w - U' zeta)
+                Gd = G @ dxh
+                dz = Wm.eig_apply(Gd - r2, -1, cap) + st["spread"](zeta, ncol)
+                DX += dxh; DZ += dz; GDX += Gd
+                continue
             rh = np.ascontiguousarray(r1 + G.T @ Wm.eig_apply(r2, -1, cap))
             rl = np.zeros_like(rh)
             if st["k"]:
