@@ -198,7 +198,15 @@ def other_configs(mbfir, ctxs):
         out["config3_fir_qp_cvx_h1_dualband_n512_m16384"] = {
             "designs_per_s": 8 / dt, "batch": 8, "streams": len(pool), "solved": sum(1 for r in res if r[1] == "Solved"),
             "ipm_iters": [r[2]["iters"] for r in res], "extended_precision_iters": [r[2]["dd_iters"] for r in res],
-            "one_design_alone_s": dt1, "one_design_status": st1}
+            "one_design_alone_s": dt1, "one_design_status": st1,
+            "extended_precision_form": {0: "capacitance (saddle-point) form, plain double on the matrix cores (capkkt.hip)", 1: "double-double factorisation (ddlin.hip)"}.get(i1.get("dd_form"), "none"),
+            # the three fp64 MFMA products of the capacitance form (Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1), HIP events around them
+            "capacitance_products": None if not i1.get("ms_cap") else {
+                "kernel": "k_cap_gemm<0|1|2> (64 x 64 tiles, v_mfma_f64_16x16x4_f64; triangular M: lower tiles only)", "bound": "mfma",
+                "achieved": i1["cap_flop"] / (i1["ms_cap"] * 1e-3) / 1e12, "peak": PEAK_FP64_MATRIX_TF, "unit": "TFLOP/s",
+                "frac": i1["cap_flop"] / (i1["ms_cap"] * 1e-3) / 1e12 / PEAK_FP64_MATRIX_TF, "traffic": None,
+                "builds": i1["dd_iters"], "ms_per_build": i1["ms_cap"] / max(1, i1["dd_iters"]), "flop_per_build": i1["cap_flop"] / max(1, i1["dd_iters"]),
+                "k_max": i1["dd_kmax"]}}
     finally:
         for c in pool[len(ctxs):]:
             c.close()

@@ -98,6 +98,11 @@ typedef struct mbfir_info {
     int collectives;     /* all-reduces a row-sharded solve issued (0 otherwise)                                   */
     int lanes;           /* designs that shared this design's lock-step batch (ms_solve, ms_gram, ms_chol are then
                             those of the whole batch)                                                      */
+    int dd_form;         /* form of the extended-precision solve that ran: 0 capacitance (saddle-point) form in plain double on
+                            the matrix cores, 1 double-double factorisation of the whole matrix, -1 none            */
+    double ms_cap;       /* capacitance form: device time of its three matrix-core products (Yt = U M', Zt = Yt M,
+                            S = Yt Yt' + X^-1), summed over the builds                                     */
+    double cap_flop;     /* ... and their flop, summed over the builds                                     */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to

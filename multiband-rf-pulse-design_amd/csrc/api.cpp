@@ -83,6 +83,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->lattice = si.lattice;
     info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
     info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes; info->collectives = si.collectives;
+    info->ms_cap = si.ms_cap; info->cap_flop = si.cap_flop; info->dd_form = si.dd_iters > 0 ? si.dd_form : -1;
 }
 
 // Solution vector -> taps, per designer.  lane: which design of the solver's last lock-step batch (fir_ap_cvx runs
@@ -162,7 +163,7 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
             const SolveInfo& other = keep_first ? second : first;
             si.ms_assemble += other.ms_assemble; si.ms_solve += other.ms_solve; si.ms_chol += other.ms_chol;
             si.ms_gram += other.ms_gram; si.h_builds += other.h_builds; si.chol_launches += other.chol_launches;
-            si.iters += other.iters; si.dd_iters += other.dd_iters;
+            si.iters += other.iters; si.dd_iters += other.dd_iters; si.ms_cap += other.ms_cap; si.cap_flop += other.cap_flop;
             ran_retry = true;
             return !keep_first;
         };
@@ -174,6 +175,9 @@ int run(mbfir_ctx* ctx, int asm_rc, const std::string& asm_err, TrigProgram& P, 
             ctx->err = st == ST_OPTIMAL_INACCURATE
                            ? "row-sharded solve met the reduced tolerances only ('Inaccurate/Solved'); the extended-precision retry runs unsharded only"
                            : "row-sharded solve ended 'numerical'; the extended-precision retry (opts.ddkkt) runs unsharded only -- solve this design on one GPU";
+        // the capacitance form of the extended-precision solve works in plain double on a k x k matrix that loses rank when the
+        // strong directions become dependent; the double-double factorisation of the whole matrix does not care: one more try
+        if (wants_retry() && so.shard_size <= 1 && so.ddkkt_theta > 0 && so.dd_form == 0 && !std::getenv("MBFIR_DDFORM")) { so.dd_form = 1; retry(false); }
         if (wants_retry() && si.lattice && !so.dense_trig && so.shard_size <= 1 && (double)P.Mf * P.N() <= 6e8) retry(true);
         // fir_ap_cvx extracts its taps on the device from the solution the LAST solve left there; after a retry the
         // winner may be an earlier attempt: put the returned solution there

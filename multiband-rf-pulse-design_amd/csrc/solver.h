@@ -38,6 +38,8 @@ struct SolveInfo {
     int chol_launches = 0;  // k_chol_step launches timed in ms_chol
     double chol_flop = 0;   // factorisation + triangular inverse, per build
     int dd_iters = 0, dd_kmax = 0;   // iterations that ran the extended-precision solve; largest strong set
+    double ms_cap = 0, cap_flop = 0; // capacitance form: device time and flop of the three matrix-core products (Yt, Zt, S), summed over the builds
+    int dd_form = 0;                 // which form of that solve ran (0 capacitance / double, 1 double-double)
     int collectives = 0;    // all-reduces the (row-sharded) solve issued
     int lanes = 1;          // designs that shared the lock-step batch (ms_* are those of the whole batch)
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences

@@ -2264,6 +2264,17 @@ struct Solver::Impl {
     bool timing = true;
     std::vector<hipEvent_t> evpool;
     size_t evused = 0;
+    std::vector<hipEvent_t> capev;       // (begin, end) pairs around the capacitance form's products
+    size_t capev_used = 0;
+    double cap_flop_sum = 0;
+    hipEvent_t next_cap_event() {
+        if (capev_used == capev.size()) {
+            hipEvent_t e;
+            MBFIR_HIP(hipEventCreate(&e));
+            capev.push_back(e);
+        }
+        return capev[capev_used++];
+    }
     hipEvent_t next_event() {
         if (evused == evpool.size()) {
             hipEvent_t e;
@@ -2371,7 +2382,12 @@ struct Solver::Impl {
             chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, 1, 0, nullptr);
             hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
             if (kp > ddk) hipMemsetAsync(D.U + (size_t)ddk * P.np, 0, sizeof(double) * (size_t)(kp - ddk) * P.np, st);
+            hipEvent_t b0 = timing ? next_cap_event() : nullptr, b1 = timing ? next_cap_event() : nullptr;
+            if (b0) hipEventRecord(b0, st);
             cap_build_launch(D.U, ddk, kp, P.np, M, D.sX, capYt, capZt, capS, st);
+            if (b1) hipEventRecord(b1, st);
+            // Yt and Zt: kp x np x np / 2 multiply-adds each (triangular M); S: kp x kp x np / 2 (lower tiles)
+            cap_flop_sum += 2.0 * (double(kp) * P.np * P.np + 0.5 * double(kp) * kp * P.np);
             chol_inv_launch(capS, capMs, nullptr, capW1, kp, capflag, st, nullptr, nullptr, c1, 1, 0, nullptr);
             cap_flag_add_launch(flag, capflag, st);           // pivots replaced in either factorisation count (oracle: chol_fixes += nfs)
         } else if (ddk > 0) {
@@ -2435,6 +2451,7 @@ Solver::~Solver() {
     if (impl->dimsT) hipFree(impl->dimsT);
     if (impl->hostDims) hipHostFree(impl->hostDims);
     for (hipEvent_t e : impl->evpool) hipEventDestroy(e);
+    for (hipEvent_t e : impl->capev) hipEventDestroy(e);
     if (impl->ev0) hipEventDestroy(impl->ev0);
     if (impl->ev1) hipEventDestroy(impl->ev1);
     if (impl->st) hipStreamDestroy(impl->st);
@@ -2857,7 +2874,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     }
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_assembled = now_ms();
-    S.evused = 0;
+    S.evused = 0; S.capev_used = 0; S.cap_flop_sum = 0;
     S.timing = o.timing;
 
     const bool sharded = S.shard_size > 1;
@@ -3072,6 +3089,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     double ms_gram = 0, ms_chol = 0;
     int builds = 0;
     S.collect_times(ms_gram, ms_chol, builds);
+    double ms_cap = 0;
+    for (size_t i = 0; i + 1 < S.capev_used; i += 2) { float t = 0; hipEventElapsedTime(&t, S.capev[i], S.capev[i + 1]); ms_cap += t; }
     for (int b = 0; b < nlanes; ++b) {
         SolveInfo& info = infos[b];
         info = LH[b].info;
@@ -3084,6 +3103,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
         info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
+        info.dd_form = S.cap_form ? 0 : 1; info.cap_flop = S.cap_flop_sum; info.ms_cap = ms_cap;
         info.chol_launches = int(S.chol_launch_count);
         info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);
         info.gram_flop = P.trig ? double(3 * P.D1 - 1) * double(LH[b].Q->Mf) * (4.0 + 4.0 * nw)      // rotation + 2 fma per weight, per point and frequency

@@ -394,6 +394,32 @@ def test_units_start_before_the_batch_is_assembled_and_survive_a_change_of_shape
         c.close()
 
 
+@pytest.mark.parametrize("case", ["qp_modelA48", "qp_modelB25", "h1_384"])
+def test_extended_precision_solve_capacitance_form_equals_the_double_double_form(case, monkeypatch):
+    """The extended-precision KKT solve has two forms: the capacitance (saddle-point) form in plain double on
+    the matrix cores -- the strong eigen-directions kept as nearly-equality constraints, a k x k Schur complement factorised
+    (capkkt.hip; the default since round 4) -- and the double-double factorisation of the whole normal matrix (ddlin.hip,
+    MBFIR_DDFORM=dd).  Same program, same iterates: verdict, iteration count, objective and taps must agree, and the BASELINE
+    config-3 family (H-1 dual band, fir_qp_cvx k=120 obj=1e6: dzrf_mb.m:210-213) must run its extended-precision iterations in
+    the form asked for."""
+    if case == "h1_384":
+        f, a, d = mbfir.spec.spec_h1_dualband(384)
+        args, opts = (384, f, a, d, 120.0, 1e6), mbfir.make_opts(grid_m=1536)
+    else:
+        args, opts = CASES[case][1], mbfir.make_opts(ddkkt=1)
+    res = {}
+    for form in ("cap", "dd"):
+        monkeypatch.setenv("MBFIR_DDFORM", form)
+        res[form] = mbfir.fir_qp_cvx(*args, opts=opts, info=True)
+    (hc, sc, ic), (hd, sd, idd) = res["cap"], res["dd"]
+    assert sc == sd == "Solved"
+    assert abs(ic["iters"] - idd["iters"]) <= 1 and ic["dd_iters"] == idd["dd_iters"] or abs(ic["dd_iters"] - idd["dd_iters"]) <= 1
+    assert abs(ic["pcost"] - idd["pcost"]) <= 1e-9 * max(1.0, abs(idd["pcost"]))
+    assert relinf(hc, hd) <= 1e-6
+    if case == "h1_384":
+        assert ic["dd_iters"] > 30 and ic["dd_form"] == 0 and idd["dd_form"] == 1 and ic["ms_cap"] > 0 and ic["cap_flop"] > 0
+
+
 def _widened(f, dfw):
     """band edges moved outwards by dfw each -- what one probe of the transition-width bisection does to them (fir_ap.m:63-106)"""
     f = np.asarray(f, float).copy()
