@@ -37,8 +37,9 @@ DDKKT_THETA = 1e6       # csrc/api.cpp uses the same value
 
 def fir_qp_cvx(n, f, a, d, k=100.0, obj=0.0, dbg=0, grid_m=0, info=False, **kw):
     P = assemble.assemble_fir_qp_cvx(n, f, a, d, k, obj, grid_m)
-    # the nearly active error cones of this designer need the extended-precision KKT solve (conic_ipm.factor_dd)
-    kw.setdefault("ddkkt", dict(theta=DDKKT_THETA))
+    # the nearly active error cones of this designer need the extended-precision KKT solve (conic_ipm.factor_dd): its
+    # capacitance form in plain double, as on the device (capkkt.hip); ddkkt=dict(theta=..., form="dd") is the double-double one
+    kw.setdefault("ddkkt", dict(theta=DDKKT_THETA, form="cap"))
     r = _solve(P, kw)
     x = r["x"]
     return _ret(x[:n] + 1j * x[n:2 * n], r, info)                                                  # :209

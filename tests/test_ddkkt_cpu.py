@@ -111,15 +111,24 @@ def test_h1_dual_band_qp_form_where_double_precision_hits_the_wall():
     P = assemble.assemble_fir_qp_cvx(n, f, a, d, 120.0, 1e6, m)
     plain = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"])
     assert plain["status"] == conic_ipm.STATUS_NUMERICAL and plain["relgap"] > 1.22e-4
-    r = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"], ddkkt=dict(theta=designers.DDKKT_THETA))
-    assert r["status"] == conic_ipm.STATUS_OPTIMAL and r["chol_fixes"] == 0
-    assert r["pres"] <= 1e-8 and r["dres"] <= 1e-8 and r["relgap"] <= 1e-8
-    # independent certificate from the returned point
-    x, s, z = r["x"], r["s"], r["z"]
-    cone = conic_ipm._Cone(P["l"], P["nq3"], P["big"])
-    assert np.linalg.norm(P["G"] @ x + s - P["h"]) <= 1e-8 * max(1.0, np.linalg.norm(P["h"]))
-    assert np.linalg.norm(P["G"].T @ z + P["c"]) <= 1e-8 * max(1.0, np.linalg.norm(P["c"]))
-    assert cone.min_residual(s) <= 1e-12 and cone.min_residual(z) <= 1e-7
-    assert abs(P["c"] @ x + P["h"] @ z) <= 1e-7 * abs(P["c"] @ x)
-    h, status = designers.fir_qp_cvx(n, f, a, d, 120.0, 1e6, grid_m=m)       # the designer uses it by default
-    assert status == "Solved" and np.abs(h - (x[:n] + 1j * x[n:2 * n])).max() <= 1e-12
+    # both forms of the extended-precision solve: the double-double factorisation of the whole normal matrix and (round 4) the
+    # capacitance form in plain double -- strong directions as nearly-equality constraints, a k x k Schur complement
+    sol = {}
+    for form in ("dd", "cap"):
+        r = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"], ddkkt=dict(theta=designers.DDKKT_THETA, form=form))
+        assert r["status"] == conic_ipm.STATUS_OPTIMAL and r["chol_fixes"] == 0, form
+        assert r["pres"] <= 1e-8 and r["dres"] <= 1e-8 and r["relgap"] <= 1e-8
+        # independent certificate from the returned point
+        x, s, z = r["x"], r["s"], r["z"]
+        cone = conic_ipm._Cone(P["l"], P["nq3"], P["big"])
+        assert np.linalg.norm(P["G"] @ x + s - P["h"]) <= 1e-8 * max(1.0, np.linalg.norm(P["h"]))
+        assert np.linalg.norm(P["G"].T @ z + P["c"]) <= 1e-8 * max(1.0, np.linalg.norm(P["c"]))
+        assert cone.min_residual(s) <= 1e-12 and cone.min_residual(z) <= 1e-7
+        assert abs(P["c"] @ x + P["h"] @ z) <= 1e-7 * abs(P["c"] @ x)
+        sol[form] = r
+    assert sol["dd"]["iters"] == sol["cap"]["iters"]
+    assert abs(sol["dd"]["pcost"] - sol["cap"]["pcost"]) <= 1e-10 * abs(sol["dd"]["pcost"])
+    xd, xc = sol["dd"]["x"], sol["cap"]["x"]
+    assert np.abs(xd[:2 * n] - xc[:2 * n]).max() <= 1e-8 * np.abs(xd[:2 * n]).max()
+    h, status = designers.fir_qp_cvx(n, f, a, d, 120.0, 1e6, grid_m=m)       # the designer uses the capacitance form by default
+    assert status == "Solved" and np.abs(h - (xc[:n] + 1j * xc[n:2 * n])).max() <= 1e-12
