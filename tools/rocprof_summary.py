@@ -21,7 +21,7 @@ def find_db(d):
 
 
 def short(name):
-    name = name.replace("mbfir::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("mbfir::", "")
     return name.split("(")[0].replace("void ", "")
 
 
