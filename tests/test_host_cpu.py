@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -167,3 +168,14 @@ def test_refine_is_clamped_and_new_options_exist():
     assert o.refine == 20 and o.ddkkt == 1 and o.lanes == 8           # the clamp to 8 sweeps happens inside the library
     with pytest.raises(TypeError):
         mbfir.make_opts(no_such_option=1)
+
+
+def test_bench_untimed_legs_run_in_a_child_whose_failure_cannot_cost_the_metric_line():
+    """bench.py's untimed legs (BASELINE configs 3 and 4, the heterogeneous batch) run in a fresh child process; whatever
+    happens to it -- here: there is no GPU, so the child's first context raises -- comes back as an "error" entry, never as an
+    exception or a lost line of the parent."""
+    sys.path.insert(0, ROOT)
+    import bench
+    res = bench.other_configs_in_child(0, 2, timeout_s=120)
+    assert isinstance(res, dict) and "error" in res and ("child exit code" in res["error"] or "GPU" in res["error"] or "Error" in res["error"])
+

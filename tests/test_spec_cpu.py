@@ -70,3 +70,25 @@ def test_bandedge_from_dinf_and_error_paths():
     with pytest.raises(ValueError):
         mbfir.spec.rf_ripple_gfa(60, 0.01, "st")
     assert abs(mbfir.spec.dinf(0.01, 0.001) - 2.5351) < 2e-2   # Parks-McClellan D-infinity for (0.01, 0.001)
+
+
+def test_spec_rand_is_the_survey_s_rand_workload():
+    """S-RAND: k in 2..8 non-overlapping bands on [-1, 1], widths U(0.01, 0.1), gaps >= 8 / n, amplitudes 0 or
+    U(0.2, 0.9) with at least one pass band, ripples U(0.002, 0.02); deterministic per seed (the bench's heterogeneous batch and the
+    heterogeneous-unit tests draw from it)."""
+    ks = set()
+    for seed in range(64):
+        f, a, d = mbfir.spec.spec_rand(512, seed)
+        k = len(d)
+        ks.add(k)
+        assert 2 <= k <= 8 and len(f) == len(a) == 2 * k
+        assert f[0] >= -1.0 and f[-1] <= 1.0 and np.all(np.diff(f) > 0)
+        widths, gaps = f[1::2] - f[0::2], f[2::2] - f[1:-1:2]
+        assert np.all(widths >= 0.01 - 1e-15) and np.all(widths <= 0.1 + 1e-15) and np.all(gaps >= 8.0 / 512 - 1e-12)
+        assert np.all(a[0::2] == a[1::2]) and np.any(a > 0) and np.all((a == 0) | ((a >= 0.2) & (a <= 0.9)))
+        assert np.all(d >= 0.002) and np.all(d <= 0.02)
+        f2, a2, d2 = mbfir.spec.spec_rand(512, seed)
+        assert np.array_equal(f, f2) and np.array_equal(a, a2) and np.array_equal(d, d2)
+    assert ks == set(range(2, 9))
+    with pytest.raises(ValueError):
+        mbfir.spec.spec_rand(16, 0, kmin=8, kmax=8)          # eight bands with gaps of 8 / n do not fit at n = 16

@@ -186,3 +186,27 @@ def test_eight_contexts_enter_the_extended_precision_path_at_once():
             assert np.array_equal(h, h1)
     finally:
         one.close()
+
+
+def test_heterogeneous_units_equal_exact_shape_units():
+    """MBFIR_HETERO=0 is round 3's rule (a lock-step unit holds designs of exactly one shape; designs whose band edges differ run one
+    per stream), the default forms heterogeneous units.  Same results either way, bit for bit; the unit sizes
+    differ."""
+    from conftest import c13
+    f, a, d = c13(64)
+    jobs = []
+    for q in range(6):
+        fq = np.asarray(f, float).copy(); fq[0::2] -= 8e-4 * q; fq[1::2] += 8e-4 * q
+        jobs.append(("fir_ap_cvx", (64, list(fq), a, d, 0.1, 1e-3)))
+    out = {}
+    for mode in ("1", "0"):
+        ctx = mbfir.Context(0)
+        try:
+            with env(MBFIR_HETERO=mode):
+                out[mode] = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=6))
+        finally:
+            ctx.close()
+    assert {r[2]["lanes"] for r in out["1"]} == {6} and max(r[2]["lanes"] for r in out["0"]) < 6
+    for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
+        assert s1 == s0 and i1["iters"] == i0["iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
+
