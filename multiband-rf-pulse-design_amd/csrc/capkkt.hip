@@ -49,15 +49,22 @@ __device__ __forceinline__ void mma_tile(const double (*As)[TLD], const double (
             for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
 }
-// 64 x 64 tile -> LDS (256 threads, 16-byte loads); keep: 0 everything, 1 the lower triangle (col <= row), 2 the upper
-// triangle of the TRANSPOSED view, i.e. entries with row >= col -- the same set; both triangular products keep col <= row of M
-template <int KEEP_LOWER>
-__device__ __forceinline__ void load_tile(double (*S)[TLD], const double* __restrict__ src, long ld) {
+// 64 x 64 tile: global -> registers (256 threads, eight 16-byte loads each, all in flight), registers -> LDS.  lower: keep the
+// lower triangle only (col <= row) -- both products with the triangular M keep exactly those entries of its diagonal tile
+struct TileRegs { double2 t[8]; };
+__device__ __forceinline__ void fetch_tile(TileRegs& R, const double* __restrict__ src, long ld) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        R.t[u] = *reinterpret_cast<const double2*>(src + (long)(e >> 5) * ld + 2 * (e & 31));
+    }
+}
+__device__ __forceinline__ void store_tile(double (*S)[TLD], const TileRegs& R, bool lower) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = threadIdx.x + 256 * u, r = e >> 5, c = 2 * (e & 31);
-        double2 t = *reinterpret_cast<const double2*>(src + (long)r * ld + c);
-        if (KEEP_LOWER) { if (c > r) t.x = 0.0; if (c + 1 > r) t.y = 0.0; }
+        double2 t = R.t[u];
+        if (lower) { if (c > r) t.x = 0.0; if (c + 1 > r) t.y = 0.0; }
         *reinterpret_cast<double2*>(&S[r][c]) = t;
     }
 }
@@ -88,19 +95,21 @@ __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+    // the next tile pair is fetched into registers while the matrix cores work on the current one (one LDS buffer, two barriers a step)
+    auto a_src = [&](int jb) { return A + (long)rb * TB * np + (long)jb * TB; };
+    auto b_src = [&](int jb) {
+        return MODE == 0 ? B + (long)cb * TB * np + (long)jb * TB             // tile (cb, jb) of M: rows = i, columns = j
+             : MODE == 1 ? B + (long)jb * TB * np + (long)cb * TB             // tile (jb, cb) of M: rows = j, columns = i
+                         : A + (long)cb * TB * np + (long)jb * TB;
+    };
+    TileRegs ra, rbb;
+    if (j0 < j1) { fetch_tile(ra, a_src(j0), np); fetch_tile(rbb, b_src(j0), np); }
     for (int jb = j0; jb < j1; ++jb) {
         __syncthreads();
-        load_tile<0>(As, A + (long)rb * TB * np + (long)jb * TB, np);
-        if (MODE == 0) {                                      // tile (cb, jb) of M, rows = i, columns = j
-            if (jb == cb) load_tile<1>(Bs, B + (long)cb * TB * np + (long)jb * TB, np);
-            else load_tile<0>(Bs, B + (long)cb * TB * np + (long)jb * TB, np);
-        } else if (MODE == 1) {                               // tile (jb, cb) of M, rows = j, columns = i
-            if (jb == cb) load_tile<1>(Bs, B + (long)jb * TB * np + (long)cb * TB, np);
-            else load_tile<0>(Bs, B + (long)jb * TB * np + (long)cb * TB, np);
-        } else {
-            load_tile<0>(Bs, A + (long)cb * TB * np + (long)jb * TB, np);
-        }
+        store_tile(As, ra, false);
+        store_tile(Bs, rbb, MODE != 2 && jb == cb);
         __syncthreads();
+        if (jb + 1 < j1) { fetch_tile(ra, a_src(jb + 1), np); fetch_tile(rbb, b_src(jb + 1), np); }
         if (MODE == 1) mma_tile<false>(As, Bs, acc);
         else mma_tile<true>(As, Bs, acc);
     }
@@ -153,17 +162,20 @@ __global__ __launch_bounds__(256) void k_cap_uy(const double* __restrict__ U, in
         if (lane == 0) w[(long)v * ldk + r] = s - t[(long)v * ldk + r];
     }
 }
-// dx[v][i] = y[v][i] - sum_{r < k} Zt[r][i] zeta[v][r] : 64 columns x 4 row groups per block, folded in a fixed order
+// dx[v][i] = y[v][i] - sum_{r < k} Zt[r][i] zeta[v][r] : 32 columns x 32 row groups per block of 1024 threads (a wave reads two
+// 256-byte row segments), the groups' sums folded in a fixed order.  (The first version -- 64 columns x 4 groups, 17 blocks, 147
+// dependent multiply-adds per thread at k = 588 -- took 75-80 us a call, four calls per iteration: 17 % of an iteration.)
+constexpr int DXC = 32, DXG = 32;
 template <int NV>
-__global__ __launch_bounds__(256) void k_cap_dx(const double* __restrict__ Zt, int k, int n, int np, const double* __restrict__ zeta, int ldk,
-                                                const double* __restrict__ y, double* __restrict__ dx, int ldv) {
-    __shared__ double part[NV][4][65];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+__global__ __launch_bounds__(1024) void k_cap_dx(const double* __restrict__ Zt, int k, int n, int np, const double* __restrict__ zeta, int ldk,
+                                                 const double* __restrict__ y, double* __restrict__ dx, int ldv) {
+    __shared__ double part[NV][DXG][DXC + 1];
+    const int c = threadIdx.x & (DXC - 1), g = threadIdx.x / DXC, i = blockIdx.x * DXC + c;
     double acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.0;
     if (i < n)
-        for (int r = g; r < k; r += 4) {
+        for (int r = g; r < k; r += DXG) {
             const double z = Zt[(long)r * np + i];
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[v] += z * zeta[(long)v * ldk + r];
@@ -173,8 +185,11 @@ __global__ __launch_bounds__(256) void k_cap_dx(const double* __restrict__ Zt, i
     __syncthreads();
     if (g == 0 && i < np) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-            dx[(long)v * ldv + i] = i < n ? y[(long)v * ldv + i] - (((part[v][0][c] + part[v][1][c]) + part[v][2][c]) + part[v][3][c]) : 0.0;
+        for (int v = 0; v < NV; ++v) {
+            double t = 0.0;
+            for (int q = 0; q < DXG; ++q) t += part[v][q][c];
+            dx[(long)v * ldv + i] = i < n ? y[(long)v * ldv + i] - t : 0.0;
+        }
     }
 }
 __global__ void k_cap_flag_add(int* __restrict__ flag, const int* __restrict__ more) { flag[0] += more[0]; }
@@ -198,8 +213,8 @@ void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* 
     else hipLaunchKernelGGL(k_cap_uy<2>, dim3(cdiv(kp, 4)), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk);
 }
 void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st) {
-    if (nv == 1) hipLaunchKernelGGL(k_cap_dx<1>, dim3(np / 64), dim3(256), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
-    else hipLaunchKernelGGL(k_cap_dx<2>, dim3(np / 64), dim3(256), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
+    if (nv == 1) hipLaunchKernelGGL(k_cap_dx<1>, dim3(np / DXC), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
+    else hipLaunchKernelGGL(k_cap_dx<2>, dim3(np / DXC), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
 }
 void cap_flag_add_launch(int* flag, const int* more, hipStream_t st) { hipLaunchKernelGGL(k_cap_flag_add, dim3(1), dim3(1), 0, st, flag, more); }
 
