@@ -1952,6 +1952,7 @@ struct Solver::Impl {
     // inverse Cholesky factor Ms (kp x kp, kp = k rounded up to 64, at most CAP_KMAX), W1s / flagS the workspace and pivot
     // counter of that factorisation, capw the right-hand side of the S solve
     bool cap_form = true;
+    int dd_passes = 2;           // refinement passes on the augmented system around the extended-precision solve (MBFIR_DD_PASSES, <= 8: the norm slots)
     double *capYt = nullptr, *capZt = nullptr, *capS = nullptr, *capMs = nullptr, *capW1 = nullptr, *capw = nullptr;
     int* capflag = nullptr;
     int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
@@ -2229,7 +2230,7 @@ struct Solver::Impl {
         hipMemsetAsync(dx, 0, sizeof(double) * NV * P.LDV, st);
         hipMemsetAsync(dz, 0, sizeof(double) * NV * P.Rp, st);
         hipMemsetAsync(gdx, 0, sizeof(double) * NV * P.Rp, st);
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < dd_passes; ++it) {
             apply_GT<NV>(dz, tmpN);
             hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
             hipLaunchKernelGGL(k_dd_r2<NV>, lane_grid(gC, nlanes), b256, 0, st, P, D, dl, bz, gdx, dz, tmpR, ddtS);                  // r2, t
@@ -2763,6 +2764,15 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
     S.cap_form = o.dd_form == 0;                              // its capacitance form in plain double (capkkt.hip) or the double-double one
     if (const char* ev = std::getenv("MBFIR_DDFORM")) S.cap_form = std::strcmp(ev, "dd") != 0;
+    // Refinement passes on the augmented system around the extended-precision solve: two for the double-double form, THREE for the
+    // capacitance form.  Measured on BASELINE config 3's family (tools/exp/c3_one_design.py): the first pass takes the residual of
+    // the constant system from ||c|| = 1e6 to 1e-8 early and to 1.2e-5 from k ~ 480 strong directions on (the lattice-built H_w
+    // against the exact operator: a floor of ~1e-11 relative), every further pass contracts it by ~2e-3.  With two passes one of the
+    // eight designs of the bench's batch (ripples x 1.02, k = 751 at mu = 3e-11) took a step of 0.006 at relgap 1.02e-8 and lost its
+    // iterate (NaN) in the next -- the oracle, whose H_w is the dense product, does not -- and had to be repeated in the
+    // double-double form (150 iterations instead of 74); with three it solves like the double-double form.  Cost: 0.135 -> 0.153 s alone.
+    S.dd_passes = S.cap_form ? 3 : 2;
+    if (const char* ev = std::getenv("MBFIR_DD_PASSES")) S.dd_passes = std::max(1, std::min(8, std::atoi(ev)));
     S.fused_hsolve = hsolve_fused_ok(int(np), 2);
     if (const char* ev = std::getenv("MBFIR_HSOLVE")) S.fused_hsolve = S.fused_hsolve && std::atoi(ev) != 0;       // 0: the two triangular GEMVs
     Arena& ar = S.ar;
@@ -2990,9 +3000,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
             info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
             if (o.verbose)
-                fprintf(stderr, "%s%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d\n",
+                fprintf(stderr, "%s%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d%s\n",
                         nlanes > 1 ? ("[" + std::to_string(b) + "] ").c_str() : "", it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES],
-                        hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU], hs[S_ALPHA], hs[S_SIGMA], L.nsweep, chol_fixes);
+                        hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU], hs[S_ALPHA], hs[S_SIGMA], L.nsweep, chol_fixes,
+                        dd_now ? [&] { char bf[200]; std::snprintf(bf, sizeof(bf), " | k %d refinement norms %.2e -> %.2e -> %.2e , %.2e -> %.2e -> %.2e", S.dd_k,
+                                       hs[S_RNA], hs[S_RNA + 1], S.dd_passes > 2 ? hs[S_RNA + 2] : 0.0, hs[S_RNB], hs[S_RNB + 1], S.dd_passes > 2 ? hs[S_RNB + 2] : 0.0);
+                                       return std::string(bf); }().c_str() : "");
             auto finish = [&](int status) { L.status = status; L.live = false; };
             if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) { finish(ST_NUMERICAL); continue; }
             if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) { finish(ST_OPTIMAL); continue; }

@@ -503,13 +503,14 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         ncol = BX.shape[1]
         DX = np.zeros((N, ncol)); DZ = np.zeros((R, ncol)); GDX = np.zeros((R, ncol))
         norms = []
-        for it in range(ddkkt.get("nref", 2) + 1):
+        nref = ddkkt.get("nref", 3 if st.get("form") == "cap" else 2)       # the capacitance form takes a third pass (solver.hip: why)
+        for it in range(nref + 1):
             r1 = BX - G.T @ DZ
             r2 = BZ - GDX + Wm.eig_apply(DZ, +1)
             n1 = float(np.max(np.sqrt(np.sum(r1 * r1, axis=0))))
             n2 = float(np.max(np.abs(r2)))
             norms.append((n1, n2))
-            if it == ddkkt.get("nref", 2):
+            if it == nref:
                 break
             t = np.ascontiguousarray(st["comp"](r2))                         # k x ncol
             if st.get("form") == "cap":
