@@ -420,6 +420,24 @@ def test_extended_precision_solve_capacitance_form_equals_the_double_double_form
         assert ic["dd_iters"] > 30 and ic["dd_form"] == 0 and idd["dd_form"] == 1 and ic["ms_cap"] > 0 and ic["cap_flop"] > 0
 
 
+def test_capacitance_form_holds_through_the_end_game_of_config3s_tightest_neighbour(monkeypatch):
+    """The design that exposed the capacitance form's weak spot (round 4): BASELINE config 3's spec with its ripples x 1.02 (the second
+    design of bench.py's config-3 batch) reaches k = 751 strong directions at mu = 3e-11; with TWO refinement passes around the
+    capacitance solve the device took a step of 0.006 at relgap 1.02e-8 and lost its iterate in the next iteration (the solve was then
+    repeated in the double-double form: 150 iterations on record instead of 74).  With three passes (the default of that form) it
+    solves like the double-double form, without the repeat."""
+    n, m = 512, 16384
+    f, a, d = mbfir.spec.spec_h1_dualband(n)
+    args = (n, f, a, [x * 1.02 for x in d], 120.0, 1e6)
+    monkeypatch.setenv("MBFIR_DDFORM", "dd")
+    hd, sd, idd = mbfir.fir_qp_cvx(*args, opts=mbfir.make_opts(grid_m=m), info=True)
+    monkeypatch.delenv("MBFIR_DDFORM")
+    hc, sc, ic = mbfir.fir_qp_cvx(*args, opts=mbfir.make_opts(grid_m=m), info=True)          # default: capacitance form, fallback armed
+    assert sd == sc == "Solved" and ic["dd_form"] == 0 and idd["dd_form"] == 1
+    assert abs(ic["iters"] - idd["iters"]) <= 1 and ic["iters"] < 100, (ic["iters"], idd["iters"])      # (no second attempt added in)
+    assert abs(ic["pcost"] - idd["pcost"]) <= 1e-9 * abs(idd["pcost"]) and relinf(hc, hd) <= 1e-6
+
+
 def _widened(f, dfw):
     """band edges moved outwards by dfw each -- what one probe of the transition-width bisection does to them (fir_ap.m:63-106)"""
     f = np.asarray(f, float).copy()
