@@ -711,12 +711,14 @@ __device__ __forceinline__ double big_dot(const double* a, const double* b, int 
 }
 
 // scaling of the big cone: wbb (w0 in [0], w1 in [1..]), eta -> Sc[S_ETAB]; lam = W z
-__global__ __launch_bounds__(1024) void k_big_scaling(int big, const double* __restrict__ s,
+__global__ __launch_bounds__(1024) void k_big_scaling(DProg P, const double* __restrict__ s,
                                                       const double* __restrict__ z, double* __restrict__ wbb,
-                                                      double* __restrict__ lam, double* __restrict__ Sc, size_t lane_bytes, const int* lane_mask) {
-    LANES_RAW(lane_bytes, lane_mask, s, z, wbb, lam, Sc);
+                                                      double* __restrict__ lam, double* __restrict__ Sc) {
+    LANES(P, s, z, wbb, lam, Sc);
     __shared__ double sh[17];
-    const int n1 = big - 1;
+    const long ob = P.l + 3L * P.nq3;                       // (the lane's own row count: heterogeneous units)
+    s += ob; z += ob; lam += ob;
+    const int big = P.big, n1 = big - 1;
     double ns = sqrt(big_dot(s + 1, s + 1, n1, sh)), nz = sqrt(big_dot(z + 1, z + 1, n1, sh));
     double a = sqrt(jres(s[0], ns)), b = sqrt(jres(z[0], nz));
     double sz1 = big_dot(s + 1, z + 1, n1, sh);
@@ -1124,7 +1126,9 @@ __global__ __launch_bounds__(256) void k_dots_r(DProg P, const double* __restric
         for (int a = 0; a < 3; ++a) { v[0] += P.h[r + a] * z1[r + a]; v[1] += P.h[r + a] * z2[r + a]; v[2] += wz[a] * wz[a]; }
         if (!P.own && P.rep[r]) v[0] = v[1] = v[2] = 0.0;
     }
-    block_partials<3>(v, part, false);
+    // (programs with the big cone: its partial row comes FIRST, the block partials behind it -- positions that do not move with the
+    //  number of blocks, so a lane of a heterogeneous unit folds exactly what its single solve folds)
+    block_partials<3>(v, part + (P.big ? 3 : 0), false);
 }
 // big-cone contribution to the same three sums (written as one extra partial row)
 __global__ __launch_bounds__(1024) void k_big_dots(DProg P, const double* __restrict__ wbb, const double* __restrict__ Sc,
@@ -1247,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restr
         }
         v[0] = soc3_step(ll, dss); v[1] = soc3_step(ll, wdz);
     }
-    block_partials<2>(v, part, true);
+    block_partials<2>(v, part + (P.big ? 2 : 0), true);
 }
 __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
                                                        const double* __restrict__ z1, const double* __restrict__ z2,
@@ -1701,7 +1705,7 @@ __global__ __launch_bounds__(256) void k_cone_resid(DProg P, const double* __res
     }
     __shared__ double sh[17];
     double m = block_max(a[0], sh), s = block_sum(a[1], sh);
-    if (threadIdx.x == 0) { part[2L * blockIdx.x] = m; part[2L * blockIdx.x + 1] = s; }
+    if (threadIdx.x == 0) { const long row = blockIdx.x + (P.big ? 1 : 0); part[2L * row] = m; part[2L * row + 1] = s; }   // (big cone's row first)
 }
 __global__ __launch_bounds__(1024) void k_big_cone_resid(DProg P, const double* __restrict__ v, double* __restrict__ part_row) {
     LANES(P, v, part_row);
@@ -2578,9 +2582,9 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     // the CLASS of the program: what all lanes of a unit must share (solve_lanes)
     std::vector<long> key{long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.nq3), long(Q.big), long(Q.quad), long(pr->c_rows.size()),
                           long(Lt.ok), long(Lt.D1), tbits};
-    // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path, big cone; MBFIR_HETERO=0:
+    // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path; MBFIR_HETERO=0:
     // round 3's rule everywhere), the exact shape: grid, rows, chunks
-    bool exact = !Lt.ok || o.dense_trig || Q.big;
+    bool exact = !Lt.ok || o.dense_trig;
     if (const char* ev = std::getenv("MBFIR_HETERO")) exact = exact || std::atoi(ev) == 0;
     if (exact) {
         const long more[] = {long(Q.Mf), long(Q.R), long(Q.l), long(pr->f_rows.size()), long(pr->yrows.size()), long(Lt.ch_start.size()), long(Lt.wf.size())};
@@ -2709,9 +2713,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         nyrows_max = std::max(nyrows_max, int(LH[b].yrows.size()));
         nchunk_max = std::max(nchunk_max, Lb.ch_start.size()); nfold_max = std::max(nfold_max, Lb.wf.size());
     }
-    // what the per-lane dimensions do not cover: the dense path (its kernels take Mf from the launch), and the big cone,
-    // whose partial row sits behind the block partials (its position in the fold would move with the unit's maxima)
-    if (hetero && (!Lt.ok || o.dense_trig || Q.big)) throw ShapeError("lock-step batch: lanes differ in shape (dense path / big cone)");
+    // what the per-lane dimensions do not cover: the dense path (its kernels take Mf from the launch)
+    if (hetero && (!Lt.ok || o.dense_trig)) throw ShapeError("lock-step batch: lanes differ in shape (dense path)");
     if (std::getenv("MBFIR_HETERO") && std::atoi(std::getenv("MBFIR_HETERO")) == 0 && hetero) throw ShapeError("lock-step batch: lanes differ in shape (MBFIR_HETERO=0)");
     // ---- sizes -----------------------------------------------------------------------------
     const int R = R_max, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Mf_max;
@@ -2899,7 +2902,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     auto cone_shift = [&](double* v) {
         const int nb = std::max(S.nbC, 1);
         hipLaunchKernelGGL(k_cone_resid, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, v, S.partR);
-        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, v, S.partR + 2L * nb);
+        if (P.big) hipLaunchKernelGGL(k_big_cone_resid, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, v, S.partR);
         hipLaunchKernelGGL(k_cone_fold, lane_grid(dim3(1), nlanes), dim3(256), 0, st, S.partR, nb + (P.big ? 1 : 0), S.RB, S.lane_bytes, P.mask);
         S.allreduce(S.RB, 1, 1);                          // max of the cone distances
         S.allreduce(S.RB + 1, 1, 0);                      // sum of squares
@@ -3049,11 +3052,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         auto launch_body = [&]() {
         // scaling + H
         hipLaunchKernelGGL(k_scaling, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
-        if (P.big) {
-            const long ob = P.l + 3L * P.nq3;
-            hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P.big, S.s + ob, S.z + ob, S.wbb, S.lam + ob, S.Sc,
-                               S.lane_bytes, P.mask);
-        }
+        if (P.big) hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.s, S.z, S.wbb, S.lam, S.Sc);
         S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
         if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
         dd_now = S.dd_k > 0;
@@ -3066,7 +3065,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             hipLaunchKernelGGL(k_dots_r, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
             int nb = std::max(S.nbC, 1);
             if (P.big) {
-                hipLaunchKernelGGL(k_big_dots, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR + 3L * nb);
+                hipLaunchKernelGGL(k_big_dots, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.Sc, z1, zz2, S.scratch, S.partR);
                 nb += 1;
             }
             if (sharded) {
@@ -3084,7 +3083,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                                S.partR2, mode, sharded ? nullptr : S.partR, ndots, xx2);
             if (P.big) {
                 hipLaunchKernelGGL(k_big_dir_post, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
-                                   S.scratch, S.partR2 + 2L * nb, mode);
+                                   S.scratch, S.partR2, mode);
                 nb += 1;
             }
             if (sharded) {

@@ -498,6 +498,31 @@ def test_heterogeneous_unit_of_linear_phase_designs():
         ctx.close()
 
 
+def test_heterogeneous_unit_of_phase_constrained_designs_with_the_big_cone():
+    """fir_qprog_phs (LP half-plane rows + the big cone (t; x)): designs of one order whose band edges differ share a unit too -- the
+    number of half-plane rows moves with the band widths, and the big cone's rows sit behind them, at a per-lane offset.  (The big
+    cone's partial row comes first in every fold since round 4, the block partials behind it, so a lane folds what its single solve
+    folds.)  Every lane bit-identical to its single solve."""
+    base = CASES["qphs21"][1]
+    jobs = []
+    for q in range(5):
+        f = list(base[1]); f[1] += 0.012 * q; f[2] += 0.02 * q
+        jobs.append(("fir_qprog_phs", (base[0], f, base[2], base[3])))
+    ctx = mbfir.Context(0)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=5))
+        assert all(r[2]["lanes"] == 5 for r in res), [r[2]["lanes"] for r in res]
+        assert len({r[2]["n_rows"] for r in res}) >= 3                    # really heterogeneous
+        for job, (h, status, info) in zip(jobs, res):
+            h1, s1, i1 = mbfir.fir_qprog_phs(*job[1], ctx=ctx, info=True)
+            assert s1 == status and i1["iters"] == info["iters"] and info["n_rows"] == i1["n_rows"]
+            if status == "Solved":
+                assert info["pcost"] == i1["pcost"] and np.array_equal(h, h1)
+        assert sum(1 for r in res if r[1] == "Solved") >= 3
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("which", ["fir_linprog", "fir_qprog_phs", "fir_qp_cvx"])
 def test_lock_step_units_of_every_designer_equal_the_single_solves(which):
     """Lock-step units for the other three designers (LP rows only; LP rows + the big cone; Q3 cones + the big cone --
