@@ -1277,6 +1277,112 @@ __device__ int g_dag_log_tasks;        // tasks per lane
 #define DAG_STAT_END(kind)
 #endif
 
+#ifdef CHOL_DAG_PERSIST
+// EXPERIMENT (tools/exp/chol_persist.sh: chol_dag_exp.hip -DCHOL_DAG_PERSIST=<workgroups per lane>; NOT used by the product):
+// persistent workgroups -- every workgroup of a lane draws tickets until they run out instead of one workgroup per task, so that a
+// task does not pay for the dispatch of a workgroup (kernel arguments, LDS allocation).  A ticket is still only drawn by a running
+// workgroup, and a workgroup takes its tickets in increasing order, so every task still only waits for tasks that have started.
+// Measured in round 4 (np = 1024; 24 / 32 / 48 / 64 workgroups per lane): bit-identical and SLOWER everywhere -- 16 lanes alone
+// 540 -> 614-640 us per factorisation, 8 lanes 445 -> 462-507, four units in flight 31.1 -> 34.1-34.9 us per design and build.
+// The dispatcher's own hand-over of a freed slot to the next queued workgroup beats a loop that serialises ticket, polls and
+// loads behind the previous task's drain: dispatch overhead is not what the tasks' slot-time goes into.
+__device__ __forceinline__ void dag_task(CholStep a, int t, int lane, double* smem, const DagCnt& dc) {
+    (void)lane;
+    const long long t_begin = 0; const bool dag_log = false; (void)t_begin; (void)dag_log;
+    int k = 0;
+    DagStep st = dag_step(a.nblk, 0);
+    while (k <= a.nblk && t >= dag_step_tasks(st)) { t -= dag_step_tasks(st); ++k; st = dag_step(a.nblk, k); }
+    if (k > a.nblk) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
+    a.k = k;
+    const int np = a.np;
+    if (t < st.nD) { panel_block<false, true>(a, 0, smem); return; }
+    t -= st.nD;
+    if (t < st.nLA) {
+        // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
+        // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
+        const int i = k + 1 + t, j = k + 1;
+        if (threadIdx.x == 0)
+            wait_flags(dc.at(dc.rowdone, k - 1, i), 4, dc.at(dc.rowdone, k - 1, j), 4, dc.at(dc.tver, i, j), k - 1, a.flag);
+        __syncthreads();
+        const long i0 = (long)i * CB, j0 = (long)j * CB, km = (long)(k - 1) * CB;
+        tile_update<true, true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
+        signal_add(dc.at(dc.tver, i, j));
+        return;
+    }
+    t -= st.nLA;
+    if (t < st.nT) {
+        // trailing update with panel k-1, a strip of row i: A_ij -= L_i,k-1 L_j,k-1'  (k + 2 <= j <= i)
+        int c = 1;
+        while (t >= strips_of(c)) { t -= strips_of(c); ++c; }             // row i = k + 1 + c has c such tiles
+        const int i = k + 1 + c, j0 = k + 2 + STRIP * t, cnt = min(STRIP, c - STRIP * t);
+        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
+            if (q == 0) { w = dc.at(dc.rowdone, k - 1, i); want = 4; }
+            else if (q & 1) { w = dc.at(dc.rowdone, k - 1, j0 + (q - 1) / 2); want = 4; }
+            else { w = dc.at(dc.tver, i, j0 + (q - 2) / 2); want = k - 1; }
+        }, a.flag);
+        const long i0 = (long)i * CB, km = (long)(k - 1) * CB;
+        strip_update<true>(smem, a.H + i0 * np + km, a.H + (long)j0 * CB * np + km, (long)CB * np, a.H + i0 * np + (long)j0 * CB, CB, -1, cnt, np);
+        drain_stores();
+        __syncthreads();
+        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    t -= st.nT;
+    if (t < st.nMS) {
+        minv_strip(a, t, smem);
+        return;
+    }
+    t -= st.nMS;
+    if (t < st.nRU1 + st.nRU) {
+        // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
+        // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
+        int i, j0, cnt;
+        if (t < st.nRU1) { i = k; j0 = t; cnt = 1; }
+        else { t -= st.nRU1; i = k + 1 + t / st.ruc; j0 = STRIP * (t % st.ruc); cnt = min(STRIP, k - 1 - j0); }
+        const long mm = (long)(k - 2) * CB;
+        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
+            if (q == 0) { w = dc.at(dc.rowdone, k - 2, i); want = 4; }
+            else if (q & 1) { w = dc.at(dc.msdone, k - 2, j0 + (q - 1) / 2); want = 4; }
+            else { const int j = j0 + (q - 2) / 2; w = dc.at(dc.ruver, i, j); want = k - 2 - j; }
+        }, a.flag);
+        strip_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j0 * CB, CB, a.M + (long)i * CB * np + (long)j0 * CB, CB,
+                            k - 2 - j0, cnt, np);
+        drain_stores();
+        __syncthreads();
+        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    t -= st.nRU1 + st.nRU;
+    if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); return; }       // tile (k+1, k): four 16-row blocks
+    t -= st.nRq;
+    row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
+}
+
+
+__global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    __shared__ int s_ticket;
+    const int lane = int(blockIdx.x) % a.nlanes;
+    if (a.mask && !a.mask[lane]) return;
+    if (lane) {
+        const size_t off = (size_t)lane * a.lane_bytes;
+        a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
+        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.cnt = lane_at(a.cnt, off);
+        if (a.Mt) a.Mt = lane_at(a.Mt, off);
+    }
+    const DagCnt dc(a.cnt, a.nblk);
+    int ntasks = 0;
+    for (int k = 0; k <= a.nblk; ++k) ntasks += dag_step_tasks(dag_step(a.nblk, k));
+    for (;;) {
+        __syncthreads();                                      // everybody is done with s_ticket and the LDS of the task before
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (t >= ntasks) break;
+        dag_task(a, t, lane, smem, dc);
+    }
+}
+#else
 __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
     __shared__ int s_ticket;
@@ -1366,6 +1472,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
     DAG_STAT_END(4)
 }
+
+#endif
 
 // nsync: ints to clear at sync (the panel flags of the split step, or the counters of the single-launch form);
 // poison (MBFIR_POISON=1, a test switch): the images of the diagonal blocks and 1 / diag(L) are filled with NaN, so that
@@ -1485,7 +1593,11 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         int ntasks = 0;
         for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
         a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
+#ifdef CHOL_DAG_PERSIST
+        hipLaunchKernelGGL(k_chol_dag, dim3(std::min(ntasks, int(CHOL_DAG_PERSIST)) * nlanes), dim3(256), 0, st, a);
+#else
         hipLaunchKernelGGL(k_chol_dag, dim3(ntasks * nlanes), dim3(256), 0, st, a);
+#endif
         if (e1) hipEventRecord(e1, st);
         if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
         return 1;
