@@ -876,6 +876,9 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
 // and drain are serial phases of 1-2 us each, and the chip's 512 slots were full (425 busy on average) -- the
 // factorisation was bound by slot-time, not by its chain.  So a task now walks a STRIP of up to four tiles that share
 // an operand, with the next tile's loads in flight behind the current product and ONE drain + signal at the end.
+#ifndef CHOL_DAG_MS_EARLY
+#define CHOL_DAG_MS_EARLY 0      /* ticket order inside a step: 0: D | LA | T | MS | RU | R ; 1: D | MS | LA | T | RU | R */
+#endif
 #ifndef CHOL_STRIP
 #define CHOL_STRIP 4
 #endif
@@ -1297,6 +1300,15 @@ __device__ __forceinline__ void dag_task(CholStep a, int t, int lane, double* sm
     const int np = a.np;
     if (t < st.nD) { panel_block<false, true>(a, 0, smem); return; }
     t -= st.nD;
+#if CHOL_DAG_MS_EARLY
+    // inverse row k - 1 right behind the diagonal block: its inputs are all from earlier steps, so these tasks never wait -- and they
+    // give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the tile updates that need them poll
+    if (t < st.nMS) {
+        minv_strip(a, t, smem);
+        return;
+    }
+    t -= st.nMS;
+#endif
     if (t < st.nLA) {
         // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
         // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
@@ -1328,11 +1340,13 @@ __device__ __forceinline__ void dag_task(CholStep a, int t, int lane, double* sm
         return;
     }
     t -= st.nT;
+#if !CHOL_DAG_MS_EARLY
     if (t < st.nMS) {
         minv_strip(a, t, smem);
         return;
     }
     t -= st.nMS;
+#endif
     if (t < st.nRU1 + st.nRU) {
         // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
         // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
@@ -1407,6 +1421,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     const int np = a.np;
     if (t < st.nD) { panel_block<false, true>(a, 0, smem); DAG_STAT_END(0) return; }
     t -= st.nD;
+#if CHOL_DAG_MS_EARLY
+    // inverse row k - 1 right behind the diagonal block: its inputs are all from earlier steps, so these tasks never wait -- and they
+    // give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the tile updates that need them poll
+    if (t < st.nMS) {
+        minv_strip(a, t, smem);
+        DAG_STAT_END(2)
+        return;
+    }
+    t -= st.nMS;
+#endif
     if (t < st.nLA) {
         // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
         // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
@@ -1440,12 +1464,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
         return;
     }
     t -= st.nT;
+#if !CHOL_DAG_MS_EARLY
     if (t < st.nMS) {
         minv_strip(a, t, smem);
         DAG_STAT_END(2)
         return;
     }
     t -= st.nMS;
+#endif
     if (t < st.nRU1 + st.nRU) {
         // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
         // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
