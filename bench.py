@@ -293,6 +293,18 @@ def main():
     if args.other_configs_child:
         other_configs_child(args.device, max(1, args.streams))
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves -- a child `python -m torch.distributed.run`, spawned
+        # BEFORE anything in this process touches the GPU (no exec from a process that has initialised it); the ranks' output
+        # (rank 0's JSON line) passes straight through, the child's exit code is ours
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -470,11 +470,16 @@ __device__ __forceinline__ void poll_pause(int spins) {
 // ONE lane polls ONE word (relaxed, agent scope: an sc1 load) until it reaches `want`; false + sentinel on expiry
 #ifdef CHOL_DAG_STATS
 __shared__ long long s_dag_wait;
+__shared__ long long s_ph[9];          // [0..7]: ticks per phase of the task (thread 0's view), [8]: the last stamp
 #define DAG_WAIT_BEGIN const long long tw0 = __builtin_amdgcn_s_memrealtime();
 #define DAG_WAIT_END s_dag_wait += __builtin_amdgcn_s_memrealtime() - tw0;
+// phases: 0 ticket + decode, 1 polls, 2 operands landed, 3 products, 4 product epilogue (subtract, stores issued), 5 substitution
+// passes, 6 drain + signal, 7 other
+#define PH(n) if (threadIdx.x == 0) { const long long ph_now = __builtin_amdgcn_s_memrealtime(); s_ph[(n)] += ph_now - s_ph[8]; s_ph[8] = ph_now; }
 #else
 #define DAG_WAIT_BEGIN
 #define DAG_WAIT_END
+#define PH(n)
 #endif
 __device__ __forceinline__ bool wait_flag(const int* word, int want, int* pivflag) {
     int spins = 0;
@@ -926,6 +931,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
         __syncthreads();                                  // P (first pass) and Q in place
+        PH(2)
         double* dst = D0 + t * dstep;
         const bool first = t == tfirst;
         v4d old[2][2];                                    // the tile's old content (accumulator layout) and the next operand:
@@ -943,6 +949,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
         }
         v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
         mma64<TRANSB>(P, Q, 0, CB, acc);
+        PH(3)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -953,6 +960,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
         acc_foreach(old, [&](int i, int j, double& v) { st_sc1(dst + (long)i * np + j, v); });
 #endif
         __syncthreads();                                  // everybody is done reading Q: free for the next operand
+        PH(4)
     }
 }
 
@@ -975,12 +983,14 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
         else if (t == 1) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
         else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow) : nullptr; want = 4; }
     }, a.flag);
+    PH(1)
     v4d accC[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (k > 0) {
         const long km = kk - CB;
         load_block<true>(X, H + kk * np + km, np);
         load_block<true>(AF, H + r0 * np + km, np);
         __syncthreads();
+        PH(2)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll 4
@@ -990,8 +1000,10 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
             }
         }
     }
+    PH(3)
     if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
     __syncthreads();                                      // also: everybody is done with X and AF
+    PH(1)
     {                                                     // the tile itself (MFMA layout) and the image of L_kk: in flight together
         double hc[4][4];
 #pragma unroll
@@ -1015,6 +1027,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     }
     if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kk + tid);
     __syncthreads();
+    PH(2)
     const int rho = tid >> 4, lam = tid & 15;
 #pragma unroll 1
     for (int q = 0; q < 4; q += 2) {                      // rows 16 q + rho and 16 (q + 1) + rho: two interleaved substitutions
@@ -1028,9 +1041,71 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
             st_sc1(H + (r0 + 16 * q + 16 + rho) * np + kk + lam + 16 * i, vb[i]);
         }
     }
+    PH(5)
     drain_stores();
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(6)
+}
+
+// Trailing tile (i, j), LEFT-LOOKING over the panels p0 .. p1-1:  A_ij -= L_ip L_jp'  one panel after the other, accumulated
+// in the task's registers (operands streamed through LDS, the next pair in flight behind the current product), the tile
+// read once and written once -- the same updates in the same order and with the same arithmetic per update as the
+// read-modify-write strips (each product from zero, then old - product): bit-identical results.
+__device__ __forceinline__ void trail_left(const CholStep& a, int i, int j, int p0, int p1, double* smem) {
+    const int tid = threadIdx.x, np = a.np;
+    const DagCnt dc(a.cnt, a.nblk);
+    const long i0 = (long)i * CB, j0 = (long)j * CB;
+    const int npan = p1 - p0;                             // <= TCHUNK <= 31
+    wait_many(1 + 2 * npan, [&](int t, const int*& w, int& want) {
+        if (t == 0) { w = p0 > 0 ? dc.at(dc.tver, i, j) : nullptr; want = p0; }
+        else { w = dc.at(dc.rowdone, p0 + ((t - 1) >> 1), ((t - 1) & 1) ? j : i); want = 4; }
+    }, a.flag);
+    PH(1)
+    double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
+    double2 at[8], bt[8];
+    auto fetch_pair = [&](int p) {
+        const rsrc_t ra = make_rsrc(a.H + i0 * np + (long)p * CB), rb = make_rsrc(a.H + j0 * np + (long)p * CB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            at[u] = ld2_sc1(ra, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+            bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+        }
+    };
+    fetch_pair(p0);
+    double* dst = a.H + i0 * np + j0;
+    v4d x[2][2];
+    acc_foreach(x, [&](int ii, int jj, double& v) { v = ld_sc1(dst + (long)ii * np + jj); });
+#pragma unroll 1
+    for (int p = p0; p < p1; ++p) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            *reinterpret_cast<double2*>(&P[e >> 5][2 * (e & 31)]) = at[u];
+            *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u];
+        }
+        __syncthreads();
+        PH(2)
+        if (p + 1 < p1) fetch_pair(p + 1);
+        v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+        mma64<true>(P, Q, 0, CB, acc);
+        PH(3)
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[aa][bb][q] = x[aa][bb][q] - acc[aa][bb][q];
+        __syncthreads();                                  // everybody is done reading P and Q
+        PH(4)
+    }
+    acc_foreach(x, [&](int ii, int jj, double& v) { st_sc1(dst + (long)ii * np + jj, v); });
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.tver, i, j), npan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(6)
 }
 
 // Inverse row r = k-1, tile j, LEFT-LOOKING: the task first accumulates  R_rj = - sum_{p = j}^{r-2} L_rp M_pj  in its
@@ -1074,6 +1149,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
         if (2 * npan > 64 && tid == 0)                    // (more than 32 panels: the rest one by one)
             for (int pq = j + 32; pq <= r - 2; ++pq) { wait_flag(dc.at(dc.rowdone, pq, r), 4, a.flag); wait_flag(dc.at(dc.msdone, pq, j), 4, a.flag); }
         __syncthreads();
+        PH(1)
         double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);
         double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
         double2 at[8], bt[8];
@@ -1097,9 +1173,11 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
                 *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u];
             }
             __syncthreads();
+            PH(2)
             if (pq + 1 <= r - 2) fetch_pair(pq + 1);
             v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
             mma64<false>(P, Q, 0, CB, acc);
+            PH(3)
             const bool first = pq == j;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa)
@@ -1108,6 +1186,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 #pragma unroll
                     for (int q = 0; q < 4; ++q) x[aa][bb][q] = first ? -acc[aa][bb][q] : x[aa][bb][q] - acc[aa][bb][q];
             __syncthreads();                              // everybody is done reading P and Q
+            PH(4)
         }
         // accumulator layout -> the layout of the passes, through LDS
         double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
@@ -1120,6 +1199,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rold[ps][h][q] = X[16 * wv + (lane >> 4) + 4 * q][32 * ps + 16 * h + c];
         __syncthreads();                                  // R0 / R1 are free for the image and the passes' staging
+        PH(4)
     } else {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps)
@@ -1134,6 +1214,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
     // ---- row r-1 of the inverse (this column), L_r,r-1 and the image of L_rr
     if (tid == 0) wait_flags(dc.img + r, 1, j < r ? dc.at(dc.rowdone, r - 1, r) : nullptr, 4, j < r ? dc.at(dc.msdone, r - 1, j) : nullptr, 4, a.flag);
     __syncthreads();
+    PH(1)
     {
         const rsrc_t ri = make_rsrc(a.Dfac + kr * CB);
         double2 t[8];
@@ -1174,6 +1255,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
             for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; Bs[e >> 5][e & 31] = bnext[u]; }
         }
         __syncthreads();                                  // Bs (and, first pass, Lz) in place; the previous pass is done with Ct
+        PH(2)
         if (j < r) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -1191,6 +1273,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
             }
         if (pass == 0) fetch(1);                          // in flight behind the substitution
         __syncthreads();
+        PH(3)
         const int rho = tid >> 4, lam = tid & 15;
         double va[4], vb[4];
 #pragma unroll
@@ -1212,10 +1295,12 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 #pragma unroll
             for (int u = 0; u < 8; ++u) dt[u] = Ct[cr * YLD + t8 + u];
         }
+        PH(5)
     }
     drain_stores();
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.msdone, r, j), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(6)
 }
 
 // =================================================================================================
@@ -1238,8 +1323,19 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 //    (tests/test_kernels_gpu.py::test_cholesky_split_step_equals_the_fused_step).
 // Task order inside step k (per lane): D(k) | the tile updates of block column k+1 (what D(k+1) and the row blocks of
 // step k+1 wait for) | the other tile updates | inverse row k-1 (left-looking: its updates included) | row blocks of step k.
-struct DagStep { int nD, nLA, nT, nMS, nRU1, nRU, nRq, nRt, nrem, ruc; };
+struct DagStep { int nD, nLA, nT, nTc, nMS, nRU1, nRU, nRq, nRt, nrem, ruc; };
 __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1) / STRIP; }
+// LEFT-LOOKING trailing updates (round 5; nblk <= 32): a trailing tile (i, j), j >= 3, no longer receives the panels 0 .. j-3 one
+// read-modify-write per panel step (the strips below, which remain for nblk > 32), but in ONE task that accumulates them in
+// registers and writes the tile once (trail_left) -- drawn in step j - 2, when panel j - 3 is complete; panel j - 2 then comes
+// from the look-ahead task of step j - 1 and panel j - 1 inside the row / diagonal block of step j, as before.  A task is
+// capped at TCHUNK panels: the columns further right get the chunk of panels [k - TCHUNK, k) in the steps k that are
+// multiples of TCHUNK (one more read-modify-write of those tiles), so that no task holds its slot for more than TCHUNK products.
+#ifndef CHOL_TCHUNK
+#define CHOL_TCHUNK 8
+#endif
+constexpr int TCHUNK = CHOL_TCHUNK;
+__host__ __device__ inline bool dag_leftT(int nblk) { return nblk <= 32; }
 // ruform: the inverse's trailing updates as tasks of their own (read-modify-write strips, the form of the per-step
 // launches) instead of inside the inverse-row tasks -- for nblk > 32, where a left-looking inverse row would hold its
 // slot for up to 62 products
@@ -1249,9 +1345,14 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     s.nrem = nrem;
     s.nD = k < nblk ? 1 : 0;
     s.nLA = (k >= 1 && k < nblk) ? nrem : 0;              // single tile updates of block column k + 1
-    s.nT = 0;                                             // strips over the tiles (i, j), k + 2 <= j <= i, of each row i:
-    if (k >= 1 && k < nblk && nrem >= 2) {                // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
-        const int m = nrem - 1, q = m / STRIP, r = m % STRIP;
+    s.nT = 0; s.nTc = 0;
+    if (dag_leftT(nblk)) {
+        if (k >= 1 && k < nblk && nrem >= 2) {
+            s.nT = nrem - 1;                              // the tiles of column k + 2: their last (or only) chunk, panels .. k - 1
+            if (k % TCHUNK == 0 && nrem >= 3) s.nTc = (nrem - 2) * (nrem - 1) / 2;     // the full chunk [k - TCHUNK, k) of the columns > k + 2
+        }
+    } else if (k >= 1 && k < nblk && nrem >= 2) {         // strips over the tiles (i, j), k + 2 <= j <= i, of each row i:
+        const int m = nrem - 1, q = m / STRIP, r = m % STRIP;      // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
         s.nT = STRIP * q * (q + 1) / 2 + r * (q + 1);
     }
     s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (its updates by the
@@ -1266,151 +1367,44 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
     return s;
 }
-__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
+__host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nTc + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
 
 #ifdef CHOL_DAG_STATS      /* tools/exp/chol_dag_exp.hip: one record per task of the unit whose H is g_dag_log_H -- kind, begin, end, ticks in polls */
 __device__ long long* g_dag_log;
 __device__ const double* g_dag_log_H;
 __device__ int g_dag_log_tasks;        // tasks per lane
-#define DAG_STAT_BEGIN const long long t_begin = __builtin_amdgcn_s_memrealtime(); const bool dag_log = a.H == g_dag_log_H; if (threadIdx.x == 0) s_dag_wait = 0;
-#define DAG_STAT_END(kind) if (dag_log && threadIdx.x == 0) { long long* rec = g_dag_log + 4 * ((long)lane * g_dag_log_tasks + s_ticket); \
-        rec[0] = (kind); rec[1] = t_begin; rec[2] = __builtin_amdgcn_s_memrealtime(); rec[3] = s_dag_wait; }
+#define DAG_REC 12
+#define DAG_STAT_BEGIN const long long t_begin = __builtin_amdgcn_s_memrealtime(); const bool dag_log = a.H == g_dag_log_H; \
+        if (threadIdx.x == 0) { s_dag_wait = 0; for (int q = 0; q < 8; ++q) s_ph[q] = 0; s_ph[8] = t_begin; }
+#define DAG_STAT_END(kind) if (dag_log && threadIdx.x == 0) { long long* rec = g_dag_log + DAG_REC * ((long)lane * g_dag_log_tasks + s_ticket); \
+        rec[0] = (kind); rec[1] = t_begin; rec[2] = __builtin_amdgcn_s_memrealtime(); rec[3] = s_dag_wait; for (int q = 0; q < 8; ++q) rec[4 + q] = s_ph[q]; }
 #else
 #define DAG_STAT_BEGIN
 #define DAG_STAT_END(kind)
 #endif
 
-#ifdef CHOL_DAG_PERSIST
-// EXPERIMENT (tools/exp/chol_persist.sh: chol_dag_exp.hip -DCHOL_DAG_PERSIST=<workgroups per lane>; NOT used by the product):
-// persistent workgroups -- every workgroup of a lane draws tickets until they run out instead of one workgroup per task, so that a
-// task does not pay for the dispatch of a workgroup (kernel arguments, LDS allocation).  A ticket is still only drawn by a running
-// workgroup, and a workgroup takes its tickets in increasing order, so every task still only waits for tasks that have started.
-// Measured in round 4 (np = 1024; 24 / 32 / 48 / 64 workgroups per lane): bit-identical and SLOWER everywhere -- 16 lanes alone
-// 540 -> 614-640 us per factorisation, 8 lanes 445 -> 462-507, four units in flight 31.1 -> 34.1-34.9 us per design and build.
-// The dispatcher's own hand-over of a freed slot to the next queued workgroup beats a loop that serialises ticket, polls and
-// loads behind the previous task's drain: dispatch overhead is not what the tasks' slot-time goes into.
-__device__ __forceinline__ void dag_task(CholStep a, int t, int lane, double* smem, const DagCnt& dc) {
-    (void)lane;
-    const long long t_begin = 0; const bool dag_log = false; (void)t_begin; (void)dag_log;
-    int k = 0;
-    DagStep st = dag_step(a.nblk, 0);
-    while (k <= a.nblk && t >= dag_step_tasks(st)) { t -= dag_step_tasks(st); ++k; st = dag_step(a.nblk, k); }
-    if (k > a.nblk) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
-    a.k = k;
-    const int np = a.np;
-    if (t < st.nD) { panel_block<false, true>(a, 0, smem); return; }
-    t -= st.nD;
-#if CHOL_DAG_MS_EARLY
-    // inverse row k - 1 right behind the diagonal block: its inputs are all from earlier steps, so these tasks never wait -- and they
-    // give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the tile updates that need them poll
-    if (t < st.nMS) {
-        minv_strip(a, t, smem);
-        return;
-    }
-    t -= st.nMS;
+#ifndef CHOL_PROBE_LDS_PAD
+#define CHOL_PROBE_LDS_PAD 0     /* experiment (tools/exp): extra doubles of LDS per workgroup, to lower the workgroups per CU */
 #endif
-    if (t < st.nLA) {
-        // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
-        // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
-        const int i = k + 1 + t, j = k + 1;
-        if (threadIdx.x == 0)
-            wait_flags(dc.at(dc.rowdone, k - 1, i), 4, dc.at(dc.rowdone, k - 1, j), 4, dc.at(dc.tver, i, j), k - 1, a.flag);
-        __syncthreads();
-        const long i0 = (long)i * CB, j0 = (long)j * CB, km = (long)(k - 1) * CB;
-        tile_update<true, true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
-        signal_add(dc.at(dc.tver, i, j));
-        return;
-    }
-    t -= st.nLA;
-    if (t < st.nT) {
-        // trailing update with panel k-1, a strip of row i: A_ij -= L_i,k-1 L_j,k-1'  (k + 2 <= j <= i)
-        int c = 1;
-        while (t >= strips_of(c)) { t -= strips_of(c); ++c; }             // row i = k + 1 + c has c such tiles
-        const int i = k + 1 + c, j0 = k + 2 + STRIP * t, cnt = min(STRIP, c - STRIP * t);
-        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
-            if (q == 0) { w = dc.at(dc.rowdone, k - 1, i); want = 4; }
-            else if (q & 1) { w = dc.at(dc.rowdone, k - 1, j0 + (q - 1) / 2); want = 4; }
-            else { w = dc.at(dc.tver, i, j0 + (q - 2) / 2); want = k - 1; }
-        }, a.flag);
-        const long i0 = (long)i * CB, km = (long)(k - 1) * CB;
-        strip_update<true>(smem, a.H + i0 * np + km, a.H + (long)j0 * CB * np + km, (long)CB * np, a.H + i0 * np + (long)j0 * CB, CB, -1, cnt, np);
-        drain_stores();
-        __syncthreads();
-        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    t -= st.nT;
-#if !CHOL_DAG_MS_EARLY
-    if (t < st.nMS) {
-        minv_strip(a, t, smem);
-        return;
-    }
-    t -= st.nMS;
-#endif
-    if (t < st.nRU1 + st.nRU) {
-        // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
-        // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
-        int i, j0, cnt;
-        if (t < st.nRU1) { i = k; j0 = t; cnt = 1; }
-        else { t -= st.nRU1; i = k + 1 + t / st.ruc; j0 = STRIP * (t % st.ruc); cnt = min(STRIP, k - 1 - j0); }
-        const long mm = (long)(k - 2) * CB;
-        wait_many(1 + 2 * cnt, [&](int q, const int*& w, int& want) {
-            if (q == 0) { w = dc.at(dc.rowdone, k - 2, i); want = 4; }
-            else if (q & 1) { w = dc.at(dc.msdone, k - 2, j0 + (q - 1) / 2); want = 4; }
-            else { const int j = j0 + (q - 2) / 2; w = dc.at(dc.ruver, i, j); want = k - 2 - j; }
-        }, a.flag);
-        strip_update<false>(smem, a.H + (long)i * CB * np + mm, a.M + mm * np + (long)j0 * CB, CB, a.M + (long)i * CB * np + (long)j0 * CB, CB,
-                            k - 2 - j0, cnt, np);
-        drain_stores();
-        __syncthreads();
-        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    t -= st.nRU1 + st.nRU;
-    if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); return; }       // tile (k+1, k): four 16-row blocks
-    t -= st.nRq;
-    row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
-}
-
-
 __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
-    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS + CHOL_PROBE_LDS_PAD];
     __shared__ int s_ticket;
     const int lane = int(blockIdx.x) % a.nlanes;
-    if (a.mask && !a.mask[lane]) return;
-    if (lane) {
-        const size_t off = (size_t)lane * a.lane_bytes;
-        a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
-        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.cnt = lane_at(a.cnt, off);
-        if (a.Mt) a.Mt = lane_at(a.Mt, off);
-    }
+    a.cnt = lane_at(a.cnt, (size_t)lane * a.lane_bytes);
     const DagCnt dc(a.cnt, a.nblk);
-    int ntasks = 0;
-    for (int k = 0; k <= a.nblk; ++k) ntasks += dag_step_tasks(dag_step(a.nblk, k));
-    for (;;) {
-        __syncthreads();                                      // everybody is done with s_ticket and the LDS of the task before
-        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (t >= ntasks) break;
-        dag_task(a, t, lane, smem, dc);
-    }
-}
-#else
-__global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
-    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
-    __shared__ int s_ticket;
-    const int lane = int(blockIdx.x) % a.nlanes;
+    // the ticket is drawn BEFORE the lane's mask is known (the mask word's load and the atomic's round trip overlap; a switched-off
+    // lane's counter is nobody's: k_chol_init clears it when the lane runs again)
+    int tk = 0;
+    if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.mask && !a.mask[lane]) return;
     if (lane) {
         const size_t off = (size_t)lane * a.lane_bytes;
         a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
-        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off); a.cnt = lane_at(a.cnt, off);
+        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
         if (a.Mt) a.Mt = lane_at(a.Mt, off);
     }
     DAG_STAT_BEGIN
-    const DagCnt dc(a.cnt, a.nblk);
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_ticket = tk;
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(s_ticket);
     int k = 0;
@@ -1419,6 +1413,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     if (k > a.nblk) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
     a.k = k;
     const int np = a.np;
+    PH(0)
     if (t < st.nD) { panel_block<false, true>(a, 0, smem); DAG_STAT_END(0) return; }
     t -= st.nD;
 #if CHOL_DAG_MS_EARLY
@@ -1445,7 +1440,25 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
         return;
     }
     t -= st.nLA;
-    if (t < st.nT) {
+    if (dag_leftT(a.nblk)) {
+        if (t < st.nT + st.nTc) {
+            // left-looking trailing tiles: column k + 2 gets its last chunk of panels (.. k - 1), and in the steps that are
+            // multiples of TCHUNK the columns further right get the full chunk [k - TCHUNK, k)
+            int i, j, p0;
+            if (t < st.nT) { j = k + 2; i = j + t; p0 = ((k - 1) / TCHUNK) * TCHUNK; }
+            else {
+                t -= st.nT;
+                int c = st.nrem - 2;                      // column j = k + 3 has nrem - 2 tiles, the next one fewer, ...
+                j = k + 3;
+                while (t >= c) { t -= c; --c; ++j; }
+                i = j + t; p0 = k - TCHUNK;
+            }
+            trail_left(a, i, j, p0, k, smem);
+            DAG_STAT_END(5)
+            return;
+        }
+        t -= st.nT + st.nTc;
+    } else if (t < st.nT) {
         // trailing update with panel k-1, a strip of row i: A_ij -= L_i,k-1 L_j,k-1'  (k + 2 <= j <= i)
         int c = 1;
         while (t >= strips_of(c)) { t -= strips_of(c); ++c; }             // row i = k + 1 + c has c such tiles
@@ -1455,15 +1468,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
             else if (q & 1) { w = dc.at(dc.rowdone, k - 1, j0 + (q - 1) / 2); want = 4; }
             else { w = dc.at(dc.tver, i, j0 + (q - 2) / 2); want = k - 1; }
         }, a.flag);
+        PH(1)
         const long i0 = (long)i * CB, km = (long)(k - 1) * CB;
         strip_update<true>(smem, a.H + i0 * np + km, a.H + (long)j0 * CB * np + km, (long)CB * np, a.H + i0 * np + (long)j0 * CB, CB, -1, cnt, np);
         drain_stores();
         __syncthreads();
         if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DAG_STAT_END(1)
+        PH(6)
+        DAG_STAT_END(5)
         return;
-    }
-    t -= st.nT;
+    } else t -= st.nT;
 #if !CHOL_DAG_MS_EARLY
     if (t < st.nMS) {
         minv_strip(a, t, smem);
@@ -1498,8 +1512,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
     DAG_STAT_END(4)
 }
-
-#endif
 
 // nsync: ints to clear at sync (the panel flags of the split step, or the counters of the single-launch form);
 // poison (MBFIR_POISON=1, a test switch): the images of the diagonal blocks and 1 / diag(L) are filled with NaN, so that
@@ -1619,11 +1631,7 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         int ntasks = 0;
         for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
         a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
-#ifdef CHOL_DAG_PERSIST
-        hipLaunchKernelGGL(k_chol_dag, dim3(std::min(ntasks, int(CHOL_DAG_PERSIST)) * nlanes), dim3(256), 0, st, a);
-#else
         hipLaunchKernelGGL(k_chol_dag, dim3(ntasks * nlanes), dim3(256), 0, st, a);
-#endif
         if (e1) hipEventRecord(e1, st);
         if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
         return 1;

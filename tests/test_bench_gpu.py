@@ -105,3 +105,18 @@ def test_two_rank_batch_bench_carries_the_shard_leg():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * 8) < 1e-6 * d["value"] * d["ms_per_step"]      # both ranks' designs
     assert "error" not in d["shard"] and d["shard"]["scaling"] == "strong" and d["shard"]["value"] > 0
+
+
+def test_plain_bench_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment (the form of the driver's N = 1 command): bench.py
+    spawns its two ranks itself and passes rank 0's one JSON line and the child's exit code through."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "1", "--taps", "64", "--grid-m", "1024", "--designs", "8", "--lanes", "4", "--streams", "2",
+                        "--no-shard", "--cpu-iters", "0", "--no-other-configs"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0

@@ -66,39 +66,45 @@ static void dag_log_on(const Unit& u) {
     int nt = 0;
     for (int k = 0; k <= u.np / 64; ++k) nt += dag_step_tasks(dag_step(u.np / 64, k));
     log_tasks = nt; log_lanes = u.nl;
-    if (!d_log) hipMalloc(&d_log, sizeof(long long) * 4 * (size_t)nt * 64);
-    hipMemset(d_log, 0, sizeof(long long) * 4 * (size_t)nt * u.nl);
+    if (!d_log) hipMalloc(&d_log, sizeof(long long) * DAG_REC * (size_t)nt * 64);
+    hipMemset(d_log, 0, sizeof(long long) * DAG_REC * (size_t)nt * u.nl);
     const double* hp = u.dH;
     hipMemcpyToSymbol(HIP_SYMBOL(g_dag_log), &d_log, sizeof(d_log)); hipMemcpyToSymbol(HIP_SYMBOL(g_dag_log_H), &hp, sizeof(hp));
     hipMemcpyToSymbol(HIP_SYMBOL(g_dag_log_tasks), &nt, sizeof(nt));
 }
 static void dag_stats(const char* what) {
     hipDeviceSynchronize();
-    std::vector<long long> L(4 * (size_t)log_tasks * log_lanes);
+    std::vector<long long> L(DAG_REC * (size_t)log_tasks * log_lanes);
     hipMemcpy(L.data(), d_log, L.size() * 8, hipMemcpyDeviceToHost);
-    const char* names[5] = {"D (diagonal block)", "T (tile update)", "MS (inverse row)", "RU (inverse update)", "R (row block)"};
-    double cnt[5] = {0}, dur[5] = {0}, wt[5] = {0};
+    const int NK = 6;
+    const char* names[NK] = {"D (diagonal block)", "LA (look-ahead tile)", "MS (inverse row)", "RU (inverse update)", "R (row block)", "T (strip)"};
+    double cnt[NK] = {0}, dur[NK] = {0}, wt[NK] = {0}, ph[NK][8] = {{0}};
     long long t0 = 0, t1 = 0;
     for (size_t q = 0; q < (size_t)log_tasks * log_lanes; ++q) {
-        const long long* r = &L[4 * q];
+        const long long* r = &L[DAG_REC * q];
         if (!r[1]) continue;
         cnt[r[0]] += 1; dur[r[0]] += double(r[2] - r[1]); wt[r[0]] += double(r[3]);
+        for (int f = 0; f < 8; ++f) ph[r[0]][f] += double(r[4 + f]);
         if (!t0 || r[1] < t0) t0 = r[1];
         if (r[2] > t1) t1 = r[2];
     }
     double tot = 0, totw = 0;
-    for (int q = 0; q < 5; ++q) { tot += dur[q]; totw += wt[q]; }
+    for (int q = 0; q < NK; ++q) { tot += dur[q]; totw += wt[q]; }
     printf("task statistics of one build of one unit, %s: first start to last end %.1f us; workgroup-time %.1f ms = %.1f slots busy on average; %.1f %% of it in polls\n",
            what, 0.01 * double(t1 - t0), 1e-5 * tot, tot / double(t1 - t0), 100.0 * totw / tot);
-    for (int q = 0; q < 5; ++q)
-        printf("  %-22s %6.0f tasks  %6.2f us each, of which %5.2f us in polls   %5.1f %% of the workgroup-time\n", names[q], cnt[q], cnt[q] ? 0.01 * dur[q] / cnt[q] : 0.0,
+    for (int q = 0; q < NK; ++q) {
+        if (!cnt[q]) continue;
+        printf("  %-22s %6.0f tasks  %6.2f us each, of which %5.2f us in polls   %5.1f %% of the workgroup-time", names[q], cnt[q], cnt[q] ? 0.01 * dur[q] / cnt[q] : 0.0,
                cnt[q] ? 0.01 * wt[q] / cnt[q] : 0.0, 100.0 * dur[q] / tot);
+        printf("   phases (us per task) ticket %.2f poll %.2f landed %.2f products %.2f epilogue %.2f subst %.2f drain %.2f\n", 0.01 * ph[q][0] / cnt[q], 0.01 * ph[q][1] / cnt[q],
+               0.01 * ph[q][2] / cnt[q], 0.01 * ph[q][3] / cnt[q], 0.01 * ph[q][4] / cnt[q], 0.01 * ph[q][5] / cnt[q], 0.01 * ph[q][6] / cnt[q]);
+    }
     // the chain: start-to-start of the diagonal blocks of lane 0
     printf("  lane 0 diagonal blocks (start, duration, in polls; us):");
     long long prev = 0;
     int tk = 0;
     for (int k = 0; k < log_tasks && tk < 17; ++k) {
-        const long long* r = &L[4 * (size_t)k];
+        const long long* r = &L[DAG_REC * (size_t)k];
         if (r[1] && r[0] == 0) { printf(" [%.1f %.1f %.1f]", prev ? 0.01 * double(r[1] - prev) : 0.0, 0.01 * double(r[2] - r[1]), 0.01 * double(r[3])); prev = r[1]; ++tk; }
     }
     printf("\n");
