@@ -14,8 +14,12 @@ constexpr int CB = 64;       // panel width
 constexpr int CLD = 66;      // padded LDS leading dimension
 
 // ---- 64x64 MFMA helper: each of the 4 waves owns a 32x32 quadrant (2x2 MFMA blocks) -----------
-// acc[a][b] += sum_k  Aop[i][k] * Bop[k][j]   with  Aop[i][k] = As[i][k]  (As row-major [64][CLD])
+// acc[a][b] -= sum_k  Aop[i][k] * Bop[k][j]   with  Aop[i][k] = As[i][k]  (As row-major [64][CLD])
 // and Bop[k][j] = transB ? Bs[j][k] : Bs[k][j].
+// Every tile update of this file ACCUMULATES INTO THE OLD VALUE (round 5): the accumulator starts as the tile's current
+// content and the sixteen MFMAs of a 64-deep product, with the A operand negated, run on it -- no product from zero followed
+// by a subtraction.  One rounding less per update and half the accumulator registers of a task that keeps a tile in
+// registers over several panels; every form of the factorisation does the same, so they stay bit-identical to one another.
 template <bool TRANSB>
 __device__ __forceinline__ void mma64(const double (*As)[CLD], const double (*Bs)[CLD], int kbeg, int kend,
                                       v4d acc[2][2]) {
@@ -25,7 +29,7 @@ __device__ __forceinline__ void mma64(const double (*As)[CLD], const double (*Bs
         const int k = k0 + (lane >> 4);
         double af[2], bf[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) af[a] = As[wi * 32 + a * 16 + (lane & 15)][k];
+        for (int a = 0; a < 2; ++a) af[a] = -As[wi * 32 + a * 16 + (lane & 15)][k];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int j = wj * 32 + b * 16 + (lane & 15);
@@ -365,46 +369,21 @@ __device__ __forceinline__ void tile_decode(int t, int& ti, int& tj) {
     tj = t - ti * (ti + 1) / 2;
 }
 
-// C_tile (64x64 at dst) -= A_tile * B_tile (TRANSB: B_tile') through the MFMA helper
+// C_tile (64x64 at dst) -= A_tile * B_tile (TRANSB: B_tile') through the MFMA helper, accumulated into the old tile
 // first: the tile has not been written in this factorisation yet -- its old content (the previous build's) counts as 0
-// DAG (single-launch factorisation): operands and the old tile come from / the result goes to other workgroups of the
-// same launch: sc1 accesses, 16 bytes each -- the product is restaged through LDS from the accumulator layout to whole
-// row segments (an 8-byte write-through store costs 2.7x a 16-byte one per byte); same arithmetic, old - product.
-template <bool TRANSB, bool DAG = false>
+// (the per-step forms; the single-launch form's single-tile updates go through strip_update)
+template <bool TRANSB>
 __device__ __forceinline__ void tile_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ Bg,
                                             double* __restrict__ dst, int np, bool first = false) {
     double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
     double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
-    load_block<DAG>(P, Ag, np);
-    load_block<DAG>(Q, Bg, np);
-    double2 old[8];
-    rsrc_t rd;
-    if constexpr (DAG) {
-        rd = make_rsrc(dst);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = threadIdx.x + 256 * u;
-            old[u] = first ? make_double2(0.0, 0.0) : ld2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
-        }
-    }
+    load_block<false>(P, Ag, np);
+    load_block<false>(Q, Bg, np);
+    v4d acc[2][2];
+    acc_foreach(acc, [&](int i, int j, double& v) { v = first ? 0.0 : dst[(long)i * np + j]; });
     __syncthreads();
-    v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
     mma64<TRANSB>(P, Q, 0, CB, acc);
-    if constexpr (DAG) {
-        __syncthreads();                                  // everybody is done reading P
-        acc_foreach(acc, [&](int i, int j, double v) { P[i][j] = v; });
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = threadIdx.x + 256 * u;
-            const double2 pr = *reinterpret_cast<const double2*>(&P[e >> 5][2 * (e & 31)]);
-            const double2 x = first ? make_double2(-pr.x, -pr.y) : make_double2(old[u].x - pr.x, old[u].y - pr.y);
-            st2_sc1(rd, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8), x);
-        }
-    } else {
-        if (first) acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] = -v; });
-        else acc_foreach(acc, [&](int i, int j, double v) { dst[(long)i * np + j] -= v; });
-    }
+    acc_foreach(acc, [&](int i, int j, double& v) { dst[(long)i * np + j] = v; });
 }
 
 #ifdef CHOL_TRACE
@@ -556,24 +535,23 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     // the wave's tiles of S = A_kk - L_k,k-1 L_k,k-1' (lower triangle, 16x16 tiles, MFMA D layout)
     const unsigned tiles = wave_tiles(wv);
     const int nt = int(tiles >> 12), m16 = lane & 15, g4 = lane >> 4;
+    // the accumulators start as the tiles of A_kk / the rows of A_ik the panel k-1 update is applied to (see mma64)
     v4d acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     v4d accC = {0, 0, 0, 0};
-    // the tiles of A_kk / A_ik the products are subtracted from: loads issued first, used after the products
-    double hv[3][4], hc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double* src = H + (kk + 16 * ti + g4 + 4 * r) * np + kk + 16 * tj + m16;
-            hv[q][r] = (!FROM_IMAGE && q < nt) ? (DAG ? ld_sc1(src) : *src) : 0.0;
+            acc[q][r] = (!FROM_IMAGE && q < nt) ? (DAG ? ld_sc1(src) : *src) : 0.0;
         }
     }
     if (rows) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double* src = H + (r0 + g4 + 4 * r) * np + kk + 16 * wv + m16;
-            hc[r] = DAG ? ld_sc1(src) : *src;
+            accC[r] = DAG ? ld_sc1(src) : *src;
         }
     }
     TRACE(0)
@@ -608,7 +586,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
 #pragma unroll 4
                 for (int k0 = 0; k0 < CB; k0 += 4) {
                     const int kx = k0 + g4;
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[16 * ti + m16][kx], X[16 * tj + m16][kx], acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[16 * ti + m16][kx], X[16 * tj + m16][kx], acc[q], 0, 0, 0);
                 }
             }
         }
@@ -616,18 +594,11 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
 #pragma unroll 4
             for (int k0 = 0; k0 < CB; k0 += 4) {
                 const int kx = k0 + g4;
-                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(AR[m16][kx], X[16 * wv + m16][kx], accC, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(-AR[m16][kx], X[16 * wv + m16][kx], accC, 0, 0, 0);
             }
         }
     }
     TRACE(2)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (q < nt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = hv[q][r] - acc[q][r];
-        }
-    }
     if (tid < CB) dsh[tid] = a.d0[kk + tid];
     double* LB = smem + R1;                               // 64 x LBLD: slabs, then S_rc of the whole lower triangle
     double* LS = smem + R2;                               // 64 x LSLD: the current slab scaled by -1 / pivot
@@ -678,7 +649,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = (lane >> 4) + 4 * r;
-            Y[rr * YLD + cc] = hc[r] - accC[r];
+            Y[rr * YLD + cc] = accC[r];
         }
     }
     __syncthreads();
@@ -758,7 +729,18 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
         }
     }
     if (tid < CB) dinv[tid] = DAG ? ld_sc1(a.dinvG + kr + tid) : a.dinvG[kr + tid];
-    v4d acc = {0, 0, 0, 0};
+    // the accumulator starts as R_rj as the updates left it; tiles no update ever reached hold the previous build's numbers
+    // and stand for their initial value: the identity on the diagonal (j == r), zero next to it (j == r - 1)
+    v4d acc;
+    {
+        const int c = lane & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 16 * wv + (lane >> 4) + 4 * q;
+            const double* src = M + (kr + t) * np + (long)j * CB + c0 + c;
+            acc[q] = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : (DAG ? ld_sc1(src) : *src);
+        }
+    }
     if (j < r) {
         load_block<DAG>(A2, a.H + kr * np + kr - CB, np);
         {
@@ -776,21 +758,14 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
 #pragma unroll 4
         for (int k0 = 0; k0 < CB; k0 += 4) {
             const int kx = k0 + (lane >> 4);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
         }
     }
     __syncthreads();
     {
-        // R_rj as the updates left it; tiles no update ever reached hold the previous build's numbers and stand for
-        // their initial value: the identity on the diagonal (j == r), zero next to it (j == r - 1)
         const int c = lane & 15;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int t = 16 * wv + (lane >> 4) + 4 * q;
-            const double* src = M + (kr + t) * np + (long)j * CB + c0 + c;
-            const double r0 = j == r ? (t == c0 + c ? 1.0 : 0.0) : j == r - 1 ? 0.0 : (DAG ? ld_sc1(src) : *src);
-            Ct[c * YLD + t] = r0 - acc[q];
-        }
+        for (int q = 0; q < 4; ++q) Ct[c * YLD + 16 * wv + (lane >> 4) + 4 * q] = acc[q];
     }
     __syncthreads();
     const int rho = tid >> 4, lam = tid & 15;
@@ -909,10 +884,10 @@ __device__ __forceinline__ void wait_many(int n, F get, int* pivflag) {
 }
 
 // dst_t -= A * B_t (TRANSB: B_t')  for t < cnt, with B_t = B0 + t * bstep, dst_t = D0 + t * dstep and A (64x64 at Ag)
-// shared by the strip; tile tfirst (if any) has not been written in this factorisation yet: see tile_update.
-// The old tile is read and the result written straight in the accumulator layout (8-byte write-through accesses: 16 lanes
-// cover one 128-byte line of a row, so every line is still written whole by one wave instruction) -- no restaging
-// through LDS, two barriers fewer per tile than the 16-byte form of tile_update<.., true>.
+// shared by the strip; tile tfirst (if any) has not been written in this factorisation yet: its old content counts as 0.
+// The old tile is read straight into the accumulator layout (8-byte write-through accesses: 16 lanes cover one 128-byte
+// line of a row, so every line is still written whole by one wave instruction) and IS the accumulator of the product
+// (mma64); the next tile's operand and old content are in flight behind the current product.
 template <bool TRANSB>
 __device__ __forceinline__ void strip_update(double* smem, const double* __restrict__ Ag, const double* __restrict__ B0, long bstep,
                                              double* __restrict__ D0, long dstep, int tfirst, int cnt, int np) {
@@ -921,43 +896,39 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
     const int tid = threadIdx.x;
     load_block<true>(P, Ag, np);
     double2 bt[8];
-    {
-        const rsrc_t rb = make_rsrc(B0);
+    v4d nxt[2][2];
+    auto fetch = [&](int t) {
+        const rsrc_t rb = make_rsrc(B0 + t * bstep);
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
-    }
-#pragma unroll 1
-    for (int t = 0; t < cnt; ++t) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
-        __syncthreads();                                  // P (first pass) and Q in place
-        PH(2)
-        double* dst = D0 + t * dstep;
+        const double* dst = D0 + t * dstep;
         const bool first = t == tfirst;
-        v4d old[2][2];                                    // the tile's old content (accumulator layout) and the next operand:
-        acc_foreach(old, [&](int i, int j, double& v) {   // in flight behind the product
+        acc_foreach(nxt, [&](int i, int j, double& v) {
 #ifdef CHOL_EXP_NO_RMW      /* timing experiment only (tools/exp): no read of the old tile */
             v = 0.0;
 #else
             v = first ? 0.0 : ld_sc1(dst + (long)i * np + j);
 #endif
         });
-        if (t + 1 < cnt) {
-            const rsrc_t rb = make_rsrc(B0 + (t + 1) * bstep);
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int t = 0; t < cnt; ++t) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
-        }
-        v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-        mma64<TRANSB>(P, Q, 0, CB, acc);
-        PH(3)
+        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
+        v4d acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) old[a][b][r] = first ? -acc[a][b][r] : old[a][b][r] - acc[a][b][r];
+            for (int b = 0; b < 2; ++b) acc[a][b] = nxt[a][b];
+        __syncthreads();                                  // P (first pass) and Q in place
+        PH(2)
+        double* dst = D0 + t * dstep;
+        if (t + 1 < cnt) fetch(t + 1);
+        mma64<TRANSB>(P, Q, 0, CB, acc);
+        PH(3)
 #ifndef CHOL_EXP_NO_RMW     /* (the timing experiment does not write either) */
-        acc_foreach(old, [&](int i, int j, double& v) { st_sc1(dst + (long)i * np + j, v); });
+        acc_foreach(acc, [&](int i, int j, double& v) { st_sc1(dst + (long)i * np + j, v); });
 #endif
         __syncthreads();                                  // everybody is done reading Q: free for the next operand
         PH(4)
@@ -984,7 +955,11 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
         else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow) : nullptr; want = 4; }
     }, a.flag);
     PH(1)
-    v4d accC[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4d accC[4];                                          // the tile itself (MFMA layout): the accumulator of the panel k-1 update
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accC[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
     if (k > 0) {
         const long km = kk - CB;
         load_block<true>(X, H + kk * np + km, np);
@@ -996,7 +971,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
 #pragma unroll 4
             for (int k0 = 0; k0 < CB; k0 += 4) {
                 const int kx = k0 + g4;
-                accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(AF[16 * q + m16][kx], X[16 * wv + m16][kx], accC[q], 0, 0, 0);
+                accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-AF[16 * q + m16][kx], X[16 * wv + m16][kx], accC[q], 0, 0, 0);
             }
         }
     }
@@ -1004,12 +979,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
     __syncthreads();                                      // also: everybody is done with X and AF
     PH(1)
-    {                                                     // the tile itself (MFMA layout) and the image of L_kk: in flight together
-        double hc[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hc[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
+    {                                                     // the image of L_kk
         const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
         double2 t[8];
 #pragma unroll
@@ -1018,7 +988,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = hc[q][r] - accC[q][r];
+            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = accC[q][r];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = 2 * (tid + 256 * u);
@@ -1051,7 +1021,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
 // Trailing tile (i, j), LEFT-LOOKING over the panels p0 .. p1-1:  A_ij -= L_ip L_jp'  one panel after the other, accumulated
 // in the task's registers (operands streamed through LDS, the next pair in flight behind the current product), the tile
 // read once and written once -- the same updates in the same order and with the same arithmetic per update as the
-// read-modify-write strips (each product from zero, then old - product): bit-identical results.
+// read-modify-write strips (each product accumulated into the tile's value, see mma64): bit-identical results.
 __device__ __forceinline__ void trail_left(const CholStep& a, int i, int j, int p0, int p1, double* smem) {
     const int tid = threadIdx.x, np = a.np;
     const DagCnt dc(a.cnt, a.nblk);
@@ -1089,15 +1059,8 @@ __device__ __forceinline__ void trail_left(const CholStep& a, int i, int j, int 
         __syncthreads();
         PH(2)
         if (p + 1 < p1) fetch_pair(p + 1);
-        v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-        mma64<true>(P, Q, 0, CB, acc);
+        mma64<true>(P, Q, 0, CB, x);
         PH(3)
-#pragma unroll
-        for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x[aa][bb][q] = x[aa][bb][q] - acc[aa][bb][q];
         __syncthreads();                                  // everybody is done reading P and Q
         PH(4)
     }
@@ -1175,16 +1138,8 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
             __syncthreads();
             PH(2)
             if (pq + 1 <= r - 2) fetch_pair(pq + 1);
-            v4d acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-            mma64<false>(P, Q, 0, CB, acc);
+            mma64<false>(P, Q, 0, CB, x);                 // (the first update writes the negated product: x starts as zero)
             PH(3)
-            const bool first = pq == j;
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[aa][bb][q] = first ? -acc[aa][bb][q] : x[aa][bb][q] - acc[aa][bb][q];
             __syncthreads();                              // everybody is done reading P and Q
             PH(4)
         }
@@ -1227,10 +1182,10 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
         }
     }
     if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + tid);
-    double af[16];                                        // L_r,r-1: row 16 wv + (lane & 15), columns 4 q + (lane >> 4)
+    double af[16];                                        // -L_r,r-1: row 16 wv + (lane & 15), columns 4 q + (lane >> 4) (negated: see mma64)
     if (j < r) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) af[q] = ld_sc1(a.H + (kr + 16 * wv + (lane & 15)) * np + kr - CB + 4 * q + (lane >> 4));
+        for (int q = 0; q < 16; ++q) af[q] = -ld_sc1(a.H + (kr + 16 * wv + (lane & 15)) * np + kr - CB + 4 * q + (lane >> 4));
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) af[q] = 0.0;
@@ -1249,7 +1204,11 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int c0 = 32 * pass;
-        v4d acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        v4d acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[h][q] = rold[pass][h][q];
         if (j < r) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; Bs[e >> 5][e & 31] = bnext[u]; }
@@ -1269,7 +1228,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int t = 16 * wv + (lane >> 4) + 4 * q;
-                Ct[(16 * h + c) * YLD + t] = rold[pass][h][q] - acc[h][q];
+                Ct[(16 * h + c) * YLD + t] = acc[h][q];
             }
         if (pass == 0) fetch(1);                          // in flight behind the substitution
         __syncthreads();
@@ -1434,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
             wait_flags(dc.at(dc.rowdone, k - 1, i), 4, dc.at(dc.rowdone, k - 1, j), 4, dc.at(dc.tver, i, j), k - 1, a.flag);
         __syncthreads();
         const long i0 = (long)i * CB, j0 = (long)j * CB, km = (long)(k - 1) * CB;
-        tile_update<true, true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, a.H + i0 * np + j0, np);
+        strip_update<true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, 0, a.H + i0 * np + j0, 0, -1, 1, np);
         signal_add(dc.at(dc.tver, i, j));
         DAG_STAT_END(1)
         return;
