@@ -20,9 +20,19 @@ constexpr int CLD = 66;      // padded LDS leading dimension
 // content and the sixteen MFMAs of a 64-deep product, with the A operand negated, run on it -- no product from zero followed
 // by a subtraction.  One rounding less per update and half the accumulator registers of a task that keeps a tile in
 // registers over several panels; every form of the factorisation does the same, so they stay bit-identical to one another.
+// timing experiments (tools/exp only; the results are wrong): -DCHOL_EXP_NO_MFMA the tile products' k-loops are skipped,
+// -DCHOL_EXP_NO_SUBST the 64-step substitutions
+#ifdef CHOL_EXP_NO_MFMA
+#define CHOL_KSTEPS(n) 1
+#else
+#define CHOL_KSTEPS(n) (n)
+#endif
 template <bool TRANSB>
 __device__ __forceinline__ void mma64(const double (*As)[CLD], const double (*Bs)[CLD], int kbeg, int kend,
                                       v4d acc[2][2]) {
+#ifdef CHOL_EXP_NO_MFMA
+    kend = kbeg + 4;
+#endif
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wi = wv >> 1, wj = wv & 1;
     for (int k0 = kbeg; k0 < kend; k0 += 4) {
@@ -83,6 +93,19 @@ __device__ __forceinline__ void st2_sc1(rsrc_t r, unsigned byte_off, double2 x) 
     v.x = unsigned(__double2loint(x.x)); v.y = unsigned(__double2hiint(x.x));
     v.z = unsigned(__double2loint(x.y)); v.w = unsigned(__double2hiint(x.y));
     __builtin_amdgcn_raw_buffer_store_b128(v, r, int(byte_off), 0, 16);
+}
+// 8-byte forms through a buffer resource: ONE 32-bit per-lane offset register serves every access of a task (the wave-uniform
+// part of the address -- a row stride times a small count, a panel -- goes into the scalar offset, the rest into the
+// instruction's immediate), where global_load / store would keep a 64-bit address pair per row alive
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ldb_sc1(rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, int(voff), int(soff), 16);
+    return __hiloint2double(int(v.y), int(v.x));
+}
+__device__ __forceinline__ void stb_sc1(rsrc_t r, unsigned voff, unsigned soff, double x) {
+    v2u v;
+    v.x = unsigned(__double2loint(x)); v.y = unsigned(__double2hiint(x));
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, int(voff), int(soff), 16);
 }
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -169,10 +192,15 @@ __device__ __forceinline__ double row_bcast(double v) {
     return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + LANE, 0xF, 0xF, true);     // row_newbcast:LANE
 }
 
+#ifdef CHOL_EXP_NO_SUBST
+constexpr int SUBST_STEPS = 1;
+#else
+constexpr int SUBST_STEPS = 64;
+#endif
 template <int J>
 __device__ __forceinline__ void subst16_steps(const double* __restrict__ lz, double dm0, double dm1, double dm2, double dm3,
                                               double& v0, double& v1, double& v2, double& v3) {
-    if constexpr (J < 64) {
+    if constexpr (J < SUBST_STEPS) {
         constexpr int I = J >> 4;
         const double cur = I == 0 ? v0 * dm0 : I == 1 ? v1 * dm1 : I == 2 ? v2 * dm2 : v3 * dm3;
         const double x = row_bcast<(J & 15)>(cur);
@@ -204,8 +232,11 @@ __device__ __forceinline__ void subst16(const double* __restrict__ Lz, const dou
 template <int J>
 __device__ __forceinline__ void subst16x2_steps(const double* __restrict__ lz, double dm0, double dm1, double dm2, double dm3,
                                                 double& a0, double& a1, double& a2, double& a3, double& b0, double& b1, double& b2, double& b3) {
-    if constexpr (J < 64) {
+    if constexpr (J < SUBST_STEPS) {
         constexpr int I = J >> 4;
+        // (the image's LDS reads of all 64 steps have constant offsets from one base: left alone, the scheduler may cluster
+        //  them far ahead of their steps -- 256 registers' worth -- and the allocator then spills; keep them within 8 steps)
+        if constexpr (J % 8 == 0 && J > 0) __builtin_amdgcn_sched_barrier(0);
         const double ca = I == 0 ? a0 * dm0 : I == 1 ? a1 * dm1 : I == 2 ? a2 * dm2 : a3 * dm3;
         const double cb = I == 0 ? b0 * dm0 : I == 1 ? b1 * dm1 : I == 2 ? b2 * dm2 : b3 * dm3;
         const double xa = row_bcast<(J & 15)>(ca), xb = row_bcast<(J & 15)>(cb);
@@ -431,6 +462,9 @@ __device__ int g_chol_lose_step = -1;
 #define CHOL_SPIN_LIMIT g_chol_spin_limit
 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the thread index as a value of its own per task: the compiler then cannot merge the address arithmetic of different task kinds
+// and hoist it to the top of the single-launch kernel, where it would have to live -- or spill -- through every task's branch
+__device__ __forceinline__ int task_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 // pause between two polls: short at first (a hand-off on the chain is noticed quickly), longer when the wait drags on --
 // hundreds of resident workgroups polling a handful of cache lines every 0.1 us slow down the very atomics they wait for
 #ifndef CHOL_BACKOFF
@@ -584,7 +618,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
             const int ti = (tiles >> (4 * q)) & 3, tj = (tiles >> (4 * q + 2)) & 3;
             if (!FROM_IMAGE && q < nt) {
 #pragma unroll 4
-                for (int k0 = 0; k0 < CB; k0 += 4) {
+                for (int k0 = 0; k0 < CHOL_KSTEPS(CB); k0 += 4) {
                     const int kx = k0 + g4;
                     acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[16 * ti + m16][kx], X[16 * tj + m16][kx], acc[q], 0, 0, 0);
                 }
@@ -592,7 +626,7 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
         }
         if (rows) {
 #pragma unroll 4
-            for (int k0 = 0; k0 < CB; k0 += 4) {
+            for (int k0 = 0; k0 < CHOL_KSTEPS(CB); k0 += 4) {
                 const int kx = k0 + g4;
                 accC = __builtin_amdgcn_mfma_f64_16x16x4f64(-AR[m16][kx], X[16 * wv + m16][kx], accC, 0, 0, 0);
             }
@@ -756,7 +790,7 @@ __device__ __forceinline__ void minv_block(const CholStep& a, int b, double* sme
         }
         __syncthreads();
 #pragma unroll 4
-        for (int k0 = 0; k0 < CB; k0 += 4) {
+        for (int k0 = 0; k0 < CHOL_KSTEPS(CB); k0 += 4) {
             const int kx = k0 + (lane >> 4);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A2[16 * wv + (lane & 15)][kx], Bs[kx][lane & 15], acc, 0, 0, 0);
         }
@@ -857,7 +891,7 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
 // factorisation was bound by slot-time, not by its chain.  So a task now walks a STRIP of up to four tiles that share
 // an operand, with the next tile's loads in flight behind the current product and ONE drain + signal at the end.
 #ifndef CHOL_DAG_MS_EARLY
-#define CHOL_DAG_MS_EARLY 0      /* ticket order inside a step: 0: D | LA | T | MS | RU | R ; 1: D | MS | LA | T | RU | R */
+#define CHOL_DAG_MS_EARLY 1      /* ticket order inside a step: 0: D | LA | T | MS | RU | R ; 1: D | LA | MS | T | RU | R */
 #endif
 #ifndef CHOL_STRIP
 #define CHOL_STRIP 4
@@ -893,7 +927,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
                                              double* __restrict__ D0, long dstep, int tfirst, int cnt, int np) {
     double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem);
     double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + CB * CLD);
-    const int tid = threadIdx.x;
+    const int tid = task_tid();
     load_block<true>(P, Ag, np);
     double2 bt[8];
     v4d nxt[2][2];
@@ -935,60 +969,83 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
     }
 }
 
-// Row blocks of ONE tile (i, k), all 64 rows: the panel k-1 update of the tile (operands loaded once), then two passes
-// of two interleaved 16-row substitutions against the image of L_kk.  Same arithmetic per row as panel_block<true>.
-__device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, double* smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// Row blocks of ONE tile (i, k), all 64 rows: the updates by the panels p0 .. k-1 (p0 = k-2 in the left-looking form: the
+// look-ahead update of a tile off the chain rides here, in the shadow of the diagonal block this task waits for anyway --
+// one task, one read-modify-write of the tile and one set of polls less per tile), then two passes of two interleaved 16-row
+// substitutions against the image of L_kk.  A wave owns 16 rows and all 64 columns, its rows of L_ip in registers in the matrix
+// cores' operand layout (see trail_left2); L_kp goes through LDS.  Same arithmetic per row as panel_block<true>.
+__device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, int p0, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
     const int k = a.k, np = a.np;
-    double* H = a.H;
     const long kk = (long)k * CB, r0 = (long)irow * CB;
-    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the staging tile Y
-    double(*AF)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);    // L_i,k-1 (all 64 rows), later the image of L_kk
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_kp, later the staging tile Y
     double* Y = smem + R0;
     double* Lz = smem + R1;
     double* dinv = smem + R3 + CB;
     const DagCnt dc(a.cnt, a.nblk);
-    const int m16 = lane & 15, g4 = lane >> 4;
-    wait_many(3, [&](int t, const int*& w, int& want) {
-        if (t == 0) { w = k >= 2 ? dc.at(dc.tver, irow, k) : nullptr; want = k - 1; }
-        else if (t == 1) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
-        else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow) : nullptr; want = 4; }
+    const int npan = k - p0;                              // 0 (k = 0), 1 or 2
+    wait_many(1 + 2 * npan, [&](int t, const int*& w, int& want) {
+        if (t == 0) { w = k >= 2 ? dc.at(dc.tver, irow, k) : nullptr; want = p0; }
+        else { w = dc.at(dc.rowdone, p0 + ((t - 1) >> 1), ((t - 1) & 1) ? irow : k); want = 4; }
     }, a.flag);
     PH(1)
-    v4d accC[4];                                          // the tile itself (MFMA layout): the accumulator of the panel k-1 update
+    const rsrc_t rA = make_rsrc(a.H + r0 * np);
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8), voX = unsigned(((16 * wv + g4) * np + m16) * 8);
+    v4d x[4];                                             // the tile itself (accumulator layout): the accumulator of the updates
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accC[q][r] = ld_sc1(H + (r0 + 16 * q + g4 + 4 * r) * np + kk + 16 * wv + m16);
-    if (k > 0) {
-        const long km = kk - CB;
-        load_block<true>(X, H + kk * np + km, np);
-        load_block<true>(AF, H + r0 * np + km, np);
-        __syncthreads();
-        PH(2)
+        for (int r = 0; r < 4; ++r) x[b][r] = ldb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + kk) * 8));
+    if (npan > 0) {
+        double af[16];
+        double2 bt[8];
+        auto fetchB = [&](int p) {
+            const rsrc_t rb = make_rsrc(a.H + kk * np + (long)p * CB);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll 4
-            for (int k0 = 0; k0 < CB; k0 += 4) {
-                const int kx = k0 + g4;
-                accC[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-AF[16 * q + m16][kx], X[16 * wv + m16][kx], accC[q], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
+        };
+        fetchB(p0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = ldb_sc1(rA, voA + 32 * q, unsigned(p0 * CB * 8));
+#pragma unroll 1
+        for (int p = p0; p < k; ++p) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&X[e >> 5][2 * (e & 31)]) = bt[u]; }
+            __syncthreads();
+            PH(2)
+            const bool more = p + 1 < k;
+            if (more) fetchB(p + 1);
+            const unsigned pn = unsigned((more ? p + 1 : p) * CB * 8);
+            double bf[2][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[0][b] = X[16 * b + m16][g4];
+#pragma unroll
+            for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+                if (q + 1 < 16) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = X[16 * b + m16][4 * (q + 1) + g4];
+                }
+                const double na = -af[q];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) x[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, bf[q & 1][b], x[b], 0, 0, 0);
+                if (more) af[q] = ldb_sc1(rA, voA + 32 * q, pn);
             }
+            PH(3)
+            if (more) __syncthreads();                    // everybody is done reading X
         }
     }
-    PH(3)
     if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
-    __syncthreads();                                      // also: everybody is done with X and AF
+    __syncthreads();                                      // also: everybody is done with X
     PH(1)
     {                                                     // the image of L_kk
         const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
         double2 t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
-        const int cc = 16 * wv + m16;                     // updated rows of A_ik (MFMA layout -> one row per DPP row), all 64
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int b = 0; b < 4; ++b)                       // updated rows of A_ik (MFMA layout -> one row per DPP row), all 64
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Y[(16 * q + g4 + 4 * r) * YLD + cc] = accC[q][r];
+            for (int r = 0; r < 4; ++r) Y[(16 * wv + g4 + 4 * r) * YLD + 16 * b + m16] = x[b][r];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = 2 * (tid + 256 * u);
@@ -999,6 +1056,7 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     __syncthreads();
     PH(2)
     const int rho = tid >> 4, lam = tid & 15;
+    const unsigned voS = unsigned((rho * np + lam) * 8);  // substitution layout: row 16 q + rho, columns lam + 16 i
 #pragma unroll 1
     for (int q = 0; q < 4; q += 2) {                      // rows 16 q + rho and 16 (q + 1) + rho: two interleaved substitutions
         double va[4], vb[4];
@@ -1007,8 +1065,8 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
         subst16x2(Lz, dinv, va, vb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            st_sc1(H + (r0 + 16 * q + rho) * np + kk + lam + 16 * i, va[i]);
-            st_sc1(H + (r0 + 16 * q + 16 + rho) * np + kk + lam + 16 * i, vb[i]);
+            stb_sc1(rA, voS + 128 * i, unsigned((16 * q * np + kk) * 8), va[i]);
+            stb_sc1(rA, voS + 128 * i, unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
         }
     }
     PH(5)
@@ -1018,56 +1076,207 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, doub
     PH(6)
 }
 
-// Trailing tile (i, j), LEFT-LOOKING over the panels p0 .. p1-1:  A_ij -= L_ip L_jp'  one panel after the other, accumulated
-// in the task's registers (operands streamed through LDS, the next pair in flight behind the current product), the tile
-// read once and written once -- the same updates in the same order and with the same arithmetic per update as the
-// read-modify-write strips (each product accumulated into the tile's value, see mma64): bit-identical results.
-__device__ __forceinline__ void trail_left(const CholStep& a, int i, int j, int p0, int p1, double* smem) {
-    const int tid = threadIdx.x, np = a.np;
+// Row blocks of the tiles (i, k) and (i + 1, k), all 128 rows, as ONE task (round 5; the single-tile form above remains for an odd
+// last tile): L_k,k-1 goes through LDS once and the image of L_kk is loaded once for both tiles; a wave owns the rows
+// 16 w .. 16 w + 15 of both tiles and all 64 columns, its rows of L_i,k-1 and L_i+1,k-1 in registers in the matrix cores' operand
+// layout (see trail_left2).  Same arithmetic per row as row_tile_block / panel_block<true>.
+__device__ __forceinline__ void row_tile_block2(const CholStep& a, int irow, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
+    const int k = a.k, np = a.np;
+    const long kk = (long)k * CB, r0 = (long)irow * CB;
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the staging tile Y
+    double* Y = smem + R0;
+    double* Lz = smem + R1;
+    double* dinv = smem + R3 + CB;
     const DagCnt dc(a.cnt, a.nblk);
-    const long i0 = (long)i * CB, j0 = (long)j * CB;
-    const int npan = p1 - p0;                             // <= TCHUNK <= 31
-    wait_many(1 + 2 * npan, [&](int t, const int*& w, int& want) {
-        if (t == 0) { w = p0 > 0 ? dc.at(dc.tver, i, j) : nullptr; want = p0; }
-        else { w = dc.at(dc.rowdone, p0 + ((t - 1) >> 1), ((t - 1) & 1) ? j : i); want = 4; }
+    wait_many(5, [&](int t, const int*& w, int& want) {
+        if (t < 2) { w = k >= 2 ? dc.at(dc.tver, irow + t, k) : nullptr; want = k - 1; }
+        else if (t == 2) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
+        else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow + t - 3) : nullptr; want = 4; }
     }, a.flag);
     PH(1)
-    double(*P)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);
-    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R1);
-    double2 at[8], bt[8];
-    auto fetch_pair = [&](int p) {
-        const rsrc_t ra = make_rsrc(a.H + i0 * np + (long)p * CB), rb = make_rsrc(a.H + j0 * np + (long)p * CB);
+    const rsrc_t rA = make_rsrc(a.H + r0 * np);
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8), voX = unsigned(((16 * wv + g4) * np + m16) * 8);
+    const unsigned row1 = unsigned(CB * np * 8);
+    v4d x0[4], x1[4];                                     // the tiles themselves (accumulator layout): the accumulators of the panel k-1 update
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x0[b][r] = ldb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + kk) * 8));
+            x1[b][r] = ldb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + kk) * 8));
+        }
+    if (k > 0) {
+        const long km = kk - CB;
+        double a0[16], a1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(km * 8)); a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(km * 8)); }
+        load_block<true>(X, a.H + kk * np + km, np);
+        __syncthreads();
+        PH(2)
+        double bf[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[0][b] = X[16 * b + m16][g4];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q + 1 < 16) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = X[16 * b + m16][4 * (q + 1) + g4];
+            }
+            const double na0 = -a0[q], na1 = -a1[q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
+                x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
+            }
+        }
+    }
+    PH(3)
+    if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
+    __syncthreads();                                      // also: everybody is done with X
+    PH(1)
+    {                                                     // the image of L_kk
+        const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            at[u] = ld2_sc1(ra, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
-            bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8));
+            const int e = 2 * (tid + 256 * u);
+            *reinterpret_cast<double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]) = t[u];
         }
+    }
+    if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kk + tid);
+    const int rho = tid >> 4, lam = tid & 15;
+    const unsigned voS = unsigned((rho * np + lam) * 8);  // substitution layout: row 16 q + rho, columns lam + 16 i
+#pragma unroll 1
+    for (int tile = 0; tile < 2; ++tile) {                // (one copy of the passes' code: the second tile moves into x0)
+        if (tile) {
+            __syncthreads();                              // the first tile's passes are done with Y
+#pragma unroll
+            for (int b = 0; b < 4; ++b) x0[b] = x1[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * wv + g4 + 4 * r) * YLD + 16 * b + m16] = x0[b][r];
+        __syncthreads();
+        if (!tile) { PH(2) }
+        const unsigned trow = tile ? row1 : 0u;
+#pragma unroll 1
+        for (int q = 0; q < 4; q += 2) {                  // rows 16 q + rho and 16 (q + 1) + rho: two interleaved substitutions
+            double va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va[i] = Y[(16 * q + rho) * YLD + lam + 16 * i]; vb[i] = Y[(16 * q + 16 + rho) * YLD + lam + 16 * i]; }
+            subst16x2(Lz, dinv, va, vb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                stb_sc1(rA, voS + 128 * i, trow + unsigned((16 * q * np + kk) * 8), va[i]);
+                stb_sc1(rA, voS + 128 * i, trow + unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
+            }
+        }
+    }
+    PH(5)
+    drain_stores();
+    __syncthreads();
+    if (tid < 2) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow + tid), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(6)
+}
+
+// Trailing tiles (i, j) and -- PAIR -- (i + 1, j), LEFT-LOOKING over the panels p0 .. p1-1:  A_ij -= L_ip L_jp'  one panel after the
+// other, accumulated in the task's registers, every tile read once and written once -- the same updates in the same order and
+// with the same arithmetic per update as the read-modify-write strips (each product accumulated into the tile's value, see
+// mma64): bit-identical results.
+// Macro tile (round 5): the two row tiles share the operand L_jp, which goes through LDS once; a wave owns the rows
+// 16 w .. 16 w + 15 of BOTH tiles and all 64 columns (2 x 4 MFMA blocks: four LDS reads feed eight MFMAs), and holds its rows of
+// L_ip, L_i+1,p in REGISTERS in the matrix cores' operand layout, loaded straight from global memory -- the next panel's
+// fragment of a k-step is requested into the same register as soon as the current panel's MFMAs of that k-step are issued (a
+// whole panel's product, ~7 us, of cover), and the next L_jp is in flight behind the product as before.  Per product 48 KB of
+// operands through the L2 instead of 64, no LDS traffic for the A operand, one barrier pair per TWO products.
+template <bool PAIR>
+__device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int p0, int p1, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4, np = a.np;
+    const DagCnt dc(a.cnt, a.nblk);
+    const long i0 = (long)i * CB, j0 = (long)j * CB;
+    const int npan = p1 - p0;                             // <= TCHUNK: 2 + 3 npan words to poll
+    wait_many(2 + 3 * npan, [&](int t, const int*& w, int& want) {
+        if (t < 2) { w = (p0 > 0 && (t == 0 || PAIR)) ? dc.at(dc.tver, i + t, j) : nullptr; want = p0; }
+        else {
+            const int p = p0 + (t - 2) / 3, q = (t - 2) % 3;
+            w = (q == 2 && !PAIR) ? nullptr : dc.at(dc.rowdone, p, q == 0 ? j : i + q - 1);
+            want = 4;
+        }
+    }, a.flag);
+    PH(1)
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);
+    const rsrc_t rA = make_rsrc(a.H + i0 * np);                           // tile row i (and i + 1): L_ip, and the tiles (i, j), (i + 1, j)
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8);        // the wave's rows of L_ip, operand layout: + 64 p (scalar) + 4 q
+    const unsigned voX = unsigned(((16 * wv + g4) * np + m16) * 8);        // accumulator layout: + 4 r rows, column j0 (scalar) + 16 b
+    const unsigned row1 = unsigned(CB * np * 8);                           // tile row i + 1
+    double a0[16], a1[16];
+    double2 bt[8];
+    auto fetchB = [&](int p) {
+        const rsrc_t rb = make_rsrc(a.H + j0 * np + (long)p * CB);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
     };
-    fetch_pair(p0);
-    double* dst = a.H + i0 * np + j0;
-    v4d x[2][2];
-    acc_foreach(x, [&](int ii, int jj, double& v) { v = ld_sc1(dst + (long)ii * np + jj); });
+    fetchB(p0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(p0 * CB * 8));
+        if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(p0 * CB * 8));
+    }
+    v4d x0[4], x1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x0[b][r] = ldb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + j0) * 8));
+            x1[b][r] = PAIR ? ldb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + j0) * 8)) : 0.0;
+        }
 #pragma unroll 1
     for (int p = p0; p < p1; ++p) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            *reinterpret_cast<double2*>(&P[e >> 5][2 * (e & 31)]) = at[u];
-            *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u];
-        }
+        for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
         __syncthreads();
         PH(2)
-        if (p + 1 < p1) fetch_pair(p + 1);
-        mma64<true>(P, Q, 0, CB, x);
+        const bool more = p + 1 < p1;
+        if (more) fetchB(p + 1);
+        // (the last panel requests its own fragments again instead of branching around the loads: the k-steps stay one
+        // straight line of code, LDS reads one k-step ahead of the MFMAs)
+        const unsigned pn = unsigned((more ? p + 1 : p) * CB * 8);
+        double bf[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[0][b] = Q[16 * b + m16][g4];
+#pragma unroll
+        for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+            if (q + 1 < 16) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = Q[16 * b + m16][4 * (q + 1) + g4];
+            }
+            const double na0 = -a0[q], na1 = -a1[q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
+                if (PAIR) x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
+            }
+            a0[q] = ldb_sc1(rA, voA + 32 * q, pn);
+            if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + pn);
+        }
         PH(3)
-        __syncthreads();                                  // everybody is done reading P and Q
+        __syncthreads();                                  // everybody is done reading Q
         PH(4)
     }
-    acc_foreach(x, [&](int ii, int jj, double& v) { st_sc1(dst + (long)ii * np + jj, v); });
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + j0) * 8), x0[b][r]);
+            if (PAIR) stb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + j0) * 8), x1[b][r]);
+        }
     drain_stores();
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.tver, i, j), npan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < (PAIR ? 2 : 1)) __hip_atomic_fetch_add(dc.at(dc.tver, i + tid, j), npan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PH(6)
 }
 
@@ -1079,7 +1288,7 @@ __device__ __forceinline__ void trail_left(const CholStep& a, int i, int j, int 
 // L_r,r-1 (held in REGISTERS in the matrix cores' operand layout), two passes of 32 columns, two interleaved
 // substitutions per thread.  No inverse-update tasks, no read-modify-write traffic on the inverse at all.
 __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6;
     const int np = a.np, r = a.k - 1;
     const long kr = (long)r * CB;
     double* M = a.M;
@@ -1217,7 +1426,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
         PH(2)
         if (j < r) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
                 const int kx = 4 * q + (lane >> 4);
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], Bs[kx][c], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], Bs[kx][16 + c], acc[1], 0, 0, 0);
@@ -1293,8 +1502,13 @@ __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1)
 #ifndef CHOL_TCHUNK
 #define CHOL_TCHUNK 8
 #endif
+#ifndef CHOL_R2
+#define CHOL_R2 0      /* two row tiles per row-block task (row_tile_block2): needs more registers than two workgroups per CU leave */
+#endif
 constexpr int TCHUNK = CHOL_TCHUNK;
 __host__ __device__ inline bool dag_leftT(int nblk) { return nblk <= 32; }
+// sum over c = 1 .. m of ceil(c / 2): the two-row tasks of columns with 1 .. m tiles
+__host__ __device__ inline int pair_tasks(int m) { const int h = m / 2; return (m & 1) ? (h + 1) * (h + 1) : h * (h + 1); }
 // ruform: the inverse's trailing updates as tasks of their own (read-modify-write strips, the form of the per-step
 // launches) instead of inside the inverse-row tasks -- for nblk > 32, where a left-looking inverse row would hold its
 // slot for up to 62 products
@@ -1303,12 +1517,16 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     DagStep s;
     s.nrem = nrem;
     s.nD = k < nblk ? 1 : 0;
-    s.nLA = (k >= 1 && k < nblk) ? nrem : 0;              // single tile updates of block column k + 1
+    // single tile updates of block column k + 1: all its tiles, or -- left-looking form -- the two on the chain, (k+1, k+1)
+    // and (k+2, k+1), alone (the others take panel k - 1 inside their row-block task of step k + 1: row_tile_block)
+    s.nLA = (k >= 1 && k < nblk) ? (dag_leftT(nblk) ? min(2, nrem) : nrem) : 0;
     s.nT = 0; s.nTc = 0;
     if (dag_leftT(nblk)) {
         if (k >= 1 && k < nblk && nrem >= 2) {
-            s.nT = nrem - 1;                              // the tiles of column k + 2: their last (or only) chunk, panels .. k - 1
-            if (k % TCHUNK == 0 && nrem >= 3) s.nTc = (nrem - 2) * (nrem - 1) / 2;     // the full chunk [k - TCHUNK, k) of the columns > k + 2
+            // the tiles of column k + 2: their last (or only) chunk, panels .. k - 1.  The two tiles on the chain, (k+2, k+2) and
+            // (k+3, k+2), one task each (the look-ahead tasks of the next step wait for them); the others two row tiles per task
+            s.nT = min(2, nrem - 1) + (max(nrem - 3, 0) + 1) / 2;
+            if (k % TCHUNK == 0 && nrem >= 3) s.nTc = pair_tasks(nrem - 2);            // the full chunk [k - TCHUNK, k) of the columns > k + 2
         }
     } else if (k >= 1 && k < nblk && nrem >= 2) {         // strips over the tiles (i, j), k + 2 <= j <= i, of each row i:
         const int m = nrem - 1, q = m / STRIP, r = m % STRIP;      // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
@@ -1323,7 +1541,11 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     s.nRU1 = (ru && k >= 2 && k < nblk) ? k - 1 : 0;      // inverse updates of row i = k (the next inverse row waits for them): single tiles
     s.nRU = (ru && k >= 2 && k < nblk) ? (nblk - k - 1) * s.ruc : 0;        // rows i > k: strips
     s.nRq = (k < nblk && nrem >= 1) ? 4 : 0;              // tile (k + 1, k) as four 16-row blocks (on the chain)
+#if CHOL_R2
+    s.nRt = (k < nblk && nrem >= 2) ? (nrem - 1 + 1) / 2 : 0;      // the other tiles of panel k, two per task (row_tile_block2)
+#else
     s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
+#endif
     return s;
 }
 __host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nTc + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
@@ -1345,10 +1567,15 @@ __device__ int g_dag_log_tasks;        // tasks per lane
 #ifndef CHOL_PROBE_LDS_PAD
 #define CHOL_PROBE_LDS_PAD 0     /* experiment (tools/exp): extra doubles of LDS per workgroup, to lower the workgroups per CU */
 #endif
-__global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
+#ifndef CHOL_DAG_WPS
+#define CHOL_DAG_WPS 2
+#endif
+__global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
     __shared__ __attribute__((aligned(16))) double smem[STEP_LDS + CHOL_PROBE_LDS_PAD];
     __shared__ int s_ticket;
-    const int lane = int(blockIdx.x) % a.nlanes;
+    // (the lane as blockIdx.x % nlanes of a 1-D grid was vector arithmetic -- the division -- and put every per-lane base pointer
+    //  derived from it into vector registers, sixteen of them, spilled once the tasks grew)
+    const int lane = int(blockIdx.x);                     // grid (lanes, tasks): the lane straight from a scalar register
     a.cnt = lane_at(a.cnt, (size_t)lane * a.lane_bytes);
     const DagCnt dc(a.cnt, a.nblk);
     // the ticket is drawn BEFORE the lane's mask is known (the mask word's load and the atomic's round trip overlap; a switched-off
@@ -1363,28 +1590,25 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
         if (a.Mt) a.Mt = lane_at(a.Mt, off);
     }
     DAG_STAT_BEGIN
+    // ticket -> (step, task of the step): lane q of every wave counts the tasks of step q, a wave scan gives the running totals --
+    // all of it while the ticket's atomic is in flight (a scalar loop over the steps took 1-2.5 us per task)
+    const int sl = int(threadIdx.x) & 63;
+    int incl = sl <= a.nblk ? dag_step_tasks(dag_step(a.nblk, sl)) : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (sl >= d) incl += u; }
     if (threadIdx.x == 0) s_ticket = tk;
     __syncthreads();
     int t = __builtin_amdgcn_readfirstlane(s_ticket);
-    int k = 0;
-    DagStep st = dag_step(a.nblk, 0);
-    while (k <= a.nblk && t >= dag_step_tasks(st)) { t -= dag_step_tasks(st); ++k; st = dag_step(a.nblk, k); }
-    if (k > a.nblk) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
+    const int k = __builtin_amdgcn_readfirstlane(__popcll(__ballot(incl <= t)));              // complete steps before the ticket (step 64 of nblk = 64: beyond the lanes)
+    if (k > a.nblk || t < 0) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
+    if (k > 0) t -= __builtin_amdgcn_readfirstlane(__shfl(incl, k - 1, 64));
+    const DagStep st = dag_step(a.nblk, k);
+    if (t >= dag_step_tasks(st)) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }
     a.k = k;
     const int np = a.np;
     PH(0)
     if (t < st.nD) { panel_block<false, true>(a, 0, smem); DAG_STAT_END(0) return; }
     t -= st.nD;
-#if CHOL_DAG_MS_EARLY
-    // inverse row k - 1 right behind the diagonal block: its inputs are all from earlier steps, so these tasks never wait -- and they
-    // give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the tile updates that need them poll
-    if (t < st.nMS) {
-        minv_strip(a, t, smem);
-        DAG_STAT_END(2)
-        return;
-    }
-    t -= st.nMS;
-#endif
     if (t < st.nLA) {
         // block column k+1 first (what D(k+1) and the row blocks of step k+1 wait for), one tile per task:
         // A_i,k+1 -= L_i,k-1 L_k+1,k-1'
@@ -1399,20 +1623,33 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
         return;
     }
     t -= st.nLA;
+#if CHOL_DAG_MS_EARLY
+    // inverse row k - 1 right behind the tiles on the chain: its inputs are all from earlier steps, so these tasks hardly wait -- and
+    // they give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the trailing tiles that
+    // need them poll
+    if (t < st.nMS) {
+        minv_strip(a, t, smem);
+        DAG_STAT_END(2)
+        return;
+    }
+    t -= st.nMS;
+#endif
     if (dag_leftT(a.nblk)) {
         if (t < st.nT + st.nTc) {
             // left-looking trailing tiles: column k + 2 gets its last chunk of panels (.. k - 1), and in the steps that are
             // multiples of TCHUNK the columns further right get the full chunk [k - TCHUNK, k)
             int i, j, p0;
-            if (t < st.nT) { j = k + 2; i = j + t; p0 = ((k - 1) / TCHUNK) * TCHUNK; }
+            bool single = false;
+            if (t < st.nT) { j = k + 2; single = t < 2; i = t < 2 ? j + t : j + 2 + 2 * (t - 2); p0 = ((k - 1) / TCHUNK) * TCHUNK; }
             else {
                 t -= st.nT;
-                int c = st.nrem - 2;                      // column j = k + 3 has nrem - 2 tiles, the next one fewer, ...
+                int c = st.nrem - 2;                      // column j = k + 3 has nrem - 2 tiles, the next one fewer, ...: two per task
                 j = k + 3;
-                while (t >= c) { t -= c; --c; ++j; }
-                i = j + t; p0 = k - TCHUNK;
+                while (t >= (c + 1) / 2) { t -= (c + 1) / 2; --c; ++j; }
+                i = j + 2 * t; p0 = k - TCHUNK;
             }
-            trail_left(a, i, j, p0, k, smem);
+            if (i + 1 < a.nblk && !single) trail_left2<true>(a, i, j, p0, k, smem);
+            else trail_left2<false>(a, i, j, p0, k, smem);
             DAG_STAT_END(5)
             return;
         }
@@ -1468,7 +1705,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_dag(CholStep a) {
     t -= st.nRU1 + st.nRU;
     if (t < st.nRq) { panel_block<true, true>(a, t + 1, smem); DAG_STAT_END(4) return; }       // tile (k+1, k): four 16-row blocks
     t -= st.nRq;
-    row_tile_block(a, k + 2 + t, smem);                   // tiles (i, k), i >= k + 2
+    {
+        const int pfirst = dag_leftT(a.nblk) ? max(0, k - 2) : max(0, k - 1);      // (left-looking form: the look-ahead update rides here)
+#if CHOL_R2
+        if (k + 2 + 2 * t + 1 < a.nblk && !dag_leftT(a.nblk)) row_tile_block2(a, k + 2 + 2 * t, smem);    // tiles (i, k), (i + 1, k), i >= k + 2
+        else row_tile_block(a, k + 2 + 2 * t, pfirst, smem);
+#else
+        row_tile_block(a, k + 2 + t, pfirst, smem);       // tiles (i, k), i >= k + 2
+#endif
+    }
     DAG_STAT_END(4)
 }
 
@@ -1590,7 +1835,7 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         int ntasks = 0;
         for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
         a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
-        hipLaunchKernelGGL(k_chol_dag, dim3(ntasks * nlanes), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_chol_dag, dim3(nlanes, ntasks), dim3(256), 0, st, a);      // (x runs fastest: the lanes' workgroups are dealt out alternately)
         if (e1) hipEventRecord(e1, st);
         if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
         return 1;
