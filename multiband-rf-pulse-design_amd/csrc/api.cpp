@@ -546,6 +546,7 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                 release_programs();
                 continue;
             }
+            std::vector<char> done(U.size(), 0);         // designs of the unit whose result is already out (a later error must not overwrite it)
             try {
                 const double t_asm = now_ms();
                 std::vector<const TrigProgram*> Ps;
@@ -565,19 +566,28 @@ int mbfir_solve_batch(mbfir_ctx* const* ctxs, int nctx, mbfir_job* jobs, int njo
                     J.rc = rc;
                     ctx->last_x = xs[b];
                     finish_job(U[b]);
+                    done[b] = 1;
                 }
+                for (size_t b = 0; b < U.size(); ++b) if (!done[b]) done[b] = 2;      // (the redo list: their single solves report for themselves)
                 for (int q : redo) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
             } catch (const ShapeError& e) {
                 // the lock-step path does not take these programs as one unit: every design of it goes through the
                 // single-design path, which reports its own verdict or error
                 ctx->err = e.what();
-                for (int q : U) { jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
-            } catch (const std::exception& e) {
-                // an internal or device error (a lost in-launch hand-off of the factorisation, a HIP error, the arena):
-                // reported for every design of the unit, NOT retried -- the single-design path takes other kernels and
-                // would hide a defect of the lock-step ones behind a slow success
+                for (size_t b = 0; b < U.size(); ++b) if (!done[b]) { const int q = U[b]; jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
+            } catch (const ResourceError& e) {
+                // the unit did not get its device memory (lanes sized to the unit's maxima: ADVICE r4): recoverable -- one design
+                // at a time needs a lane's worth
                 ctx->err = e.what();
-                for (int q : U) {
+                for (size_t b = 0; b < U.size(); ++b) if (!done[b]) { const int q = U[b]; jobs[q].rc = one_job(ctx, jobs[q], opts); finish_job(q); }
+            } catch (const std::exception& e) {
+                // an internal or device error (a lost in-launch hand-off of the factorisation, a HIP error):
+                // reported for every design of the unit that has no result yet, NOT retried -- the single-design path takes other
+                // kernels and would hide a defect of the lock-step ones behind a slow success
+                ctx->err = e.what();
+                for (size_t b = 0; b < U.size(); ++b) {
+                    if (done[b] == 1) continue;
+                    const int q = U[b];
                     std::memset(&jobs[q].info, 0, sizeof(jobs[q].info));
                     jobs[q].info.status = MBFIR_E_HIP; jobs[q].info.lanes = int(U.size());
                     jobs[q].rc = MBFIR_E_HIP;

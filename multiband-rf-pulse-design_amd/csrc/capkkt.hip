@@ -27,7 +27,7 @@ constexpr int TB = 64, TLD = 66;
 
 // acc[a][b] += A(64 x 64 tile in As) * op(B tile in Bs): each of the 4 waves owns a 32 x 32 quadrant (2 x 2 MFMA blocks);
 // v_mfma_f64_16x16x4_f64 operand layout: a = A[i = lane % 16][k = lane / 16], b = B[k = lane / 16][j = lane % 16],
-// c[q] = C[4 (lane / 16) + q][lane % 16]
+// c[q] = C[lane / 16 + 4 q][lane % 16]
 template <bool TRANSB>
 __device__ __forceinline__ void mma_tile(const double (*As)[TLD], const double (*Bs)[TLD], v4d acc[2][2]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -203,6 +203,7 @@ void cap_build_launch(const double* U, int k, int kp, int np, const double* M, c
     hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, Zt, np, np, (const double*)nullptr, 0);
     const int kb = kp / TB;
     hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2), dim3(256), 0, st, Yt, (const double*)nullptr, S, np, kp, X, k);
+    MBFIR_HIP(hipGetLastError());                         // (a refused launch -- grid, LDS -- would otherwise surface iterations later as a wrong step)
 }
 void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st) {
     if (nv == 1) hipLaunchKernelGGL(k_cap_add<1>, dim3(cdiv(np, 256)), dim3(256), 0, st, a, b, out, n, np, ldv);

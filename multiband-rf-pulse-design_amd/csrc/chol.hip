@@ -1193,6 +1193,13 @@ __device__ __forceinline__ void row_tile_block2(const CholStep& a, int irow, dou
 // fragment of a k-step is requested into the same register as soon as the current panel's MFMAs of that k-step are issued (a
 // whole panel's product, ~7 us, of cover), and the next L_jp is in flight behind the product as before.  Per product 48 KB of
 // operands through the L2 instead of 64, no LDS traffic for the A operand, one barrier pair per TWO products.
+// the compiler waits for EVERY outstanding load (s_waitcnt vmcnt(0)) in front of the LDS stores at the head of the panel loop: the
+// fragments of the last ALATE k-steps are therefore not re-requested in place at the end of a panel (their latency would be
+// exposed right there) but at the head of the next one, 16 - ALATE k-steps before they are used
+#ifndef CHOL_ALATE
+#define CHOL_ALATE 8
+#endif
+constexpr int ALATE = CHOL_ALATE;
 template <bool PAIR>
 __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int p0, int p1, double* smem) {
     const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4, np = a.np;
@@ -1220,12 +1227,8 @@ __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
     };
-    fetchB(p0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(p0 * CB * 8));
-        if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(p0 * CB * 8));
-    }
+    // (request order: the tiles, L_jp, the fragments -- as inside the loop, where L_jp of the next panel goes out before the
+    //  fragments: the loads outstanding behind L_jp are the same 32 at the head of every trip)
     v4d x0[4], x1[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -1234,6 +1237,12 @@ __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int
             x0[b][r] = ldb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + j0) * 8));
             x1[b][r] = PAIR ? ldb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + j0) * 8)) : 0.0;
         }
+    fetchB(p0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(p0 * CB * 8));
+        if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(p0 * CB * 8));
+    }
 #pragma unroll 1
     for (int p = p0; p < p1; ++p) {
 #pragma unroll
@@ -1241,9 +1250,18 @@ __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int
         __syncthreads();
         PH(2)
         const bool more = p + 1 < p1;
-        if (more) fetchB(p + 1);
-        // (the last panel requests its own fragments again instead of branching around the loads: the k-steps stay one
-        // straight line of code, LDS reads one k-step ahead of the MFMAs)
+        // (the last panel requests its own operands again instead of branching around the loads: the k-steps stay one
+        // straight line of code, LDS reads one k-step ahead of the MFMAs -- and the loads outstanding at the head of the loop
+        // are the same on every trip, so that the wait in front of the LDS stores covers L_jp alone (vmcnt(32)), not the
+        // fragments requested during the last k-steps)
+        if (p > p0) {
+#pragma unroll
+            for (int q = 16 - ALATE; q < 16; ++q) {
+                a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(p * CB * 8));
+                if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(p * CB * 8));
+            }
+        }
+        fetchB(more ? p + 1 : p);
         const unsigned pn = unsigned((more ? p + 1 : p) * CB * 8);
         double bf[2][4];
 #pragma unroll
@@ -1260,8 +1278,10 @@ __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int
                 x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
                 if (PAIR) x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
             }
-            a0[q] = ldb_sc1(rA, voA + 32 * q, pn);
-            if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + pn);
+            if (q < 16 - ALATE) {
+                a0[q] = ldb_sc1(rA, voA + 32 * q, pn);
+                if (PAIR) a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + pn);
+            }
         }
         PH(3)
         __syncthreads();                                  // everybody is done reading Q
@@ -1471,6 +1491,180 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
     PH(6)
 }
 
+// (-DCHOL_MS_PAIR=1 only: measured and not adopted, see the switch)
+// Inverse rows r and r + 1, tile j <= r, as ONE task (round 5; nblk <= 32): both rows accumulate their updates by the rows
+// p = j .. r-1 of the inverse against the SAME operand M_pj, which goes through LDS once for the two of them (a wave owns the rows
+// 16 w .. 16 w + 15 of both tiles and all 64 columns, its rows of L_rp, L_r+1,p in registers in the matrix cores' operand layout
+// with the rolling prefetch of trail_left2); row r is then finished (two 32-column passes of two interleaved substitutions against
+// the image of L_rr), its tile -- still in the staging array of the pass -- is the operand of row r + 1's last update
+// (L_r+1,r M_rj: no hand-off through memory between the two rows of the inverse), and row r + 1 is finished the same way.
+// Half the inverse's tasks, polls and operand traffic, half the links of the inverse's row-after-row chain.  Per element the
+// same MFMA chains in the same order as minv_strip / minv_block: bit-identical.
+__device__ __forceinline__ void minv_pair(const CholStep& a, int r, int j, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4, np = a.np;
+    const long kr = (long)r * CB;
+    double* M = a.M;
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);         // M_pj ([k][column]); later the image of L_rr, L_r+1,r+1
+    double* Lz = smem + R0;
+    double* Ct = smem + R1;                                                // staging [column][row], stride YLD, 32 columns
+    double* dinv = smem + R3;
+    const DagCnt dc(a.cnt, a.nblk);
+    const int npan = r - j;
+    {
+        // (the image of L_r+1,r+1 is this step's diagonal block's: polled when row r + 1 is finished, below; the rows r - 2 and
+        //  r - 1 of the inverse are the pair task's before this one in the row-after-row chain of the inverse: polled when the
+        //  accumulation gets to them -- every earlier panel is done by then -- not up front)
+        const int nw = 2 + 3 * npan;
+        for (int w0 = 0; w0 < nw; w0 += 64)
+            wait_many(min(64, nw - w0), [&](int t, const int*& w, int& want) {
+                const int q = w0 + t;
+                if (q == 0) { w = dc.img + r; want = 1; }
+                else if (q == 1) { w = dc.at(dc.rowdone, r, r + 1); want = 4; }
+                else {
+                    const int pq = j + (q - 2) / 3, kind = (q - 2) % 3;
+                    w = kind == 2 ? (pq >= r - 2 ? nullptr : dc.at(dc.msdone, pq, j)) : dc.at(dc.rowdone, pq, r + kind);
+                    want = 4;
+                }
+            }, a.flag);
+    }
+    PH(1)
+    const rsrc_t rL = make_rsrc(a.H + kr * np);                            // tile rows r (and r + 1) of L
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8), row1 = unsigned(CB * np * 8);
+    v4d x0[4], x1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x0[b][q] = (j == r && 16 * wv + g4 + 4 * q == 16 * b + m16) ? 1.0 : 0.0;      // R_rr starts as the identity
+            x1[b][q] = 0.0;
+        }
+    double a0[16], a1[16];
+    if (npan > 0) {
+        double2 bt[8];
+        auto fetchB = [&](int p) {
+            const rsrc_t rb = make_rsrc(M + (long)p * CB * np + (long)j * CB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
+        };
+        bool chained = false;                                              // the rows r - 2, r - 1 of the inverse have been polled
+        auto chain_poll = [&]() {
+            if (tid == 0) wait_flags(r - 2 >= j ? dc.at(dc.msdone, r - 2, j) : nullptr, 4, dc.at(dc.msdone, r - 1, j), 4, nullptr, 0, a.flag);
+            __syncthreads();
+            chained = true;
+            PH(1)
+        };
+        if (j >= r - 2) chain_poll();
+        fetchB(j);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = ldb_sc1(rL, voA + 32 * q, unsigned(j * CB * 8)); a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + unsigned(j * CB * 8)); }
+#pragma unroll 1
+        for (int p = j; p < r; ++p) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
+            __syncthreads();
+            PH(2)
+            const bool more = p + 1 < r;
+            if (!chained && p + 1 >= r - 2) chain_poll();
+            fetchB(more ? p + 1 : p);                                      // (see trail_left2)
+            const unsigned pn0 = unsigned((more ? p + 1 : p) * CB * 8), pn1 = unsigned((p + 1) * CB * 8);      // row r + 1 goes on to L_r+1,r
+            double bf[2][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[0][b] = Q[g4][16 * b + m16];
+#pragma unroll
+            for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+                if (q + 1 < 16) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = Q[4 * (q + 1) + g4][16 * b + m16];
+                }
+                const double na0 = -a0[q], na1 = -a1[q];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
+                    x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
+                }
+                a0[q] = ldb_sc1(rL, voA + 32 * q, pn0);
+                a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + pn1);
+            }
+            PH(3)
+            __syncthreads();                                               // everybody is done reading Q
+            PH(4)
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = 0.0; a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + unsigned(r * CB * 8)); }
+    }
+    // ---- row r: L_rr M_rj = R_rj, 32 columns per pass; each pass's columns then update row r + 1 (a1 = L_r+1,r)
+    const int rho = tid >> 4, lam = tid & 15;
+#pragma unroll 1
+    for (int row = 0; row < 2; ++row) {
+        if (row) {
+            if (tid == 0) wait_flag(dc.img + r + 1, 1, a.flag);
+            __syncthreads();
+            PH(1)
+        }
+        {
+            const rsrc_t ri = make_rsrc(a.Dfac + (kr + row * CB) * CB);
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+            }
+        }
+        if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + row * CB + tid);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ct[(16 * h + m16) * YLD + 16 * wv + g4 + 4 * q] = pass ? x0[2 + h][q] : x0[h][q];
+            __syncthreads();                                               // Ct (and, first pass, the image) in place
+            PH(2)
+            double va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va[i] = Ct[rho * YLD + lam + 16 * i]; vb[i] = Ct[(16 + rho) * YLD + lam + 16 * i]; }
+            subst16x2(Lz, dinv, va, vb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Ct[rho * YLD + lam + 16 * i] = va[i]; Ct[(16 + rho) * YLD + lam + 16 * i] = vb[i]; }
+            __syncthreads();
+            {
+                const int t = tid >> 2, c8 = (tid & 3) * 8;               // row t of the tile, columns 32 pass + c8 .. + 7
+                const rsrc_t rm = make_rsrc(M + (kr + row * CB) * np + (long)j * CB + 32 * pass);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2)
+                    st2_sc1(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
+            }
+            if (a.Mt) {                                                    // the transpose for the second triangular GEMV (np > 1024)
+                const int cr = tid >> 3, t8 = (tid & 7) * 8;
+                double* dt = a.Mt + ((long)j * CB + 32 * pass + cr) * np + kr + row * CB + t8;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dt[u] = Ct[cr * YLD + t8 + u];
+            }
+            if (row == 0) {                                                // R_r+1,j (these 32 columns) -= L_r+1,r M_rj
+                v4d y0 = pass ? x1[2] : x1[0], y1 = pass ? x1[3] : x1[1];
+#pragma unroll
+                for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+                    const int kx = 4 * q + g4;
+                    const double na1 = -a1[q];
+                    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, Ct[m16 * YLD + kx], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, Ct[(16 + m16) * YLD + kx], y1, 0, 0, 0);
+                }
+                if (pass) { x1[2] = y0; x1[3] = y1; } else { x1[0] = y0; x1[1] = y1; }
+            }
+            __syncthreads();                                               // everybody is done with Ct (and, last pass, with the image)
+            PH(5)
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x0[b] = x1[b];                         // second trip: row r + 1
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid < 2) __hip_atomic_fetch_add(dc.at(dc.msdone, r + tid, j), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PH(6)
+}
+
 // =================================================================================================
 // The whole factorisation (and inverse) in ONE launch: every block of the seventeen k_chol_step launches above becomes
 // a task of one grid; the launch boundaries are replaced by the dependency counters of DagCnt.
@@ -1502,6 +1696,12 @@ __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1)
 #ifndef CHOL_TCHUNK
 #define CHOL_TCHUNK 8
 #endif
+#ifndef CHOL_MS_PAIR
+#define CHOL_MS_PAIR 0 /* two inverse rows per task (minv_pair).  Measured in round 5 (tools/exp/chol_dag_exp.hip, np = 1024): bit-identical,
+                          72 tasks of 64 us instead of 136 of 37 (-10 % of the inverse's workgroup-time) -- and SLOWER: 16 lanes alone 570 ->
+                          658 us, four units in flight 31.1 -> 32.4 us per design and build; the inverse's row-after-row chain gets the
+                          longer links.  Kept for the record, off */
+#endif
 #ifndef CHOL_R2
 #define CHOL_R2 0      /* two row tiles per row-block task (row_tile_block2): needs more registers than two workgroups per CU leave */
 #endif
@@ -1532,7 +1732,16 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
         const int m = nrem - 1, q = m / STRIP, r = m % STRIP;      // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
         s.nT = STRIP * q * (q + 1) / 2 + r * (q + 1);
     }
-    s.nMS = k >= 1 ? k : 0;                               // the k tiles of inverse row k - 1, one task each (its updates by the
+    // inverse rows.  nblk <= 32: the rows k - 1 and k together in the odd steps k < nblk (minv_pair: k tasks for the tiles j <= k - 1 of
+    // both rows -- they accumulate while the diagonal block of step k, whose image row k waits for, is being eliminated -- and one
+    // for the diagonal tile of row k), the last row of an odd nblk alone in step nblk.  nblk > 32:
+#if CHOL_MS_PAIR
+    s.nMS = dag_ruform(nblk) ? (k >= 1 ? k : 0)
+          : ((k & 1) && k < nblk) ? k + 1 : (k == nblk && (nblk & 1)) ? k : 0;
+#else
+    s.nMS = k >= 1 ? k : 0;
+#endif
+                                                          // the k tiles of inverse row k - 1, one task each (its updates by the
                                                           // panels before, then two 32-column passes): row r of the inverse waits
                                                           // for row r - 1, so more tiles per task would be a longer chain (measured:
                                                           // four tiles per task doubled the build)
@@ -1628,7 +1837,14 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
     // they give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the trailing tiles that
     // need them poll
     if (t < st.nMS) {
-        minv_strip(a, t, smem);
+#if CHOL_MS_PAIR
+        if (!dag_ruform(a.nblk) && k < a.nblk) {
+            if (t < k) minv_pair(a, k - 1, t, smem);      // rows k - 1 and k, tile t
+            else { a.k = k + 1; minv_strip(a, k, smem); a.k = k; }      // the diagonal tile of row k
+        } else minv_strip(a, t, smem);                    // (the last row of an odd nblk; nblk > 32: row k - 1)
+#else
+        minv_strip(a, t, smem);                           // row k - 1, tile t
+#endif
         DAG_STAT_END(2)
         return;
     }
@@ -1676,7 +1892,14 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
     } else t -= st.nT;
 #if !CHOL_DAG_MS_EARLY
     if (t < st.nMS) {
-        minv_strip(a, t, smem);
+#if CHOL_MS_PAIR
+        if (!dag_ruform(a.nblk) && k < a.nblk) {
+            if (t < k) minv_pair(a, k - 1, t, smem);      // rows k - 1 and k, tile t
+            else { a.k = k + 1; minv_strip(a, k, smem); a.k = k; }      // the diagonal tile of row k
+        } else minv_strip(a, t, smem);                    // (the last row of an odd nblk; nblk > 32: row k - 1)
+#else
+        minv_strip(a, t, smem);                           // row k - 1, tile t
+#endif
         DAG_STAT_END(2)
         return;
     }

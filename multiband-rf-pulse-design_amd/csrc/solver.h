@@ -13,6 +13,11 @@ namespace mbfir {
 struct ShapeError : std::runtime_error {
     explicit ShapeError(const std::string& s) : std::runtime_error(s) {}
 };
+// a lock-step unit did not get its device memory (every lane is sized to the unit's maxima): recoverable -- the caller takes
+// the unit's designs through the single-design path -- unlike an internal or device error, which is reported
+struct ResourceError : std::runtime_error {
+    explicit ResourceError(const std::string& s) : std::runtime_error(s) {}
+};
 
 enum { ST_OPTIMAL = 0, ST_PRIMAL_INFEASIBLE = 1, ST_DUAL_INFEASIBLE = 2, ST_MAXIT = 3, ST_NUMERICAL = 4,
        ST_OPTIMAL_INACCURATE = 5 };

@@ -941,7 +941,10 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
         hz = fold_partials(partR, nbR, 4, 2, false, sh);
         gxs2 = fold_partials(partR, nbR, 4, 3, false, sh);
         if (phase == 0) {
-            if (threadIdx.x == 0) { RB[0] = rz2; RB[1] = sz; RB[2] = hz; RB[3] = gxs2; }
+            // (row-sharded: the fifth slot carries this rank's pivot-replacement count -- every rank factorises the same H itself,
+            //  and the wall exit / the NUMERICAL verdict branch on that count: summed over the ranks with the row sums, every rank
+            //  sees the SAME number whatever its own factorisation said, so the ranks cannot part ways in front of a collective)
+            if (threadIdx.x == 0) { RB[0] = rz2; RB[1] = sz; RB[2] = hz; RB[3] = gxs2; RB[4] = flag ? double(flag[0]) : 0.0; }
             return;
         }
     } else {
@@ -973,7 +976,7 @@ __global__ __launch_bounds__(1024) void k_scal_resid(DProg P, double* __restrict
         Sc[S_RELGAP] = den > 0 ? gap / den : 1e300;
         Sc[S_PINF] = hz < 0 ? sqrt(gtz2) / (-hz) : 1e300;
         Sc[S_DINF] = cx < 0 ? sqrt(gxs2) / (-cx) : 1e300;
-        Sc[S_CHOLFIX] = flag ? double(flag[0]) : 0.0;
+        Sc[S_CHOLFIX] = phase == 1 ? RB[4] : (flag ? double(flag[0]) : 0.0);
     }
 }
 
@@ -1966,7 +1969,11 @@ struct Solver::Impl {
         if (bytes <= ar.cap) { ar.reset(); return; }
         if (ar.base) MBFIR_HIP(hipFree(ar.base));
         ar.base = nullptr; ar.cap = 0;
-        MBFIR_HIP(hipMalloc(&ar.base, bytes));
+        if (hipMalloc(&ar.base, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ar.base = nullptr;
+            throw ResourceError("arena of " + std::to_string(bytes >> 20) + " MiB not available on the device");
+        }
         ar.cap = bytes;
         ar.reset();
     }
@@ -2940,8 +2947,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             S.apply_G<1>(S.x, S.Gx);
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, S.Gx, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, nullptr, nullptr);
         }
-        if (sharded) hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, rmail, 0, (const int*)nullptr);
-        S.apply_GT<1>(S.z, S.GTz, sharded ? 4 : 0);
+        if (sharded) hipLaunchKernelGGL(k_scal_resid, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, rmail, 0, (const int*)S.flag);
+        S.apply_GT<1>(S.z, S.GTz, sharded ? 5 : 0);
         hipLaunchKernelGGL(k_scal_resid, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.GTz, S.x, S.rx, S.bx2, S.partR, S.nbR, rmail, sharded ? 1 : 2, (const int*)S.flag);
     };
     // ---- launch graphs (round 4, opt-in: MBFIR_GRAPH=1).  The host thread of ONE design spends 44 % of the solve issuing the ~80

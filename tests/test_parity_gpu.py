@@ -162,7 +162,11 @@ def test_full_size_c3_properties(dense):
     dx_rel = np.abs(z[: 2 * n - 1] - xg).max() / np.abs(xg).max()
     tap_tol = max(1e-6, sens["amplification_max"] * dx_rel)
     assert tap_tol <= 5e-4, (dx_rel, tap_tol)                 # (the device reproduces the oracle's iterate to <= 2e-10 relative)
-    assert relinf(h, hg) <= tap_tol, (relinf(h, hg), dx_rel, tap_tol)
+    # the derived bound explains the tolerance, fixed literals near the measured values guard against regressions (a
+    # bound that grows with the solver's own error lets a solve that moves x ten times further pass): the iterate within 1e-9
+    # relative of the fixture's (measured 3e-12 lattice, 3e-11 dense), the taps inside north_star's 1e-6 (measured 2e-8 / 6e-7)
+    assert dx_rel <= 1e-9, dx_rel
+    assert relinf(h, hg) <= min(tap_tol, 1e-6), (relinf(h, hg), dx_rel, tap_tol)
 
 
 def test_config5_2048_taps_131072_grid_properties():
@@ -413,7 +417,7 @@ def test_extended_precision_solve_capacitance_form_equals_the_double_double_form
         res[form] = mbfir.fir_qp_cvx(*args, opts=opts, info=True)
     (hc, sc, ic), (hd, sd, idd) = res["cap"], res["dd"]
     assert sc == sd == "Solved"
-    assert abs(ic["iters"] - idd["iters"]) <= 1 and ic["dd_iters"] == idd["dd_iters"] or abs(ic["dd_iters"] - idd["dd_iters"]) <= 1
+    assert abs(ic["iters"] - idd["iters"]) <= 1 and abs(ic["dd_iters"] - idd["dd_iters"]) <= 1
     assert abs(ic["pcost"] - idd["pcost"]) <= 1e-9 * max(1.0, abs(idd["pcost"]))
     assert relinf(hc, hd) <= 1e-6
     if case == "h1_384":

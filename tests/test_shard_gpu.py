@@ -177,7 +177,8 @@ def test_config5_row_sharded_at_full_size_in_loop_back():
         # what the ACHIEVED ||dx|| (sharded vs unsharded solution) supports, with the amplification measured here, at this
         # optimum, by finite differences through the device's own fmp2 along eight random directions of that size.
         dx_rel, tap_tol, amp = _tap_tolerance(n, z0, info["_z"], h0)
-        assert relinf(h, h0) <= tap_tol, (relinf(h, h0), dx_rel, amp, tap_tol)
+        # (and a fixed regression bound near the measured 1.5e-3 -- the derived bound alone grows with the solve's own error)
+        assert relinf(h, h0) <= min(tap_tol, 5e-3), (relinf(h, h0), dx_rel, amp, tap_tol)
         # measured on one MI355X: ||dx|| 1.5e-7 relative between the sharded and the unsharded solution (they stop within two
         # iterations of each other on an objective that is flat around its minimiser), amplification 3.8e5 along random
         # directions of that size -> the supported tolerance is 6e-2 (0.17 with the factor 3); the taps actually differ by
