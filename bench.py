@@ -280,7 +280,8 @@ def main():
     ap.add_argument("--shard-n", type=int, default=2048)
     ap.add_argument("--shard-grid-m", type=int, default=131072)
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the row-sharded config-5 leg")
-    ap.add_argument("--shard-timeout", type=int, default=240, help="N > 1: seconds the row-sharded leg may take before the line "
+    ap.add_argument("--no-shard-dense", action="store_true", help="N > 1: skip the dense-path half of the row-sharded leg")
+    ap.add_argument("--shard-timeout", type=int, default=360, help="N > 1: seconds the row-sharded leg may take before the line "
                     "is printed without it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks: ranks then share devices and the solver's "
@@ -352,10 +353,13 @@ def main():
                 return 0
             c.set_allreduce(hook)
 
-    def shard_leg(n, grid_m, steps, warmup):
-        """ONE design, its frequency rows split over the ranks (strong scaling)."""
+    def shard_leg(n, grid_m, steps, warmup, dense=None):
+        """ONE design, its frequency rows split over the ranks (strong scaling).  dense: the materialised trig matrix and the MFMA
+        Gram product (north_star's own design: the packed lower triangle of the normal matrix is all-reduced per iteration)
+        instead of the lattice path (the trigonometric moments are)."""
+        dense = int(args.dense if dense is None else dense)
         f, a, d = mbfir.spec.spec_c13_bssfp(n)
-        o = mbfir.make_opts(grid_m=grid_m, shard_rank=rank, shard_size=world, dense_trig=int(args.dense))
+        o = mbfir.make_opts(grid_m=grid_m, shard_rank=rank, shard_size=world, dense_trig=dense)
         info = None
         for _ in range(warmup):
             mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=o, ctx=ctx, info=True)
@@ -371,10 +375,10 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        # the same design unsharded on this rank (no collective): what one GPU does alone, and the split of the sharded
-        # solve into the part that shards (row work: moments, G v, G'v, step lengths) and the part that does not (the
-        # factorisation of the replicated N x N normal matrix, which rank 0 runs while the others wait in a collective)
-        o1 = mbfir.make_opts(grid_m=grid_m, dense_trig=int(args.dense))
+        # the same design unsharded on this rank IN THE SAME MODE (no collective): what one GPU does alone, and the split of
+        # the sharded solve into the part that shards (row work: Gram product / moments, G v, G'v, step lengths) and the part
+        # that does not (the factorisation of the replicated N x N normal matrix, which every rank runs for itself)
+        o1 = mbfir.make_opts(grid_m=grid_m, dense_trig=dense)
         mbfir.fir_ap_cvx(n, f, a, d, 0.1, 1e-3, opts=o1, ctx=ctx, info=True)
         fence()
         t1 = time.perf_counter()
@@ -385,16 +389,17 @@ def main():
         sharded_ms = el / steps * 1e3
         chol_ms = info1["ms_chol"]                          # the factorisations of the unsharded solve = the replicated part
         amdahl = one_gpu_ms / (chol_ms + (one_gpu_ms - chol_ms) / world) if one_gpu_ms > 0 else None
-        return {"metric": "FIR designs/sec, n=%d taps m=%d, frequency rows of one design sharded x%d" % (n, grid_m, world),
-                "value": steps / el, "unit": "designs/s", "ms_per_design": sharded_ms, "scaling": "strong",
+        return {"metric": "FIR designs/sec, n=%d taps m=%d, frequency rows of one design sharded x%d (%s path)" % (n, grid_m, world, "dense" if dense else "lattice"),
+                "value": steps / el, "unit": "designs/s", "ms_per_design": sharded_ms, "scaling": "strong", "mode": "dense" if dense else "lattice",
                 "iters": info["iters"], "collectives_per_iteration": info["collectives"] / max(1, info["iters"]),
+                "collective_MB_per_iteration": info["collective_bytes"] / max(1, info["iters"]) / 1e6,
                 "one_gpu_unsharded_ms": one_gpu_ms, "speedup_vs_one_gpu": one_gpu_ms / sharded_ms if st1 == "Solved" else None,
                 "phase_split_ms": {"replicated_factorisation": chol_ms, "shardable_row_work_one_gpu": one_gpu_ms - chol_ms,
                                    "sharded_solve_total": sharded_ms},
                 "amdahl_bound_speedup_at_this_n_gpus": amdahl,
-                "note": "strong scaling of ONE design is bounded by the replicated factorisation (rank 0 factorises the N x N normal "
-                        "matrix, the moments of which were all-reduced; the other ranks wait); the weak-scaling batch figure above "
-                        "(independent designs, no collective) is the mode that approaches N x",
+                "note": "strong scaling of ONE design is bounded by the replicated factorisation (every rank factorises the same N x N "
+                        "normal matrix itself -- lattice: from the all-reduced moments, dense: from the all-reduced packed lower "
+                        "triangle); the weak-scaling batch figure above (independent designs, no collective) is the mode that approaches N x",
                 "reductions": "ncclAllReduce on the solver stream (mbfir_comm_init)" if args.backend == "nccl" else "host hook (gloo rehearsal)"}
 
     shard_primary = args.mode == "shard" and world > 1
@@ -607,7 +612,15 @@ def main():
         dog.start()
         try:
             wire_shard(ctx)
-            shard_res = shard_leg(args.shard_n, args.shard_grid_m, 1, 1)
+            shard_res = shard_leg(args.shard_n, args.shard_grid_m, 1, 1, dense=0)
+            # ... and north_star's own design, the dense path with the Gram product on the matrix cores, against the dense
+            # path on one GPU: the three predictions of DESIGN section 7 (replicas ~N x, lattice-sharded ~1.3-1.5 x, dense-sharded
+            # 5.6-6.2 x at 8 GPUs) are all in the first SCALE record
+            if not args.no_shard_dense:
+                try:
+                    shard_res["dense"] = shard_leg(args.shard_n, args.shard_grid_m, 1, 0, dense=1)
+                except Exception as e:                      # noqa: BLE001
+                    shard_res["dense"] = {"error": "%s: %s" % (type(e).__name__, e)}
         except Exception as e:                              # noqa: BLE001
             shard_res = {"error": "%s: %s" % (type(e).__name__, e)}
         dog.cancel()

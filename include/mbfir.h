@@ -103,6 +103,8 @@ typedef struct mbfir_info {
     double ms_cap;       /* capacitance form: device time of its three matrix-core products (Yt = U M', Zt = Yt M,
                             S = Yt Yt' + X^-1), summed over the builds                                     */
     double cap_flop;     /* ... and their flop, summed over the builds                                     */
+    double collective_bytes;   /* bytes the all-reduces of a row-sharded solve carried on this rank (dense path: the PACKED lower
+                                  triangle of the normal matrix per build, N (N + 1) / 2 doubles rounded up to 64 x 64 tiles)    */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to
@@ -188,8 +190,10 @@ typedef struct mbfir_program mbfir_program;
 int  mbfir_assemble(int which, int n, int nband, const double* f, const double* a, const double* d,
                     const double* params, int grid_m, mbfir_program** out, char* err, int errlen);
 void mbfir_program_free(mbfir_program* p);
-/* the rows process `rank` of `size` keeps in a row-sharded solve (see mbfir_opts.shard_*): frequencies
- * i % size == rank with their rows and cones; rows without a frequency go to rank 0 */
+/* the rows process `rank` of `size` keeps in a row-sharded solve (see mbfir_opts.shard_*): the frequencies are dealt out by
+ * folded +w / -w PAIRS (pair q goes to rank q % size: both partners on one rank, one lattice recurrence serves them) with their
+ * rows and cones; rows without a frequency (identity rows, spike / per-tap cones, the big cone) are REPLICATED on every rank and
+ * counted once in the sums over the rows (mbfir_program_rep) */
 int  mbfir_program_shard(const mbfir_program* p, int rank, int size, mbfir_program** out);
 /* dims[0..9] = Nt, Ne, R, l, nq3, big, Mf, quad(0/1), nnz_id, reserved */
 void mbfir_program_dims(const mbfir_program* p, int* dims);

@@ -83,6 +83,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->lattice = si.lattice;
     info->chol_launches = si.chol_launches; info->chol_flop = si.chol_flop; info->builds = si.h_builds;
     info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes; info->collectives = si.collectives;
+    info->collective_bytes = si.collective_bytes;
     info->ms_cap = si.ms_cap; info->cap_flop = si.cap_flop; info->dd_form = si.dd_iters > 0 ? si.dd_form : -1;
 }
 

@@ -46,6 +46,7 @@ struct SolveInfo {
     double ms_cap = 0, cap_flop = 0; // capacitance form: device time and flop of the three matrix-core products (Yt, Zt, S), summed over the builds
     int dd_form = 0;                 // which form of that solve ran (0 capacitance / double, 1 double-double)
     int collectives = 0;    // all-reduces the (row-sharded) solve issued
+    double collective_bytes = 0;   // ... and the bytes they carried (per rank)
     int lanes = 1;          // designs that shared the lock-step batch (ms_* are those of the whole batch)
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
 };

@@ -1661,6 +1661,22 @@ __global__ __launch_bounds__(256) void k_H_yy(DProg P, const double* __restrict_
     LANES(P, dl, w3, H, m3c);
     h_yy_block(P, dl, w3, H, ld, base, m3c, true);
 }
+// Dense row-sharded solves: the ranks' normal matrices are summed as their PACKED LOWER TRIANGLE (the 64 x 64 tiles (i, j <= i), one
+// after the other: nblk (nblk + 1) / 2 x 4096 doubles instead of np^2 -- the factorisation never reads a tile above the diagonal)
+__global__ __launch_bounds__(256) void k_pack_tril(const double* __restrict__ H, int np, double* __restrict__ out, int unpack) {
+    const int t = blockIdx.x;
+    int ti = int((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while ((long)ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    double* Hw = const_cast<double*>(H);
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int r = e >> 5, c2 = 2 * (e & 31);
+        double2* tile = reinterpret_cast<double2*>(out + (long)t * 4096 + r * 64 + c2);
+        double2* mat = reinterpret_cast<double2*>(Hw + ((long)ti * 64 + r) * np + (long)tj * 64 + c2);
+        if (unpack) *mat = *tile; else *tile = *mat;
+    }
+}
 __global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
     LANES(P, yy, H);
     const int e = threadIdx.x / 3, f = threadIdx.x % 3;
@@ -1903,9 +1919,11 @@ struct Solver::Impl {
     ncclComm_t comm = nullptr;
     int comm_size = 0, comm_rank = 0;
     long n_collectives = 0;      // issued by the current solve
+    double collective_bytes = 0; // ... and the bytes they carried
     void allreduce(double* buf, long count, int op) {
         if (shard_size <= 1) return;
         ++n_collectives;
+        collective_bytes += 8.0 * double(count);
         if (comm) {
             ncclResult_t r = rccl().AllReduce(buf, buf, size_t(count), ncclDouble, op == 1 ? ncclMax : ncclSum, comm, st);
             if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "failed"));
@@ -2392,7 +2410,21 @@ struct Solver::Impl {
                 }
             }
         }
-        if (!lead_factor()) allreduce(H, (long)P.np * P.np, 0);   // dense path: sum the shards' normal matrices
+        if (!lead_factor() && shard_size > 1) {
+            // dense path: sum the shards' normal matrices -- the packed lower triangle (M, rewritten by the factorisation that
+            // follows, is the staging buffer), in AR_CHUNKS collectives so that a ring's pipeline starts on the first tile rows
+            // while the later ones are still queued behind it (MBFIR_AR_CHUNKS; 1 = one collective)
+            const long nb = P.np / 64, ntile = nb * (nb + 1) / 2;
+            hipLaunchKernelGGL(k_pack_tril, dim3((unsigned)ntile), dim3(256), 0, st, H, P.np, M, 0);
+            int chunks = 4;
+            if (const char* ev = std::getenv("MBFIR_AR_CHUNKS")) chunks = std::max(1, std::atoi(ev));
+            chunks = int(std::min<long>(chunks, ntile));
+            for (int c = 0; c < chunks; ++c) {
+                const long lo = ntile * c / chunks, hi = ntile * (c + 1) / chunks;
+                allreduce(M + lo * 4096, (hi - lo) * 4096, 0);
+            }
+            hipLaunchKernelGGL(k_pack_tril, dim3((unsigned)ntile), dim3(256), 0, st, H, P.np, M, 1);
+        }
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
         if (ddk > 0 && cap_form) {
             // capacitance form: the ordinary double-precision factorisation of H_w, then Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1
@@ -2664,7 +2696,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (S.shard_size > 1 && !S.ar_fn && !S.comm) throw HipError("row-sharded solve without a communicator or an all-reduce hook");
     if (S.comm && S.shard_size > 1 && (S.comm_size != S.shard_size || S.comm_rank != S.shard_rank))
         throw HipError("row-sharded solve: shard_rank / shard_size differ from the RCCL communicator's");
-    S.n_collectives = 0;
+    S.n_collectives = 0; S.collective_bytes = 0;
     if (S.shard_size > 1 && nlanes > 1) throw ShapeError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
@@ -3205,6 +3237,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.lattice = P.trig;
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
+        info.collective_bytes = S.collective_bytes;
         info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
         info.dd_form = S.cap_form ? 0 : 1; info.cap_flop = S.cap_flop_sum; info.ms_cap = ms_cap;
         info.chol_launches = int(S.chol_launch_count);

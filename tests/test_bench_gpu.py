@@ -104,7 +104,10 @@ def test_two_rank_batch_bench_carries_the_shard_leg():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * 8) < 1e-6 * d["value"] * d["ms_per_step"]      # both ranks' designs
-    assert "error" not in d["shard"] and d["shard"]["scaling"] == "strong" and d["shard"]["value"] > 0
+    assert "error" not in d["shard"] and d["shard"]["scaling"] == "strong" and d["shard"]["value"] > 0 and d["shard"]["mode"] == "lattice"
+    # round 5: the same leg on the dense path (north_star's design: Gram product on the matrix cores, packed lower triangle all-reduced)
+    dd = d["shard"]["dense"]
+    assert "error" not in dd and dd["mode"] == "dense" and dd["value"] > 0 and dd["collective_MB_per_iteration"] > 0
 
 
 def test_plain_bench_with_gpus_2_starts_its_own_ranks():
