@@ -107,6 +107,55 @@ __device__ __forceinline__ void stb_sc1(rsrc_t r, unsigned voff, unsigned soff, 
     v.x = unsigned(__double2loint(x)); v.y = unsigned(__double2hiint(x));
     __builtin_amdgcn_raw_buffer_store_b64(v, r, int(voff), int(soff), 16);
 }
+// ---- hand-offs of the single-launch factorisation (k_chol_dag), XCD-LOCAL form (round 5) -----------------------------------
+// MI355X has eight XCDs with an L2 each; the L2s are not coherent with one another, which is why the hand-offs above write
+// through to memory (sc1 stores drop the line from the writer's L2) and every consumer's load misses its L2 and goes out to the
+// fabric -- the factorisation's 480 tasks per lane are a chain of such round trips (measured: with the tile products' MFMA loops
+// compiled out the build takes 57 % of its time).  But inside ONE XCD the L2 IS the point of coherence: if every task of a lane
+// runs on the same XCD, a plain store (write-through L1, line KEPT in the L2) is visible to every CU of that XCD as soon as it is
+// acknowledged, the consumer's sc1 load (past its L1) hits the L2, and the dependency counters can be L2 atomics.  So k_chol_dag
+// gives every lane an OWNER XCD -- the XCD of the first workgroup that asks, claimed by an agent-scope compare-and-swap -- and a
+// workgroup only ever draws tickets of lanes its own XCD owns (it reads HW_REG_XCC_ID; nothing is assumed about the dispatcher's
+// placement, which HIP does not promise: under the observed round-robin placement workgroup (lane, task) simply finds its own lane
+// owned by its XCD).  Correctness rests on "one XCD, one L2" alone; completeness (every ticket drawn) is checked by k_chol_check.
+// MEASURED AND NOT ADOPTED (round 5, tools/exp/r5_xcd.sh; the switch stays for the record, default 0 = the write-through form):
+// bit-identical on every size and lane count tried (0 words differ, alone and with four staggered units in flight; the placement
+// probe tools/exp/xcc_probe.hip shows the round-robin deal, so every workgroup found its own column's lane), and SLOWER: 16 lanes
+// alone 562 -> 610 us, four units in flight 32.0 -> 36.3 us per design and build, two lanes of np = 4096 on two XCDs 3.3 -> 13.3 ms.
+// The tasks' phase stamps do not move (operands landed 7.4 -> 7.6 us per inverse-row task, drain 0.83 -> 0.84): what a task waits
+// for after its polls is not the fabric round trip of an L2 miss, and confining a lane to the 64 slots of one XCD costs more
+// than L2-served hand-offs return.
+#ifndef CHOL_XCD_LOCAL
+#define CHOL_XCD_LOCAL 0
+#endif
+constexpr int DAG_AUX = CHOL_XCD_LOCAL ? 0 : 16;          // buffer-store cache policy of the hand-off stores: plain | sc1
+__device__ __forceinline__ void dag_st2(rsrc_t r, unsigned byte_off, double2 x) {
+    v4u v;
+    v.x = unsigned(__double2loint(x.x)); v.y = unsigned(__double2hiint(x.x));
+    v.z = unsigned(__double2loint(x.y)); v.w = unsigned(__double2hiint(x.y));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, int(byte_off), 0, DAG_AUX);
+}
+__device__ __forceinline__ void dag_stb(rsrc_t r, unsigned voff, unsigned soff, double x) {
+    v2u v;
+    v.x = unsigned(__double2loint(x)); v.y = unsigned(__double2hiint(x));
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, int(voff), int(soff), DAG_AUX);
+}
+__device__ __forceinline__ void dag_st(double* p, double v) {
+#if CHOL_XCD_LOCAL
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// the dependency counters: adds and flag stores in the owner XCD's L2 (workgroup scope: no sc1) -- the polls stay sc1 loads, which
+// pass the poller's L1 and read that L2
+#if CHOL_XCD_LOCAL
+#define DAG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#else
+#define DAG_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ __forceinline__ int dag_add(int* word, int n) { return __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, DAG_SCOPE); }
+__device__ __forceinline__ void dag_set(int* word, int v) { __hip_atomic_store(word, v, __ATOMIC_RELAXED, DAG_SCOPE); }
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -441,6 +490,7 @@ struct CholStep {
     int nlanes;
     const int* mask;         // nlanes ints (or null): lanes switched off
     int* cnt;                // single-launch form (k_chol_dag): the lane's dependency counters, see DagCnt
+    int ntasks;              // ... and its number of tasks
     int phase;               // 0: one launch per panel step, every row block factorises L_kk itself (lowest latency,
                              //    one design); 1: split step for lock-step batches in ONE launch -- the diagonal block
                              //    (one per lane) publishes the image of L_kk in Dfac and raises sync[k]; the row
@@ -524,6 +574,11 @@ __device__ __forceinline__ void signal_add(int* word) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void dag_signal_add(int* word) {
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) dag_add(word, 1);
+}
 
 // Dependency counters of the single-launch factorisation, nblk x nblk ints each, per lane (zeroed by k_chol_init):
 //   rowdone[k][i]  row blocks of tile (i, k) that have stored their 16 rows of L_ik                     (complete: 4)
@@ -533,15 +588,18 @@ __device__ __forceinline__ void signal_add(int* word) {
 //                  nblk = 32 the inverse rows accumulate their updates themselves -- minv_strip)   (0 .. i - j - 1)
 //   img[k]         1 once the image of L_kk and 1 / diag(L_kk) are in Dfac / dinvG;   ticket: the lane's task counter
 struct DagCnt {
-    int *rowdone, *tver, *msdone, *ruver, *img, *ticket;
+    int *rowdone, *tver, *msdone, *ruver, *img, *ticket, *done, *owner;
     int nblk;
     __device__ DagCnt(int* base, int nb) : nblk(nb) {
         rowdone = base; tver = base + nb * nb; msdone = base + 2 * nb * nb; ruver = base + 3 * nb * nb; img = base + 4 * nb * nb;
         ticket = img + nb;
+        done = ticket + 1;                                // tasks of the lane that have finished (k_chol_check)
+        owner = ticket + 64;                              // 1 + the XCD that owns the lane in this launch (0: nobody yet); a cache line of its own:
+                                                          // the one word here that XCDs contend for (agent-scope compare-and-swap)
     }
     __device__ int* at(int* arr, int a, int b) const { return arr + a * nblk + b; }
 };
-__host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4; }
+__host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4 + 96; }
 __host__ __device__ inline bool dag_ruform(int nblk) { return nblk > 32; }     // see dag_step
 
 template <bool FROM_IMAGE, bool DAG = false>
@@ -693,16 +751,16 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = 2 * (tid + 256 * u);
-                st2_sc1(ri, unsigned(e * 8), *reinterpret_cast<const double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]));
+                dag_st2(ri, unsigned(e * 8), *reinterpret_cast<const double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]));
             }
         } else {
             for (int e = tid; e < CB * CB; e += 256) __hip_atomic_store(a.Dfac + kk * CB + e, Lz[(e >> 6) * ZLD + (e & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid < CB) __hip_atomic_store(a.dinvG + kk + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < CB) { if constexpr (DAG) dag_st(a.dinvG + kk + tid, dinv[tid]); else __hip_atomic_store(a.dinvG + kk + tid, dinv[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         if (DAG || a.phase == 1) {                        // release the row blocks (and the inverse-row blocks) of this lane
             drain_stores();                               // every storing wave: its sc1 stores have left the CU ...
             __syncthreads();                              // ... before the one lane that signals for all of them does
-            if (tid == 0 && k != g_chol_lose_step) __hip_atomic_store(DAG ? dc.img + k : a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && k != g_chol_lose_step) { if constexpr (DAG) dag_set(dc.img + k, 1); else __hip_atomic_store(a.sync + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         TRACE(5)
         return;
@@ -716,8 +774,8 @@ __device__ __forceinline__ void panel_block(const CholStep& a, int b, double* sm
     TRACE(6)
     if constexpr (DAG) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st_sc1(H + (r0 + rho) * np + kk + lam + 16 * i, v[i]);
-        signal_add(dc.at(dc.rowdone, k, irow));
+        for (int i = 0; i < 4; ++i) dag_st(H + (r0 + rho) * np + kk + lam + 16 * i, v[i]);
+        dag_signal_add(dc.at(dc.rowdone, k, irow));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) H[(r0 + rho) * np + kk + lam + 16 * i] = v[i];
@@ -962,7 +1020,7 @@ __device__ __forceinline__ void strip_update(double* smem, const double* __restr
         mma64<TRANSB>(P, Q, 0, CB, acc);
         PH(3)
 #ifndef CHOL_EXP_NO_RMW     /* (the timing experiment does not write either) */
-        acc_foreach(acc, [&](int i, int j, double& v) { st_sc1(dst + (long)i * np + j, v); });
+        acc_foreach(acc, [&](int i, int j, double& v) { dag_st(dst + (long)i * np + j, v); });
 #endif
         __syncthreads();                                  // everybody is done reading Q: free for the next operand
         PH(4)
@@ -1065,14 +1123,14 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, int 
         subst16x2(Lz, dinv, va, vb);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            stb_sc1(rA, voS + 128 * i, unsigned((16 * q * np + kk) * 8), va[i]);
-            stb_sc1(rA, voS + 128 * i, unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
+            dag_stb(rA, voS + 128 * i, unsigned((16 * q * np + kk) * 8), va[i]);
+            dag_stb(rA, voS + 128 * i, unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
         }
     }
     PH(5)
     drain_stores();
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) dag_add(dc.at(dc.rowdone, k, irow), 4);
     PH(6)
 }
 
@@ -1171,15 +1229,15 @@ __device__ __forceinline__ void row_tile_block2(const CholStep& a, int irow, dou
             subst16x2(Lz, dinv, va, vb);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                stb_sc1(rA, voS + 128 * i, trow + unsigned((16 * q * np + kk) * 8), va[i]);
-                stb_sc1(rA, voS + 128 * i, trow + unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
+                dag_stb(rA, voS + 128 * i, trow + unsigned((16 * q * np + kk) * 8), va[i]);
+                dag_stb(rA, voS + 128 * i, trow + unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
             }
         }
     }
     PH(5)
     drain_stores();
     __syncthreads();
-    if (tid < 2) __hip_atomic_fetch_add(dc.at(dc.rowdone, k, irow + tid), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2) dag_add(dc.at(dc.rowdone, k, irow + tid), 4);
     PH(6)
 }
 
@@ -1291,12 +1349,12 @@ __device__ __forceinline__ void trail_left2(const CholStep& a, int i, int j, int
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            stb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + j0) * 8), x0[b][r]);
-            if (PAIR) stb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + j0) * 8), x1[b][r]);
+            dag_stb(rA, voX + 128 * b, unsigned((4 * r * np + j0) * 8), x0[b][r]);
+            if (PAIR) dag_stb(rA, voX + 128 * b, row1 + unsigned((4 * r * np + j0) * 8), x1[b][r]);
         }
     drain_stores();
     __syncthreads();
-    if (tid < (PAIR ? 2 : 1)) __hip_atomic_fetch_add(dc.at(dc.tver, i + tid, j), npan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < (PAIR ? 2 : 1)) dag_add(dc.at(dc.tver, i + tid, j), npan);
     PH(6)
 }
 
@@ -1475,7 +1533,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
             const rsrc_t rm = make_rsrc(M + kr * np + (long)j * CB + c0);
 #pragma unroll
             for (int u = 0; u < 8; u += 2)
-                st2_sc1(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
+                dag_st2(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
         }
         if (a.Mt) {                                       // the transpose for the second triangular GEMV, straight from the staging tile
             const int cr = tid >> 3, t8 = (tid & 7) * 8;  // 32 rows of Mt (columns of this pass) x 64 entries
@@ -1487,7 +1545,7 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
     }
     drain_stores();
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(dc.at(dc.msdone, r, j), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) dag_add(dc.at(dc.msdone, r, j), 4);
     PH(6)
 }
 
@@ -1634,7 +1692,7 @@ __device__ __forceinline__ void minv_pair(const CholStep& a, int r, int j, doubl
                 const rsrc_t rm = make_rsrc(M + (kr + row * CB) * np + (long)j * CB + 32 * pass);
 #pragma unroll
                 for (int u = 0; u < 8; u += 2)
-                    st2_sc1(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
+                    dag_st2(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
             }
             if (a.Mt) {                                                    // the transpose for the second triangular GEMV (np > 1024)
                 const int cr = tid >> 3, t8 = (tid & 7) * 8;
@@ -1661,7 +1719,7 @@ __device__ __forceinline__ void minv_pair(const CholStep& a, int r, int j, doubl
     }
     drain_stores();
     __syncthreads();
-    if (tid < 2) __hip_atomic_fetch_add(dc.at(dc.msdone, r + tid, j), 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2) dag_add(dc.at(dc.msdone, r + tid, j), 4);
     PH(6)
 }
 
@@ -1776,38 +1834,12 @@ __device__ int g_dag_log_tasks;        // tasks per lane
 #ifndef CHOL_PROBE_LDS_PAD
 #define CHOL_PROBE_LDS_PAD 0     /* experiment (tools/exp): extra doubles of LDS per workgroup, to lower the workgroups per CU */
 #endif
-#ifndef CHOL_DAG_WPS
-#define CHOL_DAG_WPS 2
-#endif
-__global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
-    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS + CHOL_PROBE_LDS_PAD];
-    __shared__ int s_ticket;
-    // (the lane as blockIdx.x % nlanes of a 1-D grid was vector arithmetic -- the division -- and put every per-lane base pointer
-    //  derived from it into vector registers, sixteen of them, spilled once the tasks grew)
-    const int lane = int(blockIdx.x);                     // grid (lanes, tasks): the lane straight from a scalar register
-    a.cnt = lane_at(a.cnt, (size_t)lane * a.lane_bytes);
+// one task: `a` is the lane's own (pointers shifted), tk its ticket, incl the running task totals of the steps (lane q of the wave:
+// steps 0 .. q; see k_chol_dag)
+__device__ __forceinline__ void dag_task(CholStep a, const int lane, const int tk, const int incl, double* smem, int& s_ticket) {
     const DagCnt dc(a.cnt, a.nblk);
-    // the ticket is drawn BEFORE the lane's mask is known (the mask word's load and the atomic's round trip overlap; a switched-off
-    // lane's counter is nobody's: k_chol_init clears it when the lane runs again)
-    int tk = 0;
-    if (threadIdx.x == 0) tk = __hip_atomic_fetch_add(dc.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.mask && !a.mask[lane]) return;
-    if (lane) {
-        const size_t off = (size_t)lane * a.lane_bytes;
-        a.H = lane_at(a.H, off); a.M = lane_at(a.M, off); a.d0 = lane_at(a.d0, off); a.Dfac = lane_at(a.Dfac, off);
-        a.dinvG = lane_at(a.dinvG, off); a.flag = lane_at(a.flag, off);
-        if (a.Mt) a.Mt = lane_at(a.Mt, off);
-    }
     DAG_STAT_BEGIN
-    // ticket -> (step, task of the step): lane q of every wave counts the tasks of step q, a wave scan gives the running totals --
-    // all of it while the ticket's atomic is in flight (a scalar loop over the steps took 1-2.5 us per task)
-    const int sl = int(threadIdx.x) & 63;
-    int incl = sl <= a.nblk ? dag_step_tasks(dag_step(a.nblk, sl)) : 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (sl >= d) incl += u; }
-    if (threadIdx.x == 0) s_ticket = tk;
-    __syncthreads();
-    int t = __builtin_amdgcn_readfirstlane(s_ticket);
+    int t = tk;
     const int k = __builtin_amdgcn_readfirstlane(__popcll(__ballot(incl <= t)));              // complete steps before the ticket (step 64 of nblk = 64: beyond the lanes)
     if (k > a.nblk || t < 0) { if (threadIdx.x == 0) atomicAdd(a.flag, CHOL_SYNC_LOST); return; }      // (a ticket word somebody else touched)
     if (k > 0) t -= __builtin_amdgcn_readfirstlane(__shfl(incl, k - 1, 64));
@@ -1827,7 +1859,7 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
         __syncthreads();
         const long i0 = (long)i * CB, j0 = (long)j * CB, km = (long)(k - 1) * CB;
         strip_update<true>(smem, a.H + i0 * np + km, a.H + j0 * np + km, 0, a.H + i0 * np + j0, 0, -1, 1, np);
-        signal_add(dc.at(dc.tver, i, j));
+        dag_signal_add(dc.at(dc.tver, i, j));
         DAG_STAT_END(1)
         return;
     }
@@ -1885,7 +1917,7 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
         strip_update<true>(smem, a.H + i0 * np + km, a.H + (long)j0 * CB * np + km, (long)CB * np, a.H + i0 * np + (long)j0 * CB, CB, -1, cnt, np);
         drain_stores();
         __syncthreads();
-        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (int(threadIdx.x) < cnt) dag_add(dc.at(dc.tver, i, j0 + int(threadIdx.x)), 1);
         PH(6)
         DAG_STAT_END(5)
         return;
@@ -1921,7 +1953,7 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
                             k - 2 - j0, cnt, np);
         drain_stores();
         __syncthreads();
-        if (int(threadIdx.x) < cnt) __hip_atomic_fetch_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (int(threadIdx.x) < cnt) dag_add(dc.at(dc.ruver, i, j0 + int(threadIdx.x)), 1);
         DAG_STAT_END(3)
         return;
     }
@@ -1938,6 +1970,100 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
 #endif
     }
     DAG_STAT_END(4)
+}
+
+#ifndef CHOL_DAG_WPS
+#define CHOL_DAG_WPS 2
+#endif
+constexpr int DAG_SWEEP_ROWS = 2;      // the workgroups of the last task rows of the grid go on drawing tickets until their XCD's lanes have none left
+// Grid (lanes rounded up to a multiple of 8, tasks per lane): x runs fastest, so under the observed round-robin placement of
+// consecutive workgroups on the eight XCDs the workgroups of one lane all land on one XCD -- which then owns the lane (see the
+// XCD-local hand-offs at the top of this file).  Nothing depends on that placement for correctness: a workgroup reads its XCD from
+// HW_REG_XCC_ID and only draws tickets of lanes its XCD owns (its own column's lane first, then the others); where the placement
+// leaves an XCD short of workgroups for its lanes' tasks, the sweepers of the last rows finish them, and k_chol_check holds every
+// lane to its task count.
+__global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS + CHOL_PROBE_LDS_PAD];
+    __shared__ int s_ticket, s_lane;
+    // ticket -> (step, task of the step): lane q of every wave counts the tasks of step q, a wave scan gives the running totals --
+    // all of it while the ticket's atomic is in flight (a scalar loop over the steps took 1-2.5 us per task)
+    const int sl = int(threadIdx.x) & 63;
+    int incl = sl <= a.nblk ? dag_step_tasks(dag_step(a.nblk, sl)) : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (sl >= d) incl += u; }
+    const int nl = a.nlanes;
+    int pref = int(blockIdx.x) < nl ? int(blockIdx.x) : int(blockIdx.x) % nl;
+#if CHOL_XCD_LOCAL
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15) + 1;
+    const bool sweeper = int(blockIdx.y) + DAG_SWEEP_ROWS >= int(gridDim.y);
+#else
+    if (int(blockIdx.x) >= nl) return;
+#endif
+    // one ticket: choose the lane, draw, run the task; false when this workgroup's XCD has no ticket left
+    auto serve = [&]() -> bool {
+        if (threadIdx.x == 0) {
+            int got_lane = -1, got_t = 0;
+#if CHOL_XCD_LOCAL
+            for (int q = 0; q < nl && got_lane < 0; ++q) {
+                const int l = pref + q < nl ? pref + q : pref + q - nl;
+                if (a.mask && !a.mask[l]) continue;
+                const DagCnt dl(lane_at(a.cnt, (size_t)l * a.lane_bytes), a.nblk);
+                int o = __hip_atomic_load(dl.owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o == 0) {                                 // nobody's yet: the first XCD to ask owns the lane for this launch
+                    int expect = 0;
+                    o = __hip_atomic_compare_exchange_strong(dl.owner, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? xcc : expect;
+                }
+                if (o != xcc) continue;
+                const int t = dag_add(dl.ticket, 1);
+                if (t < a.ntasks) { got_lane = l; got_t = t; }
+            }
+#else
+            // the ticket is drawn whether or not the lane is switched off (a switched-off lane's counter is nobody's: k_chol_init
+            // clears it when the lane runs again)
+            const DagCnt dl(lane_at(a.cnt, (size_t)pref * a.lane_bytes), a.nblk);
+            const int t = dag_add(dl.ticket, 1);
+            if (!(a.mask && !a.mask[pref]) && t < a.ntasks) { got_lane = pref; got_t = t; }
+#endif
+            s_lane = got_lane; s_ticket = got_t;
+        }
+        __syncthreads();
+        const int lane = __builtin_amdgcn_readfirstlane(s_lane);
+        if (lane < 0) return false;
+        const int tk = __builtin_amdgcn_readfirstlane(s_ticket);
+        CholStep al = a;
+        {
+            const size_t off = (size_t)lane * a.lane_bytes;
+            al.H = lane_at(a.H, off); al.M = lane_at(a.M, off); al.d0 = lane_at(a.d0, off); al.Dfac = lane_at(a.Dfac, off);
+            al.dinvG = lane_at(a.dinvG, off); al.flag = lane_at(a.flag, off); al.cnt = lane_at(a.cnt, off);
+            if (a.Mt) al.Mt = lane_at(a.Mt, off);
+        }
+        dag_task(al, lane, tk, incl, smem, s_ticket);
+        __syncthreads();                                  // everybody is done with the task's LDS and with s_lane / s_ticket
+#if CHOL_XCD_LOCAL
+        if (threadIdx.x == 0) dag_add(DagCnt(al.cnt, a.nblk).done, 1);
+#endif
+        pref = lane;
+        return true;
+    };
+    // (the first task outside the sweepers' loop: inside a loop the compiler hoists every task kind's per-thread address arithmetic
+    //  in front of it and spills what it hoisted)
+    if (!serve()) return;
+#if CHOL_XCD_LOCAL
+    if (!sweeper) return;
+#pragma unroll 1
+    while (serve()) {}
+#endif
+}
+
+// every live lane has run all its tasks (a lane whose XCD never received a workgroup would otherwise go unnoticed: the ticket scheme
+// guarantees that a drawn ticket is served, not that every ticket is drawn); a shortfall raises CHOL_SYNC_LOST like a lost hand-off
+__global__ void k_chol_check(int* cnt, int nblk, int ntasks, int* flag, size_t lane_bytes, const int* mask, int nlanes) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlanes || (mask && !mask[l])) return;
+    const DagCnt dc(lane_at(cnt, (size_t)l * lane_bytes), nblk);
+    if (*dc.done != ntasks) atomicAdd(lane_at(flag, (size_t)l * lane_bytes), CHOL_SYNC_LOST);
 }
 
 // nsync: ints to clear at sync (the panel flags of the split step, or the counters of the single-launch form);
@@ -2058,7 +2184,11 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         int ntasks = 0;
         for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
         a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
-        hipLaunchKernelGGL(k_chol_dag, dim3(nlanes, ntasks), dim3(256), 0, st, a);      // (x runs fastest: the lanes' workgroups are dealt out alternately)
+        a.ntasks = ntasks;
+        // (x runs fastest: the lanes' workgroups are dealt out alternately; x padded to a multiple of 8 so that a column of the grid
+        //  keeps its XCD under round-robin placement -- the surplus columns help the lanes their XCD owns)
+        hipLaunchKernelGGL(k_chol_dag, dim3(CHOL_XCD_LOCAL ? (nlanes + 7) / 8 * 8 : nlanes, ntasks), dim3(256), 0, st, a);
+        if (CHOL_XCD_LOCAL) hipLaunchKernelGGL(k_chol_check, dim3(1), dim3(64), 0, st, a.cnt, nblk, ntasks, flag, lane_bytes, mask, nlanes);
         if (e1) hipEventRecord(e1, st);
         if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
         return 1;
