@@ -1416,12 +1416,20 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
         v4d x[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
 #pragma unroll 1
         for (int pq = j; pq <= r - 2; ++pq) {
+#ifdef CHOL_DAG_STATS      /* phase 7: waiting for the prefetched operand pair; phase 5 (no substitution ran yet): the LDS stores; phase 2: the barrier */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PH(7)
+#endif
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = tid + 256 * u;
                 *reinterpret_cast<double2*>(&P[e >> 5][2 * (e & 31)]) = at[u];
                 *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u];
             }
+#ifdef CHOL_DAG_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PH(0)
+#endif
             __syncthreads();
             PH(2)
             if (pq + 1 <= r - 2) fetch_pair(pq + 1);

@@ -96,8 +96,8 @@ static void dag_stats(const char* what) {
         if (!cnt[q]) continue;
         printf("  %-22s %6.0f tasks  %6.2f us each, of which %5.2f us in polls   %5.1f %% of the workgroup-time", names[q], cnt[q], cnt[q] ? 0.01 * dur[q] / cnt[q] : 0.0,
                cnt[q] ? 0.01 * wt[q] / cnt[q] : 0.0, 100.0 * dur[q] / tot);
-        printf("   phases (us per task) ticket %.2f poll %.2f landed %.2f products %.2f epilogue %.2f subst %.2f drain %.2f\n", 0.01 * ph[q][0] / cnt[q], 0.01 * ph[q][1] / cnt[q],
-               0.01 * ph[q][2] / cnt[q], 0.01 * ph[q][3] / cnt[q], 0.01 * ph[q][4] / cnt[q], 0.01 * ph[q][5] / cnt[q], 0.01 * ph[q][6] / cnt[q]);
+        printf("   phases (us per task) ticket %.2f poll %.2f landed %.2f products %.2f epilogue %.2f subst %.2f drain %.2f other %.2f\n", 0.01 * ph[q][0] / cnt[q], 0.01 * ph[q][1] / cnt[q],
+               0.01 * ph[q][2] / cnt[q], 0.01 * ph[q][3] / cnt[q], 0.01 * ph[q][4] / cnt[q], 0.01 * ph[q][5] / cnt[q], 0.01 * ph[q][6] / cnt[q], 0.01 * ph[q][7] / cnt[q]);
     }
     // the chain: start-to-start of the diagonal blocks of lane 0
     printf("  lane 0 diagonal blocks (start, duration, in polls; us):");
