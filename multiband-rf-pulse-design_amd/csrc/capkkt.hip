@@ -24,6 +24,7 @@ namespace mbfir {
 
 namespace {
 constexpr int TB = 64, TLD = 66;
+constexpr int CAP_SPLIT = 4;      // parts of a tile's K range (see k_cap_gemm)
 
 // acc[a][b] += A(64 x 64 tile in As) * op(B tile in Bs): each of the 4 waves owns a 32 x 32 quadrant (2 x 2 MFMA blocks);
 // v_mfma_f64_16x16x4_f64 operand layout: a = A[i = lane % 16][k = lane / 16], b = B[k = lane / 16][j = lane % 16],
@@ -73,9 +74,13 @@ __device__ __forceinline__ void store_tile(double (*S)[TLD], const TileRegs& R, 
 // MODE 1:  C = A B ,  B = M lower-triangular:            C[r][i] = sum_{j >= i} A[r][j] M[j][i]        (Zt = Yt M)
 // MODE 2:  C = A A' + diag (lower tiles only):           C[r][q] = sum_j A[r][j] A[q][j]               (S = Yt Yt' + X^-1)
 //          diag: 1 / X[r] for r < k, 1 for the padding rows r >= k (whose rows of A are zero)
+// Split over K (round 5): blockIdx.z takes the z-th of gridDim.z contiguous parts of the tile's K range and writes its partial
+// product to the slab C + z * slab_stride; k_cap_fold adds the parts in a fixed order (and the diagonal term of MODE 2).  One
+// block per 64 x 64 tile left 170 blocks for 256 CUs, each a serial chain of up to 17 (load, two barriers, 64 MFMAs per wave)
+// steps with nothing to overlap them: 0.087 of the fp64 matrix peak.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int np, int ldc,
-                                                  const double* __restrict__ X, int k) {
+                                                  long slab_stride) {
     __shared__ __attribute__((aligned(16))) double As[TB][TLD];
     __shared__ __attribute__((aligned(16))) double Bs[TB][TLD];
     int rb, cb;
@@ -89,7 +94,13 @@ __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, 
         rb = blockIdx.y; cb = blockIdx.x;
     }
     const int nblk = np / TB;
-    const int j0 = MODE == 1 ? cb : 0, j1 = MODE == 0 ? cb + 1 : nblk;
+    int j0 = MODE == 1 ? cb : 0, j1 = MODE == 0 ? cb + 1 : nblk;
+    {
+        const int span = j1 - j0, z = blockIdx.z, nz = gridDim.z;
+        const int lo = j0 + int((long)span * z / nz), hi = j0 + int((long)span * (z + 1) / nz);
+        j0 = lo; j1 = hi;
+        C += (long)z * slab_stride;
+    }
     v4d acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -121,10 +132,20 @@ __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = rb * TB + wi * 32 + a * 16 + (lane >> 4) + 4 * q, c = cb * TB + wj * 32 + b * 16 + (lane & 15);
-                double v = acc[a][b][q];
-                if (MODE == 2 && r == c) v += r < k ? 1.0 / X[r] : 1.0;
-                C[(long)r * ldc + c] = v;
+                C[(long)r * ldc + c] = acc[a][b][q];
             }
+}
+// C = sum of the nsplit partial products of the slab (fixed order); MODE 2: the lower tiles only, plus the diagonal term
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cap_fold(const double* __restrict__ part, int nsplit, long slab_stride, double* __restrict__ C, int rows, int ldc,
+                                                  const double* __restrict__ X, int k) {
+    const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows || c >= ldc) return;
+    if (MODE == 2 && (c / TB) > (r / TB)) return;
+    double v = 0.0;
+    for (int z = 0; z < nsplit; ++z) v += part[(long)z * slab_stride + (long)r * ldc + c];
+    if (MODE == 2 && r == c) v += r < k ? 1.0 / X[r] : 1.0;
+    C[(long)r * ldc + c] = v;
 }
 
 // rw = a + b  (NV vectors of np entries, stride ldv; entries past n are zeroed)
@@ -197,12 +218,18 @@ __global__ void k_cap_flag_add(int* __restrict__ flag, const int* __restrict__ m
 
 // Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1 (lower tiles; padding rows k .. kp-1 get a unit diagonal).  U: kp x np with zero rows from k on;
 // M: the inverse Cholesky factor of H_w (lower triangle valid); S: kp x kp.
-void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, hipStream_t st) {
-    const dim3 g(np / TB, kp / TB);
-    hipLaunchKernelGGL(k_cap_gemm<0>, g, dim3(256), 0, st, U, M, Yt, np, np, (const double*)nullptr, 0);
-    hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, Zt, np, np, (const double*)nullptr, 0);
+size_t cap_part_doubles(int kmax, int np) { return (size_t)CAP_SPLIT * kmax * (size_t)std::max(np, kmax); }
+void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, double* part,
+                      hipStream_t st) {
     const int kb = kp / TB;
-    hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2), dim3(256), 0, st, Yt, (const double*)nullptr, S, np, kp, X, k);
+    const long sA = (long)kp * np, sS = (long)kp * kp;
+    const dim3 g(np / TB, kb, CAP_SPLIT), gf(cdiv(np, 256), kp), gs(cdiv(kp, 256), kp);
+    hipLaunchKernelGGL(k_cap_gemm<0>, g, dim3(256), 0, st, U, M, part, np, np, sA);
+    hipLaunchKernelGGL(k_cap_fold<0>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Yt, kp, np, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, part, np, np, sA);
+    hipLaunchKernelGGL(k_cap_fold<1>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Zt, kp, np, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2, 1, CAP_SPLIT), dim3(256), 0, st, Yt, (const double*)nullptr, part, np, kp, sS);
+    hipLaunchKernelGGL(k_cap_fold<2>, gs, dim3(256), 0, st, part, CAP_SPLIT, sS, S, kp, kp, X, k);
     MBFIR_HIP(hipGetLastError());                         // (a refused launch -- grid, LDS -- would otherwise surface iterations later as a wrong step)
 }
 void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st) {

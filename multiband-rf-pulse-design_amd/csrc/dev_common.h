@@ -126,7 +126,9 @@ void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const
 // Capacitance form of the extended-precision solve (capkkt.hip): Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1 on the fp64 matrix cores
 // (U: kp x np with zero rows from k on; M: inverse Cholesky factor of the capped normal matrix, lower triangle; S: kp x kp,
 // lower tiles, unit diagonal on the padding rows), and the vector kernels of its solves
-void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, hipStream_t st);
+void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, double* part,
+                      hipStream_t st);
+size_t cap_part_doubles(int kmax, int np);                // the split-K slab `part` of cap_build_launch
 void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st);
 void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st);
 void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st);

@@ -1677,6 +1677,12 @@ __global__ __launch_bounds__(256) void k_pack_tril(const double* __restrict__ H,
         if (unpack) *mat = *tile; else *tile = *mat;
     }
 }
+__global__ void k_zero3(double* __restrict__ a, long na, double* __restrict__ b, long nb, double* __restrict__ c, long nc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = 0.0;
+    if (i < nb) b[i] = 0.0;
+    if (i < nc) c[i] = 0.0;
+}
 __global__ void k_H_yy_add(DProg P, const double* __restrict__ yy, double* __restrict__ H) {
     LANES(P, yy, H);
     const int e = threadIdx.x / 3, f = threadIdx.x % 3;
@@ -1978,7 +1984,7 @@ struct Solver::Impl {
     // counter of that factorisation, capw the right-hand side of the S solve
     bool cap_form = true;
     int dd_passes = 2;           // refinement passes on the augmented system around the extended-precision solve (MBFIR_DD_PASSES, <= 8: the norm slots)
-    double *capYt = nullptr, *capZt = nullptr, *capS = nullptr, *capMs = nullptr, *capW1 = nullptr, *capw = nullptr;
+    double *capYt = nullptr, *capZt = nullptr, *capS = nullptr, *capMs = nullptr, *capW1 = nullptr, *capw = nullptr, *capPart = nullptr;
     int* capflag = nullptr;
     int dd_k = 0;                 // strong directions of the current iteration (0: plain double-precision solve)
     int dd_iters = 0, dd_kmax_seen = 0;
@@ -2238,7 +2244,7 @@ struct Solver::Impl {
             nbp += 1;
         }
         for (int attempt = 0; attempt < 8; ++attempt) {
-            hipMemsetAsync(D.kcnt, 0, sizeof(int), st);
+            if (attempt > 0) hipMemsetAsync(D.kcnt, 0, sizeof(int), st);        // (the first attempt's counter was cleared by k_dd_prep)
             hipLaunchKernelGGL(k_dd_select, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, D, partR, nbp, theta);
             hipLaunchKernelGGL(k_dd_order, dim3(1), dim3(1024), 0, st, P, D);
             MBFIR_HIP(hipMemcpyAsync(hostFlag + 1, D.kcnt, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2256,9 +2262,8 @@ struct Solver::Impl {
         const dim3 gC(std::max(nbC, 1)), b256(256);
         const int k = dd_k;
         double *Bh = ddB, *Bl = ddB + 2L * P.LDV;
-        hipMemsetAsync(dx, 0, sizeof(double) * NV * P.LDV, st);
-        hipMemsetAsync(dz, 0, sizeof(double) * NV * P.Rp, st);
-        hipMemsetAsync(gdx, 0, sizeof(double) * NV * P.Rp, st);
+        // (one launch instead of three memsets: the trace of BASELINE config 3's batch held 10 348 fill kernels)
+        hipLaunchKernelGGL(k_zero3, dim3(cdiv(NV * std::max<long>(P.LDV, P.Rp), 256)), dim3(256), 0, st, dx, long(NV) * P.LDV, dz, long(NV) * P.Rp, gdx, long(NV) * P.Rp);
         for (int it = 0; it < dd_passes; ++it) {
             apply_GT<NV>(dz, tmpN);
             hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
@@ -2431,11 +2436,10 @@ struct Solver::Impl {
             // on the matrix cores and the same factorisation routine on S (kp x kp)
             const int kp = int(round_up(ddk, 64));
             chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, 1, 0, nullptr);
-            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
-            if (kp > ddk) hipMemsetAsync(D.U + (size_t)ddk * P.np, 0, sizeof(double) * (size_t)(kp - ddk) * P.np, st);
+            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(kp), nlanes), dim3(256), 0, st, P, D, P.np, ddk);      // (rows ddk .. kp-1: zero padding)
             hipEvent_t b0 = timing ? next_cap_event() : nullptr, b1 = timing ? next_cap_event() : nullptr;
             if (b0) hipEventRecord(b0, st);
-            cap_build_launch(D.U, ddk, kp, P.np, M, D.sX, capYt, capZt, capS, st);
+            cap_build_launch(D.U, ddk, kp, P.np, M, D.sX, capYt, capZt, capS, capPart, st);
             if (b1) hipEventRecord(b1, st);
             // Yt and Zt: kp x np x np / 2 multiply-adds each (triangular M); S: kp x kp x np / 2 (lower tiles)
             cap_flop_sum += 2.0 * (double(kp) * P.np * P.np + 0.5 * double(kp) * kp * P.np);
@@ -2443,7 +2447,7 @@ struct Solver::Impl {
             cap_flag_add_launch(flag, capflag, st);           // pivots replaced in either factorisation count (oracle: chol_fixes += nfs)
         } else if (ddk > 0) {
             if (c0) hipEventRecord(c0, st);
-            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np);
+            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(ddk), nlanes), dim3(256), 0, st, P, D, P.np, ddk);
             dd_syrk_launch(D.U, P.np, D.sX, D.kcnt, P.np, H, M, st);
             dd_chol_launch(H, M, Mt, W1, ddri, ddri + P.np, ddd0, P.np, DD_PIVTOL, flag, st, ddinv);
             if (c1) hipEventRecord(c1, st);
@@ -2885,6 +2889,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             S.capS = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX); S.capMs = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX);
             S.capW1 = ar.get<double>((size_t)CAP_KMAX * CAP_KMAX + 65 * (size_t)CAP_KMAX); S.capw = ar.get<double>(2 * (size_t)DD_KMAX);
             S.capflag = ar.get<int>(4);
+            S.capPart = ar.get<double>(cap_part_doubles(CAP_KMAX, int(np)));
         }
     }
     S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
