@@ -3003,10 +3003,34 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     int graph_builds = 0;
     const IterGraph* last_graph = nullptr;
     launch_residuals();
+    // The head of the NEXT iteration -- NT scaling, normal matrix, factorisation: everything that depends on the iterate (s, z) alone --
+    // goes to the stream BEFORE the host has looked at this iterate's scalars (round 5): the host waits on an event behind the
+    // scalars' copy, not on the stream, so the GPU works on the head (~0.5 ms) while the host wakes up, takes its decisions
+    // (verdicts, sweep counts, masks) and issues the rest of the iteration behind it.  Before, the stream stood empty for that long
+    // every iteration (single design: ~100 us of a 780 us iteration; a lock-step unit alone: 1.46 ms wall for 1.33 ms of kernels).
+    // A lane the host then retires has had one scaling and factorisation too many (it runs under the previous iteration's masks):
+    // they touch nothing the result is read from.  Not with the extended-precision solve (its strong-set count needs the host
+    // mid-head), row-sharded solves and launch graphs.  MBFIR_SPECULATE=0 restores the old order.
+    bool speculate = !use_dd && !sharded && !use_graph;
+    if (const char* ev = std::getenv("MBFIR_SPECULATE")) speculate = speculate && std::atoi(ev) != 0;
+    auto launch_head = [&]() {
+        hipLaunchKernelGGL(k_scaling, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
+        if (P.big) hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.s, S.z, S.wbb, S.lam, S.Sc);
+        S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
+        if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
+        dd_now = S.dd_k > 0;
+        S.build_H(S.dd_k);
+    };
     for (it = 0; it <= o.max_iter; ++it) {
         MBFIR_HIP(hipMemcpy2DAsync(S.hostSc, sizeof(double) * S_COUNT, S.Sc, S.lane_bytes, sizeof(double) * S_COUNT, nlanes, hipMemcpyDeviceToHost, st));
+        const bool head_out = speculate && it < o.max_iter;
+        if (head_out) {
+            MBFIR_HIP(hipEventRecord(S.ev0, st));
+            launch_head();
+        }
         const double t_sync0 = trace_host ? now_ms() : 0.0;
-        MBFIR_HIP(hipStreamSynchronize(st));
+        if (head_out) MBFIR_HIP(hipEventSynchronize(S.ev0));
+        else MBFIR_HIP(hipStreamSynchronize(st));
         if (trace_host) { const double t1 = now_ms(); host_issue_ms += t_sync0 - t_issue0; host_wait_ms += t1 - t_sync0; t_issue0 = t1; }
         if (last_graph && S.timing) {                         // (gram begin, gram end, chol begin, chol end) of the replay just finished
             for (size_t e = last_graph->ev_lo; e + 3 < last_graph->ev_hi; e += 4) {
@@ -3094,13 +3118,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             if (LH[b].live) nsweep_max = std::max(nsweep_max, LH[b].nsweep);
         push_masks();
         auto launch_body = [&]() {
-        // scaling + H
-        hipLaunchKernelGGL(k_scaling, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
-        if (P.big) hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.s, S.z, S.wbb, S.lam, S.Sc);
-        S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
-        if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
-        dd_now = S.dd_k > 0;
-        S.build_H(S.dd_k);
+        // scaling + H (already on the stream when the head went out ahead of the host)
+        if (!head_out) launch_head();
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
         if (S.dd_k > 0) S.kkt_solve_dd<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, S_RNA);
         else S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep_max, S_RNA, true);  // W^-2 bz2 came with k_scaling
