@@ -117,7 +117,9 @@ constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement
 
 // ------------------------------------------------------------------------------------------------
 // device-side problem description
-struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, pad0, pad1; };
+// (round 5: a unit may also hold designs of different ORDERS -- the probes of a min-order search: the dimensions that move with the
+//  order follow the six that move with the band edges)
+struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, Nt, N, nq3, big, D1, seg, useg, pad0, pad1, pad2; };
 struct DProg {
     int Nt, Ne, N, Mf, R, l, nq3, big, quad;
     int ld, Mpad, LDV, Rp, np;
@@ -166,6 +168,11 @@ struct DProg {
     __device__ __forceinline__ void load_dims(int lane) {
         const LaneDims d = dims[lane];
         Mf = d.Mf; R = d.R; l = d.l; nyrows = d.nyrows; nfold = d.nfold; nchunk = d.nchunk;
+        // ... and the lane's own order: unknowns, cone counts, lattice extent and its segments.  The STRIDES (ld, LDV, Rp, np, LDM,
+        // Mpad) stay the unit's: a shorter lane's vectors and matrices sit in the same layout, padded -- H by identity rows and
+        // columns, which the factorisation passes through untouched (the same blocks see the same arithmetic as in the lane's
+        // single solve at its own np; the padding blocks factorise to the identity)
+        Nt = d.Nt; N = d.N; nq3 = d.nq3; big = d.big; D1 = d.D1; seg = d.seg; useg = d.useg;
     }
     template <class T>
     __device__ __forceinline__ static void sh(const T*& p, size_t off) { p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + off); }
@@ -562,8 +569,9 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
 // seed tables for the recurrences below (once per design)
 __global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb, double4* __restrict__ seeds) {
     LANES(P, seeds);
+    if (P.dims) { na = P.D1; nb = nb ? 2 * P.D1 - 1 : 0; }      // (the launch carries the unit's largest extent: the lane's own)
     const int m = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
-    if (m >= na + nb) return;
+    if (m >= na + nb || ch >= P.nchunk) return;
     const double t = m < na ? t0a + m : t0b + (m - na);
     double s, c, sd, cd;
     sincos(P.ch_w0[ch] * t, &s, &c);
@@ -632,6 +640,7 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double2* __
                                                       int na, int nb, double* __restrict__ partial) {
     if (!P.seeds_shared && blockIdx.z) seeds = reinterpret_cast<const double4*>(reinterpret_cast<const char*>(seeds) + (size_t)blockIdx.z * P.lane_bytes);
     LANES(P, src, partial);
+    if (P.dims) { na = P.D1; nb = nb ? 2 * P.D1 - 1 : 0; }      // (the launch carries the unit's largest extent: the lane's own)
     __shared__ double2 pp[NV][CGRP][CHK];                 // (pe, po)
     const int tid = threadIdx.x;
     const int ch0 = blockIdx.y * P.cgrp;
@@ -1945,6 +1954,7 @@ struct Solver::Impl {
     // lock-step batch: nlanes designs of identical shape in one arena, lane b at + b * lane_bytes (see DProg)
     int nlanes = 1, nlanes_last = 1;
     bool taps_valid = false;     // hout holds the taps of the last unit's solutions (specfact_last)
+    int lane_n[64] = {};         // taps of the lanes of the last unit (they differ when the unit held designs of different orders)
     long chol_launch_count = 0;  // k_chol_step launches of the current solve
     size_t lane_bytes = 0;
     bool lane_live[64] = {};     // host copy of mask row 0 (the dense Gram products are launched per lane)
@@ -2623,12 +2633,21 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     long tbits = 0;
     std::memcpy(&tbits, &Lt.tmin, sizeof(double));
     // the CLASS of the program: what all lanes of a unit must share (solve_lanes)
-    std::vector<long> key{long(Q.which), long(Q.n), long(Q.Nt), long(Q.Ne), long(Q.nq3), long(Q.big), long(Q.quad), long(pr->c_rows.size()),
-                          long(Lt.ok), long(Lt.D1), tbits};
+    // (round 5: designs of different ORDERS share a unit too -- the probes of a min-order search -- when their padded sizes fall into
+    //  the same power-of-two bucket: a unit runs every lane at the size of its largest)
+    long bucket = 64;
+    while (bucket < round_up(Q.N(), 64)) bucket *= 2;
+    std::vector<long> key{long(Q.which), bucket, long(Q.Ne), long(Q.nq3 > 0), long(Q.big > 0), long(Q.quad), long(Lt.ok), tbits};
     // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path; MBFIR_HETERO=0:
     // round 3's rule everywhere), the exact shape: grid, rows, chunks
     bool exact = !Lt.ok || o.dense_trig;
     if (const char* ev = std::getenv("MBFIR_HETERO")) exact = exact || std::atoi(ev) == 0;
+    int hetero_orders = 1;
+    if (const char* ev = std::getenv("MBFIR_HETERO_ORDERS")) hetero_orders = std::atoi(ev);
+    if (exact || !hetero_orders) {                            // (round 4's rule: one order per unit)
+        const long ord[] = {long(Q.n), long(Q.Nt), long(Q.nq3), long(Q.big), long(pr->c_rows.size()), long(Lt.D1)};
+        key.insert(key.end(), std::begin(ord), std::end(ord));
+    }
     if (exact) {
         const long more[] = {long(Q.Mf), long(Q.R), long(Q.l), long(pr->f_rows.size()), long(pr->yrows.size()), long(Lt.ch_start.size()), long(Lt.wf.size())};
         key.insert(key.end(), std::begin(more), std::end(more));
@@ -2663,7 +2682,15 @@ int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
     // lock-step batches exist on the lattice path only; the extended-precision KKT solve (on by default for
     // fir_qp_cvx) and row-sharded solves run one design at a time
     if (o.shard_size > 1 || o.ddkkt_theta > 0) return 1;
-    const long np = round_up(Q.N(), 64);
+    long np = round_up(Q.N(), 64);
+    if (!(o.dense_trig || !lane_prep(Q, o)->Lt.ok)) {        // (lattice path: designs of one size bucket share units -- shape_key -- and a unit
+        long bucket = 64;                                     //  is as large as its largest lane)
+        while (bucket < np) bucket *= 2;
+        int hetero_orders = 1;
+        if (const char* ev = std::getenv("MBFIR_HETERO_ORDERS")) hetero_orders = std::atoi(ev);
+        if (const char* ev = std::getenv("MBFIR_HETERO")) hetero_orders = hetero_orders && std::atoi(ev) != 0;
+        if (hetero_orders) np = bucket;
+    }
     long cap = std::min<long>(32, 16384 / np);
     if (o.dense_trig || !lane_prep(Q, o)->Lt.ok) {
         // dense path (opts.dense_trig, or a grid / column set without the lattice structure): every lane materialises
@@ -2740,42 +2767,55 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     // ---- the unit: one CLASS (designer, order, unknowns, cones, lattice extent); within it the lanes' grids, row counts and
     // chunk lists may differ (designs of one order with different band edges: the probes of fir_ap.m:63-106, sweeps over
     // specs) -- arrays and launches are then sized to the unit's maxima and every lane carries its own dimensions (DProg::dims)
+    // (round 5: the ORDER may differ too -- the probes of a min-order search, fir_ap.m:143-176, ss/fir_min_order_linprog.m:98-145:
+    //  unknowns, cone counts, lattice extent and taps become per-lane dimensions like the six above; what stays common is the
+    //  designer, the slack columns, the kind of cones and the lattice's origin)
     int Mf_max = Q.Mf, R_max = Q.R, l_max = Q.l, nyrows_max = int(LH[0].yrows.size());
+    int Nt_max = Q.Nt, nq3_max = Q.nq3, big_max = Q.big, D1_max = Lt.D1, n_max = Q.n;
     size_t nchunk_max = Lt.ch_start.size(), nfold_max = Lt.wf.size();
-    bool hetero = false;
+    bool hetero = false, orders = false;
     for (int b = 1; b < nlanes; ++b) {
         const TrigProgram& Qb = *LH[b].Q;
         const LatticeInfo& Lb = LH[b].Lt;
-        if (Qb.which != Q.which || Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.Ne != Q.Ne || Qb.nq3 != Q.nq3 || Qb.big != Q.big || Qb.quad != Q.quad ||
-            Lb.ok != Lt.ok || Lb.D1 != Lt.D1 || Lb.tmin != Lt.tmin || LH[b].c_rows.size() != LH[0].c_rows.size())
-            throw ShapeError("lock-step batch: lanes differ in class (designer, order, cone structure or lattice extent)");
+        if (Qb.which != Q.which || Qb.Ne != Q.Ne || (Qb.nq3 > 0) != (Q.nq3 > 0) || (Qb.big > 0) != (Q.big > 0) || Qb.quad != Q.quad ||
+            Lb.ok != Lt.ok || Lb.tmin != Lt.tmin)
+            throw ShapeError("lock-step batch: lanes differ in class (designer, slack columns, cone kinds or lattice origin)");
+        if (Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.nq3 != Q.nq3 || Qb.big != Q.big || Lb.D1 != Lt.D1 || LH[b].c_rows.size() != LH[0].c_rows.size())
+            hetero = orders = true;
         if (Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ch_start.size() != Lt.ch_start.size() ||
             Lb.wf.size() != Lt.wf.size())
             hetero = true;
         Mf_max = std::max(Mf_max, Qb.Mf); R_max = std::max(R_max, Qb.R); l_max = std::max(l_max, Qb.l);
         nyrows_max = std::max(nyrows_max, int(LH[b].yrows.size()));
         nchunk_max = std::max(nchunk_max, Lb.ch_start.size()); nfold_max = std::max(nfold_max, Lb.wf.size());
+        Nt_max = std::max(Nt_max, Qb.Nt); nq3_max = std::max(nq3_max, Qb.nq3); big_max = std::max(big_max, Qb.big);
+        D1_max = std::max(D1_max, Lb.D1); n_max = std::max(n_max, Qb.n);
     }
+    auto seg_of = [](int D1) {
+        int sg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(D1, 1), 16), 8))));
+        if (const char* ev = std::getenv("MBFIR_SEG")) sg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
+        return sg;
+    };
     // what the per-lane dimensions do not cover: the dense path (its kernels take Mf from the launch)
     if (hetero && (!Lt.ok || o.dense_trig)) throw ShapeError("lock-step batch: lanes differ in shape (dense path)");
     if (std::getenv("MBFIR_HETERO") && std::atoi(std::getenv("MBFIR_HETERO")) == 0 && hetero) throw ShapeError("lock-step batch: lanes differ in shape (MBFIR_HETERO=0)");
     // ---- sizes -----------------------------------------------------------------------------
-    const int R = R_max, Nt = Q.Nt, Ne = Q.Ne, N = Q.N(), Mf = Mf_max;
+    const int R = R_max, Nt = Nt_max, Ne = Q.Ne, N = Nt_max + Q.Ne, Mf = Mf_max;
     const int nw = Q.quad ? 3 : 1;
     S.gp = gram_plan(Mf, Nt, nw);
     DProg& P = S.P;
     P.trig = Lt.ok ? 1 : 0;
-    P.D1 = Lt.D1; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(Lt.D1, 1), 64));
-    P.seg = std::min(SEGMAX, std::max(64, int(round_up(cdiv(std::max(Lt.D1, 1), 16), 8))));
-    if (const char* ev = std::getenv("MBFIR_SEG")) P.seg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
-    P.useg = Lt.ok ? cdiv(Lt.D1, P.seg) : 1;
+    P.D1 = D1_max; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(D1_max, 1), 64));
+    P.seg = seg_of(D1_max);
+    P.useg = 1;
+    if (Lt.ok) for (int b = 0; b < nlanes; ++b) P.useg = std::max(P.useg, cdiv(LH[b].Lt.D1, seg_of(LH[b].Lt.D1)));      // (launches: the most segments any lane has)
     P.nchunk = int(nchunk_max); P.nfold = int(nfold_max);
     P.seeds_shared = 0;
     if (nlanes > 1 && Lt.ok) {                               // sweeps over Peak / ripple keep the grid: one seed table serves the unit
         bool same = true;
         for (int b = 1; b < nlanes && same; ++b) {
             const LatticeInfo& Lb = LH[b].Lt;
-            same = Lb.wf == Lt.wf && Lb.ch_w0 == Lt.ch_w0 && Lb.ch_dw == Lt.ch_dw && Lb.ch_start == Lt.ch_start && Lb.ch_count == Lt.ch_count;
+            same = Lb.D1 == Lt.D1 && Lb.wf == Lt.wf && Lb.ch_w0 == Lt.ch_w0 && Lb.ch_dw == Lt.ch_dw && Lb.ch_start == Lt.ch_start && Lb.ch_count == Lt.ch_count;
         }
         P.seeds_shared = same ? 1 : 0;
     }
@@ -2784,8 +2824,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                          // half the partial-moment traffic of one pair per block -- with four units in flight the solver moves
                          // 3 TB/s through HBM, and that, not the recurrences, is what the moment kernels then wait for
     if (const char* ev = std::getenv("MBFIR_CGRP")) P.cgrp = std::max(1, std::min(CGRP, std::atoi(ev)));
-    P.LDM = int(round_up(3 * std::max(Lt.D1, 1), 256));
-    P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = l_max; P.nq3 = Q.nq3; P.big = Q.big; P.quad = Q.quad;
+    P.LDM = int(round_up(3 * std::max(D1_max, 1), 256));
+    P.Nt = Nt; P.Ne = Ne; P.N = N; P.Mf = Mf; P.R = R; P.l = l_max; P.nq3 = nq3_max; P.big = big_max; P.quad = Q.quad;
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
     P.nyrows = nyrows_max;
@@ -2794,7 +2834,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (hetero) {
         for (int b = 0; b < nlanes; ++b) {
             const TrigProgram& Qb = *LH[b].Q;
-            S.hostDims[b] = LaneDims{Qb.Mf, Qb.R, Qb.l, int(LH[b].yrows.size()), int(LH[b].Lt.wf.size()), int(LH[b].Lt.ch_start.size()), 0, 0};
+            const int d1 = LH[b].Lt.D1, sg = seg_of(d1);
+            S.hostDims[b] = LaneDims{Qb.Mf, Qb.R, Qb.l, int(LH[b].yrows.size()), int(LH[b].Lt.wf.size()), int(LH[b].Lt.ch_start.size()),
+                                     Qb.Nt, Qb.Nt + Qb.Ne, Qb.nq3, Qb.big, d1, sg, LH[b].Lt.ok ? cdiv(d1, sg) : 1, 0, 0, 0};
         }
         MBFIR_HIP(hipMemcpyAsync(S.dimsT, S.hostDims, sizeof(LaneDims) * nlanes, hipMemcpyHostToDevice, st));
         P.dims = S.dimsT;
@@ -2804,7 +2846,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.nbR = cdiv(R, 256); S.nbN = cdiv(N, 256); S.nbC = cdiv(ncone, 256);
     if (S.nbR + 1 > NPART * 64) throw HipError("problem too large for the reduction buffers");
     const size_t ld = P.ld, np = P.np, LDV = P.LDV, Rp = P.Rp, Mpad = P.Mpad;
-    const int lp = Q.which == DES_AP ? specfact_lp(Q.n) : 0;
+    const int lp = Q.which == DES_AP ? specfact_lp(n_max) : 0;
+    for (int b = 0; b < nlanes; ++b) S.lane_n[b] = LH[b].Q->n;
     std::vector<int> tiles(gram_table_ints(S.gp));
     gram_tiles_host(S.gp, tiles.data());
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
@@ -2892,7 +2935,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             S.capPart = ar.get<double>(cap_part_doubles(CAP_KMAX, int(np)));
         }
     }
-    S.hout = ar.get<double>(2 * (size_t)Q.n + 8);
+    S.hout = ar.get<double>(2 * (size_t)n_max + 8);
     S.sfwork = ar.get<double>(6 * (size_t)std::max(lp, 1));
     zero_bytes = size_t(ar.base + ar.off - zero_from);
     S.slab = ar.get<double>(P.trig ? 0 : S.gp.slab_doubles);
@@ -3225,8 +3268,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             L.status = ST_OPTIMAL_INACCURATE;
             MBFIR_HIP(hipMemcpyAsync(xo, reinterpret_cast<char*>(S.xbest) + (size_t)b * S.lane_bytes, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
         }
-        xouts[b].assign(N, 0.0);
-        MBFIR_HIP(hipMemcpyAsync(xouts[b].data(), xo, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        const int Nb = L.Q->N();                              // (the lane's own unknowns: N is the unit's largest)
+        xouts[b].assign(Nb, 0.0);
+        MBFIR_HIP(hipMemcpyAsync(xouts[b].data(), xo, sizeof(double) * Nb, hipMemcpyDeviceToHost, st));
     }
     MBFIR_HIP(hipStreamSynchronize(st));
     const double t_end = now_ms();
@@ -3257,7 +3301,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.ms_assemble = t_assembled - t_begin;
         info.ms_solve = t_end - t_assembled;                  // of the whole lock-step batch
         info.ms_gram = ms_gram; info.ms_chol = ms_chol; info.h_builds = builds;
-        info.n_freq = LH[b].Q->Mf; info.n_rows = LH[b].Q->R; info.n_unknowns = N;
+        info.n_freq = LH[b].Q->Mf; info.n_rows = LH[b].Q->R; info.n_unknowns = LH[b].Q->N();
         info.lattice = P.trig;
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
@@ -3293,9 +3337,17 @@ void Solver::specfact_last(int n, double* h_re, double* h_im, int lane) {
     if (lane < 0 || lane >= S.nlanes_last) throw HipError("specfact: no such lane");
     const size_t off = (size_t)lane * S.lane_bytes / sizeof(double);
     if (!S.taps_valid) {                                  // one launch factorises every lane of the last unit (a lane
-        specfact_launch(S.xout, n, S.sfwork, S.hout, S.st, S.nlanes_last, S.lane_bytes);    // without a solution yields
-        S.taps_valid = true;                              // numbers nobody asks for)
+        bool one_n = true;                                // without a solution yields numbers nobody asks for); a unit of
+        for (int b = 1; b < S.nlanes_last; ++b) one_n = one_n && S.lane_n[b] == S.lane_n[0];       // different orders: lane by lane
+        if (one_n) specfact_launch(S.xout, n, S.sfwork, S.hout, S.st, S.nlanes_last, S.lane_bytes);
+        else
+            for (int b = 0; b < S.nlanes_last; ++b) {
+                const size_t ob = (size_t)b * S.lane_bytes / sizeof(double);
+                specfact_launch(S.xout + ob, S.lane_n[b], S.sfwork + ob, S.hout + ob, S.st, 1, 0);
+            }
+        S.taps_valid = true;
     }
+    if (n != S.lane_n[lane]) throw HipError("specfact: the lane holds a design of another order");
     std::vector<double> h(2 * (size_t)n);
     MBFIR_HIP(hipMemcpyAsync(h.data(), S.hout + off, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, S.st));
     MBFIR_HIP(hipStreamSynchronize(S.st));

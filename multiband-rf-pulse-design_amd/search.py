@@ -24,6 +24,9 @@ def _widen(f, f_add):
     return fn
 
 
+UNIT_ORDER_MAX = 200      # longest filter whose min-order probes share lock-step units (see fir_ap's design())
+
+
 def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *, probes=1, opts=None, log=None, unit_probes=True):
     """Returns (h, status, n_op, f_op) like fir_ap.m.  probes: candidates evaluated concurrently per
     search round (1 = the reference's bisection).  log: optional list receiving (kind, value, status).
@@ -44,10 +47,14 @@ def fir_ap(n, f, a, d, Peak=1e-3, min_order=0, min_tran=0, min_peak=0, dbg=0, *,
             nn, ff = jobs[0]
             return [mbfir.fir_ap_cvx(nn, ff, a, d, LAMBDA, Peak, opts=opts)]
         batch = [("fir_ap_cvx", (nn, ff, a, d, LAMBDA, Peak)) for nn, ff in jobs]
-        if unit_probes and len({nn for nn, _ in jobs}) == 1:
-            # one order, different band edges (the probes of a transition-width round): ONE lock-step unit on one stream --
-            # every launch carries all probes (heterogeneous unit) instead of one design per stream
-            return mbfir.solve_batch(batch, opts=mbfir.opts_with(opts, lanes=len(batch)), streams=1)
+        one_order = len({nn for nn, _ in jobs}) == 1
+        if unit_probes and (one_order or max(nn for nn, _ in jobs) <= UNIT_ORDER_MAX):
+            # the probes of a round -- one order and different band edges (transition-width round), or different orders (min-order
+            # round; round 5) -- as ONE lock-step unit per size bucket: every launch carries all of them (heterogeneous unit,
+            # DESIGN.md section 5) instead of one design per stream.  A unit of different orders runs every lane at the size of its
+            # largest and ends with its slowest: measured on S-C13 (tools/gpu_search_orders.py) it wins at n = 100 (0.098 s against
+            # 0.119 s one design per stream, 0.142 s bisection) and loses at n = 512 (2.1 s against 1.5 s), so long filters keep the streams
+            return mbfir.solve_batch(batch, opts=mbfir.opts_with(opts, lanes=len(batch)), streams=1 if one_order else min(len(jobs), 2))
         return mbfir.solve_batch(batch, opts=opts, streams=min(len(jobs), 4))
 
     n_op, f_op = n, f

@@ -484,6 +484,59 @@ def test_heterogeneous_units_designs_of_one_order_with_different_band_edges():
             c.close()
 
 
+def test_heterogeneous_units_designs_of_different_orders():
+    """a lock-step unit takes designs of one designer and DIFFERENT ORDERS -- the probes of the reference's
+    min-order bisection (fir_ap.m:143-176: dt fixed, only the tap count changes on every probe).  Unknowns, cone counts, lattice
+    extent and taps are per-lane dimensions; the unit's arrays, launches and the factorisation are sized to the largest lane, the
+    shorter lanes' normal matrices padded by identity rows and columns.  Designs share a unit when their padded sizes fall into one
+    power-of-two bucket (here 2 n in (128, 256]).  Every lane must equal its single-design solve BIT FOR BIT (verdict, iterations,
+    objective, taps); an infeasible probe keeps its verdict inside the unit."""
+    f, a, d = c13(100)                                              # the min-order regime: the band edges of n = 100 stay, the order moves
+    orders = [100, 96, 128, 90, 84, 77, 70, 66, 110]
+    jobs = [("fir_ap_cvx", (n, f, a, d, 0.1, 1e-3)) for n in orders]
+    jobs.insert(4, ("fir_ap_cvx", (72, f, a, [x * 0.02 for x in d], 0.1, 1e-3)))                  # far too tight: infeasible
+    orders.insert(4, 72)
+    ctxs = [mbfir.Context(0), mbfir.Context(0)]
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=ctxs, info=True, opts=mbfir.make_opts(lanes=5))
+        assert all(r[2]["lanes"] == 5 for r in res), [r[2]["lanes"] for r in res]                 # ten jobs of one size bucket: two units of five
+        for q, (job, (h, status, info)) in enumerate(zip(jobs, res)):
+            h1, s1, i1 = getattr(mbfir, job[0])(*job[1], ctx=ctxs[0], info=True)
+            assert s1 == status and i1["iters"] == info["iters"], (q, orders[q], status, s1, info["iters"], i1["iters"])
+            assert info["n_unknowns"] == i1["n_unknowns"] == 2 * orders[q] and info["n_rows"] == i1["n_rows"]
+            if status == "Solved":
+                assert h.shape == (orders[q],) and info["pcost"] == i1["pcost"] and np.array_equal(h, h1), (q, orders[q])
+        assert res[4][1] == "Failed" and sum(1 for r in res if r[1] == "Solved") == 9
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_heterogeneous_units_of_other_designers_with_different_orders():
+    """... and for fir_linprog (ss/fir_min_order_linprog.m:98-145: odd and even lengths are searched separately, so a round's
+    probes share the parity, hence the lattice's origin) and for a program with the big cone, whose size moves with the order
+    (fir_qp_cvx without its extended-precision solve).  fir_qprog_phs centres its delays (ss/fir_qprog_phs.m:227-231): the
+    lattice's origin moves with the order, its probes stay one design per unit."""
+    base = CASES["lin_real64"][1]
+    jobs = [("fir_linprog", (n, base[1], base[2], base[3])) for n in (128, 120, 112, 100, 88, 80)]      # nx = n / 2 in (32, 64]
+    qb = CASES["qp_modelB25"][1]
+    jobs += [("fir_qp_cvx", (n,) + tuple(qb[1:])) for n in (23, 25, 27, 29)]
+    fq, aq, dq = CASES["qphs21"][1][1:4]
+    jobs += [("fir_qprog_phs", (n, fq, aq, dq)) for n in (21, 25)]
+    ctx = mbfir.Context(0)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(lanes=6, ddkkt=-1))
+        assert [r[2]["lanes"] for r in res] == [6] * 6 + [4] * 4 + [1] * 2, [r[2]["lanes"] for r in res]
+        for job, (h, status, info) in zip(jobs, res):
+            h1, s1, i1 = getattr(mbfir, job[0])(*job[1], ctx=ctx, info=True, opts=mbfir.make_opts(ddkkt=-1))
+            assert s1 == status and i1["iters"] == info["iters"] and info["n_rows"] == i1["n_rows"], (job[0], job[1][0], status, s1, info["iters"], i1["iters"])
+            if status == "Solved":
+                assert info["pcost"] == i1["pcost"] and np.array_equal(h, h1), (job[0], job[1][0])
+        assert sum(1 for r in res if r[1] == "Solved") >= 9
+    finally:
+        ctx.close()
+
+
 def test_heterogeneous_unit_of_linear_phase_designs():
     """The same for fir_linprog (LP rows only, one-sided grid for real filters): pass-band edges moved per design."""
     base = CASES["lin_real64"][1]

@@ -2,9 +2,11 @@
 ripples / spike bound / weights only (mostly the same shape: they share a lock-step unit; where the shape follows from the
 ripples the batch front end separates them).  All variants of SEVERAL seeds go through one mbfir_solve_batch call (mixed
 shapes: units are formed speculatively and regrouped); every job must equal its single-design solve bit for bit.
-    python tools/gpu_fuzz_lockstep.py lo hi [seeds per call] [lanes (0 automatic)] [edges]
+    python tools/gpu_fuzz_lockstep.py lo hi [seeds per call] [lanes (0 automatic)] [edges | orders]
 With `edges` the variants of a seed also differ in their band edges (scaled towards DC): designs of one order whose grids, row
-counts and chunk lists differ share HETEROGENEOUS units (round 4) and must still equal their single solves bit for bit."""
+counts and chunk lists differ share HETEROGENEOUS units (round 4) and must still equal their single solves bit for bit.
+With `orders` (round 5) the variants differ in their ORDER as well (n, n + 2, n + 4, ... : the same parity, as the probes of the
+reference's min-order searches): unknowns, cone counts and lattice extent per lane, the unit sized to its largest design."""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); warnings.filterwarnings("ignore")
@@ -15,7 +17,8 @@ import test_fuzz_gpu as F
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 per_call = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-edges = len(sys.argv) > 5 and sys.argv[5] == "edges"       # round 4: the variants also differ in their BAND EDGES (heterogeneous units)
+edges = len(sys.argv) > 5 and sys.argv[5] in ("edges", "orders")       # round 4: the variants also differ in their BAND EDGES (heterogeneous units)
+orders = len(sys.argv) > 5 and sys.argv[5] == "orders"     # round 5: ... and in their ORDER
 scales = (1.0, 1.25, 0.8, 1.6, 0.9, 1.1)
 fscale = (1.0, 0.97, 0.99, 0.93, 0.985, 0.95)              # edges scaled towards DC: grids, row counts and chunk lists all move
 def variants(seed):
@@ -26,6 +29,7 @@ def variants(seed):
         a[3] = np.asarray(args[3]) * s                      # ripples
         if which == "fir_ap_cvx": a[5] = args[5] * (2.0 - s)      # the spike bound too
         if edges: a[1] = np.asarray(args[1]) * fscale[q]
+        if orders: a[0] = args[0] + 2 * q
         out.append((which, tuple(a)))
     return out
 bad, t0, njobs, lanes_seen = [], time.time(), 0, {}
