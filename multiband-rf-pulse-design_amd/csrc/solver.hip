@@ -417,10 +417,50 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
 // Block x < nblk_cols: 32 columns x 8 split groups -> out[v][j] (4 loads in flight per thread);
 // the last block forms the y block.
 constexpr int GTC = 32, GTG = 8;       // 256 threads: a 1024-thread block waits for a whole CU once other units share the chip
+// rn_bx != null (round 5, one launch less per KKT solve): the LAST workgroup of the lane to finish also forms the residual
+// r = bx - G'v and its norm -- k_resid_norm's sums with 256 threads, in its order -- (rn_cnt: one int per lane, zero between launches).
+struct GtResid { const double* bx; double* r; double* Sc; int slot; int* cnt; };
+template <int NV>
+__device__ __forceinline__ void gt_resid_tail(const DProg& P, const GtResid& F, const double* __restrict__ t, double* red) {
+    // The hand-over between workgroups WITHOUT a device-wide fence: __threadfence() writes back and invalidates the XCD's whole L2
+    // on this chip (the eight L2s are not coherent with each other) -- with four units in flight that cost 12 % of the batch.  The
+    // values handed over are stored write-through and loaded past the caches instead (agent-scope relaxed atomics: sc1), the
+    // stores are drained (workgroup fence: s_waitcnt only) before the counter moves.
+    __shared__ int s_last;
+    const int tid = threadIdx.y * GTC + threadIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(F.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    double m = 0;
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        for (int j = tid; j < P.N; j += GTC * GTG) {
+            const long o = (long)v * P.LDV + j;
+            const double r = F.bx[o] - __hip_atomic_load(t + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F.r[o] = r;
+            a += r * r;
+        }
+        // (block_sum for a 32 x 8 block: waves are 64 consecutive threads of the x-fastest order)
+        a = wave_sum(a);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = a;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0;
+            for (int w = 0; w < GTC * GTG / 64; ++w) s += red[w];
+            red[16] = s;
+        }
+        __syncthreads();
+        m = fmax(m, sqrt(red[16]));
+    }
+    if (tid == 0) { F.Sc[F.slot] = m; __hip_atomic_store(F.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
 template <int NV>
 __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
-                                                    const double* __restrict__ val, double* __restrict__ out) {
-    LANES(P, partial, val, out);
+                                                    const double* __restrict__ val, double* __restrict__ out, GtResid F) {
+    LANES(P, partial, val, out, F.bx, F.r, F.Sc, F.cnt);
     if (P.dims && P.trig) nsplit = (P.nchunk + P.cgrp - 1) / P.cgrp;      // the lane's own partial count (see k_fold_partials)
     __shared__ double sh[2 * NV][GTG][GTC + 1];
     __shared__ double red[17];
@@ -443,9 +483,11 @@ __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* 
                 if (tid == 0) {
                     double t = 0;
                     for (int w = 0; w < GTC * GTG / 64; ++w) t += red[w];
-                    out[(long)v * P.LDV + P.Nt + e] = t;
+                    if (F.bx) __hip_atomic_store(out + (long)v * P.LDV + P.Nt + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else out[(long)v * P.LDV + P.Nt + e] = t;
                 }
             }
+        if (F.bx) gt_resid_tail<NV>(P, F, out, red);
         return;
     }
     const int j = blockIdx.x * GTC + c;
@@ -496,9 +538,11 @@ __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* 
                 const int r = P.c_rows[q];
                 g += P.alpha[r] * val[(long)v * P.Rp + r];
             }
-            out[(long)v * P.LDV + j] = g;
+            if (F.bx) __hip_atomic_store(out + (long)v * P.LDV + j, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[(long)v * P.LDV + j] = g;
         }
     }
+    if (F.bx) gt_resid_tail<NV>(P, F, out, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,11 +679,13 @@ __global__ __launch_bounds__(256) void k_freq_fold(DProg P, const double* __rest
 #pragma unroll
     for (int v = 0; v < NV; ++v) out[(long)v * P.Mpad + k] = make_double2(a[v] + b[v], a[v] - b[v]);
 }
-template <int NV>
+// FOLD (round 5: one launch less per G'v): the folded operands are formed HERE from the row vector `rows` -- what k_freq_fold<NV, true>
+// would have written to src (same sums, same order) -- by every block for the 256 frequencies of its chunk group.
+template <int NV, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double2* __restrict__ src, const double4* __restrict__ seeds,
-                                                      int na, int nb, double* __restrict__ partial) {
+                                                      int na, int nb, double* __restrict__ partial, const double* __restrict__ rows = nullptr) {
     if (!P.seeds_shared && blockIdx.z) seeds = reinterpret_cast<const double4*>(reinterpret_cast<const char*>(seeds) + (size_t)blockIdx.z * P.lane_bytes);
-    LANES(P, src, partial);
+    LANES(P, src, partial, rows);
     if (P.dims) { na = P.D1; nb = nb ? 2 * P.D1 - 1 : 0; }      // (the launch carries the unit's largest extent: the lane's own)
     __shared__ double2 pp[NV][CGRP][CHK];                 // (pe, po)
     const int tid = threadIdx.x;
@@ -648,8 +694,16 @@ __global__ __launch_bounds__(256) void k_trig_moments(DProg P, const double2* __
         const int cc = e / CHK, q = e - cc * CHK, ch = ch0 + cc;
         const bool live = ch < P.nchunk && q < P.ch_count[ch < P.nchunk ? ch : 0];
         const int k = live ? P.ch_start[ch] + q : 0;
+        if constexpr (FOLD) {
+            double a[NV], b[NV];
+            freq_operands<NV, true>(P, rows, live ? P.fold_pos[k] : -1, a);
+            freq_operands<NV, true>(P, rows, live ? P.fold_neg[k] : -1, b);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) pp[v][cc][q] = make_double2(a[v] + b[v], a[v] - b[v]);
+        } else {
 #pragma unroll
         for (int v = 0; v < NV; ++v) pp[v][cc][q] = live ? src[(long)v * P.Mpad + k] : make_double2(0.0, 0.0);
+        }
     }
     __syncthreads();
     const int m = blockIdx.x * MPTS + tid;
@@ -2160,12 +2214,16 @@ struct Solver::Impl {
     }
     // tail: that many scalars directly behind the NV * LDV entries of `out` ride in the same all-reduce (row-sharded solves: a
     // scalar mailbox packed into the vector reduction that follows it -- one latency-bound collective less)
+    // rn_bx != null: the residual r = rn_bx - G'v and its norm (Sc[rn_slot]) ride in k_gt_finish (unsharded solves)
     template <int NV>
-    void apply_GT(const double* val, double* out, int tail = 0) {
+    void apply_GT(const double* val, double* out, int tail = 0, const double* rn_bx = nullptr, double* rn_r = nullptr, int rn_slot = 0) {
         if (P.trig) {
             dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, P.cgrp)), b(256);
             const dim3 gf(cdiv(P.nfold, 256));
-            if (P.quad) {
+            if (fuse_fold) {
+                if (P.quad) hipLaunchKernelGGL((k_trig_moments<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, (const double2*)nullptr, P.seed_tau, P.D1, 0, partial, val);
+                else hipLaunchKernelGGL((k_trig_moments<NV, true>), lane_grid(g, nlanes), b, 0, st, P, (const double2*)nullptr, P.seed_tau, P.D1, 0, partial, val);
+            } else if (P.quad) {
                 hipLaunchKernelGGL((k_freq_fold<2 * NV, true>), lane_grid(gf, nlanes), b, 0, st, P, val, PPf);
                 hipLaunchKernelGGL((k_trig_moments<2 * NV>), lane_grid(g, nlanes), b, 0, st, P, PPf, P.seed_tau, P.D1, 0, partial);
             } else {
@@ -2177,7 +2235,8 @@ struct Solver::Impl {
             if (P.quad) hipLaunchKernelGGL((k_atmulti<2 * NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
             else hipLaunchKernelGGL((k_atmulti<NV, true>), lane_grid(g, nlanes), b, 0, st, P, A1, val, partial);
         }
-        hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, P.cgrp) : nsplit_at, val, out);
+        hipLaunchKernelGGL(k_gt_finish<NV>, lane_grid(dim3(cdiv(P.Nt, GTC) + 1), nlanes), dim3(GTC, GTG), 0, st, P, partial, P.trig ? cdiv(P.nchunk, P.cgrp) : nsplit_at, val, out,
+                           GtResid{rn_bx, rn_r, Sc, rn_slot, gt_cnt});
         allreduce(out, (long)NV * P.LDV + tail, 0);       // sum the shards' G'v (N-space vectors are replicated)
     }
     template <int NV>
@@ -2192,6 +2251,9 @@ struct Solver::Impl {
     // all-reduces per iteration): the factors are bit-identical across the ranks (same moments, same deterministic
     // assembly and factorisation), the solves with them are local.
     bool lead_factor() const { return shard_size > 1 && P.trig; }
+    // launch fusions of round 5 (MBFIR_FUSE=0: the separate kernels; results are bit-identical either way -- tests/test_switches_gpu.py)
+    bool fuse_fold = true;
+    int* gt_cnt = nullptr;       // workgroups of the current k_gt_finish that are done (per lane; GtResid)
     // out = M' M (rhs + rhs2)
     template <int NV>
     void hsolve(const double* rhs, double* out, const double* rhs2 = nullptr) {
@@ -2221,8 +2283,11 @@ struct Solver::Impl {
         hsolve<NV>(bx, dx, tmpN);                                                           // M'M (bx + G' W^-2 bz)
         apply_G_winv2<NV>(dx, gdx, wbz, dz);
         double* r = rhsN;
+        if (fuse_fold && shard_size <= 1) apply_GT<NV>(dz, tmpN, 0, bx, r, slot);                       // G'dz ; r = bx - G'dz ; n_0
+        else {
         apply_GT<NV>(dz, tmpN);
         hipLaunchKernelGGL(k_resid_norm<NV>, g1, dim3(SCAL_T), 0, st, P, bx, tmpN, r, Sc, slot);      // r = bx - G'dz ; n_0
+        }
         if (nsweep <= 0) return;
         const int* live = P.mask;
         P.mask = mask_row(1);
@@ -2864,6 +2929,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_DD_PASSES")) S.dd_passes = std::max(1, std::min(8, std::atoi(ev)));
     S.fused_hsolve = hsolve_fused_ok(int(np), 2);
     if (const char* ev = std::getenv("MBFIR_HSOLVE")) S.fused_hsolve = S.fused_hsolve && std::atoi(ev) != 0;       // 0: the two triangular GEMVs
+    S.fuse_fold = true;
+    if (const char* ev = std::getenv("MBFIR_FUSE")) S.fuse_fold = std::atoi(ev) != 0;                               // 0: the separate kernels of round 4
     Arena& ar = S.ar;
     char* zero_from = nullptr;
     size_t zero_bytes = 0;
@@ -2897,7 +2964,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     }
     S.Mom = ar.get<double>(18 * (size_t)P.LDM); S.MomB = ar.get<double>(12 * (size_t)P.LDM);
     S.H = ar.get<double>(np * np); S.M = ar.get<double>(np * np); S.Mt = ar.get<double>(np * np); S.W1 = ar.get<double>(np * np + 65 * np);
-    S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.RB = ar.get<double>(16);
+    S.Sc = ar.get<double>(S_COUNT); S.flag = ar.get<int>(4); S.gt_cnt = ar.get<int>(4); S.RB = ar.get<double>(16);
     S.x = ar.get<double>(LDV); S.tmpN = ar.get<double>(2 * LDV); S.tmpN2 = ar.get<double>(2 * LDV);
     S.rhsN = ar.get<double>(2 * LDV); S.yN = ar.get<double>(2 * LDV); S.pN = ar.get<double>(2 * LDV); S.bx2 = ar.get<double>(2 * LDV);
     S.dx2 = ar.get<double>(2 * LDV); S.rx = ar.get<double>(LDV); S.GTz = ar.get<double>(LDV + 16);        /* + the mailbox of the residual sums, packed behind G'z */

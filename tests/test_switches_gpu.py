@@ -8,6 +8,8 @@ environment switch (read at solve time), and the switched-off form is the refere
   MBFIR_POISON=1       NaN in the diagonal-block images before every build (a stale read shows deterministically)
   MBFIR_HSOLVE=0       the preconditioner M'(M b) as two triangular GEMVs on M and the stored M' instead of one pass over M
   MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
+  MBFIR_FUSE=0         round 4's separate launches: k_freq_fold in front of the moment kernel, k_hsolve_fold and k_cg_start behind
+                       the one-pass M'(M b), ... (round 5 fused them into their neighbours; the sums and their order are unchanged)
 """
 import os
 
@@ -254,5 +256,31 @@ def test_speculative_head_in_a_lock_step_batch():
     for mode in ("0", "1"):
         with env(MBFIR_SPECULATE=mode):
             out[mode] = mbfir.solve_batch(jobs, info=True, opts=mbfir.make_opts(lanes=6))
+    for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
+        assert s1 == s0 and i1["iters"] == i0["iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
+
+
+# ---- round 5: launch fusions ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which,args,okw", CASES)
+def test_fused_launches_change_no_bit(which, args, okw):
+    """fewer launches per iteration -- the folded operands formed inside the moment kernel, the partial vectors of
+    M'(M b) added by the last workgroup to finish, the CG start riding there too.  Same sums in the same order: not one bit moves."""
+    fn = getattr(mbfir, which)
+    opts = mbfir.make_opts(**okw) if okw else None
+    with env(MBFIR_FUSE=0):
+        h0, s0, i0 = fn(*args, info=True, opts=opts)
+    with env(MBFIR_FUSE=1):
+        h1, s1, i1 = fn(*args, info=True, opts=opts)
+    assert s0 == s1 == "Solved" and i0["iters"] == i1["iters"] and i0["pcost"] == i1["pcost"] and np.array_equal(h0, h1)
+
+
+def test_fused_launches_change_no_bit_in_a_lock_step_batch():
+    jobs = [("fir_ap_cvx", CASES[0][1][:4] + (0.1, 1e-3 * (1 + 0.3 * q))) for q in range(6)]
+    jobs += [("fir_ap_cvx", (36 + 2 * q, F6, A6, D3, 0.1, 1e-2)) for q in range(4)]              # other orders: per-lane N in the CG start
+    out = {}
+    for mode in ("0", "1"):
+        with env(MBFIR_FUSE=mode):
+            out[mode] = mbfir.solve_batch(jobs, info=True, opts=mbfir.make_opts(lanes=5))
+    assert any(i["lanes"] == 5 for _, _, i in out["1"])
     for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
         assert s1 == s0 and i1["iters"] == i0["iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
