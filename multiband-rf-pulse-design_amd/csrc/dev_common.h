@@ -77,8 +77,9 @@ struct GramPlan {
 };
 GramPlan gram_plan(int Mf, int Nt, int nw);
 // T[w] (ld x ld, full symmetric) = A' diag(d[w]) A ; A is Mpad x ld row-major, d is nw x Mpad.
+// d_stride: doubles between the weight vectors of d (0: gp.Mpad; a lane of a heterogeneous unit keeps the unit's stride)
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
-                 const int* tile_ij, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                 const int* tile_ij, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, size_t d_stride = 0);
 int gram_grid_blocks(const GramPlan& gp);                 // workgroups of one k_gram launch
 int gram_table_ints(const GramPlan& gp);                  // length of the table gram_tiles_host fills
 void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // tile list + the XCD-aware (tile, split) pair of every workgroup

@@ -205,7 +205,8 @@ void gram_tiles_host(const GramPlan& gp, int* tile_ij) {
 }
 
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
-                 const int* tile_ij, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                 const int* tile_ij, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, size_t d_stride) {
+    if (!d_stride) d_stride = (size_t)gp.Mpad;
     // One k_gram launch per weight vector: three accumulator sets (384 VGPRs) would spill, and the
     // kernel is MFMA-bound, so re-reading A from L2/MALL costs nothing measurable.  The optional
     // events bracket the k_gram launches only (roofline timing), the split-K fold comes after.
@@ -213,7 +214,7 @@ void gram_launch(const GramPlan& gp, const double* A, const double* d, double* s
     const size_t per_w = (size_t)gp.nsplit * gp.ntiles * GT * GT;
     if (ev0) hipEventRecord(ev0, st);
     for (int w = 0; w < gp.nw; ++w)
-        hipLaunchKernelGGL(k_gram<1>, grid, dim3(256), 0, st, A, gp.ld, d + (size_t)w * gp.Mpad, gp.Mpad,
+        hipLaunchKernelGGL(k_gram<1>, grid, dim3(256), 0, st, A, gp.ld, d + (size_t)w * d_stride, gp.Mpad,
                            gp.chunks, tile_ij, gp.ntiles, slab + w * per_w);
     if (ev1) hipEventRecord(ev1, st);
     for (int w = 0; w < gp.nw; ++w)

@@ -119,10 +119,11 @@ constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement
 // device-side problem description
 // (round 5: a unit may also hold designs of different ORDERS -- the probes of a min-order search: the dimensions that move with the
 //  order follow the six that move with the band edges)
-struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, Nt, N, nq3, big, D1, seg, useg, pad0, pad1, pad2; };
+struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, Nt, N, nq3, big, D1, seg, useg, Mown /* dense path: the lane's own padded row count */, pad1, pad2; };
 struct DProg {
     int Nt, Ne, N, Mf, R, l, nq3, big, quad;
     int ld, Mpad, LDV, Rp, np;
+    int Mown;                         // dense path: the lane's own padded row count (the split partials a fold adds; = Mpad unless dims)
     const double *w, *col_tau, *col_scale, *psign, *c;
     const int *col_kind, *pcol;
     const int *freq, *col;
@@ -172,7 +173,7 @@ struct DProg {
         // Mpad) stay the unit's: a shorter lane's vectors and matrices sit in the same layout, padded -- H by identity rows and
         // columns, which the factorisation passes through untouched (the same blocks see the same arithmetic as in the lane's
         // single solve at its own np; the padding blocks factorise to the identity)
-        Nt = d.Nt; N = d.N; nq3 = d.nq3; big = d.big; D1 = d.D1; seg = d.seg; useg = d.useg;
+        Nt = d.Nt; N = d.N; nq3 = d.nq3; big = d.big; D1 = d.D1; seg = d.seg; useg = d.useg; Mown = d.Mown;
     }
     template <class T>
     __device__ __forceinline__ static void sh(const T*& p, size_t off) { p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + off); }
@@ -233,8 +234,10 @@ __global__ void k_make_xx(DProg P, const double* __restrict__ v, double* __restr
 template <int NVV>
 __global__ __launch_bounds__(256) void k_amulti(const double* __restrict__ A1, int ld, int Mf,
                                                 const double* __restrict__ XX, int ldv,
-                                                double* __restrict__ UU, int Mpad, size_t lane_bytes, const int* __restrict__ lane_mask) {
+                                                double* __restrict__ UU, int Mpad, size_t lane_bytes, const int* __restrict__ lane_mask,
+                                                const LaneDims* __restrict__ dims) {
     LANES_RAW(lane_bytes, lane_mask, A1, XX, UU);
+    if (dims) Mf = dims[blockIdx.z].Mf;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wv;
     if (row >= Mf) return;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(1024) void k_fold_partials(const double* __restrict
                                                         int ldo, double* __restrict__ TT, size_t lane_bytes, const int* lane_mask,
                                                         const LaneDims* __restrict__ dims, int cgrp) {
     LANES_RAW(lane_bytes, lane_mask, partial, TT);
-    if (dims) nsplit = (dims[blockIdx.z].nchunk + cgrp - 1) / cgrp;
+    if (dims) nsplit = cgrp > 0 ? (dims[blockIdx.z].nchunk + cgrp - 1) / cgrp : (dims[blockIdx.z].Mown - cgrp - 1) / -cgrp;     // (cgrp < 0: dense path, -cgrp rows per split)
     __shared__ double sh[16][65];
     const int c = threadIdx.x, sg = threadIdx.y, j = blockIdx.x * 64 + c, v = blockIdx.y;
     double t = 0;
@@ -461,7 +464,7 @@ template <int NV>
 __global__ __launch_bounds__(GTC * GTG) void k_gt_finish(DProg P, const double* __restrict__ partial, int nsplit,
                                                     const double* __restrict__ val, double* __restrict__ out, GtResid F) {
     LANES(P, partial, val, out, F.bx, F.r, F.Sc, F.cnt);
-    if (P.dims && P.trig) nsplit = (P.nchunk + P.cgrp - 1) / P.cgrp;      // the lane's own partial count (see k_fold_partials)
+    if (P.dims) nsplit = P.trig ? (P.nchunk + P.cgrp - 1) / P.cgrp : (P.Mown + AT_ROWS - 1) / AT_ROWS;      // the lane's own partial count (see k_fold_partials)
     __shared__ double sh[2 * NV][GTG][GTC + 1];
     __shared__ double red[17];
     const int c = threadIdx.x, sg = threadIdx.y;
@@ -2023,7 +2026,8 @@ struct Solver::Impl {
 
     // per-solve device pointers
     DProg P{};
-    GramPlan gp;
+    GramPlan gp;                 // the unit's sizes: ld, the largest Mpad and slab of its lanes
+    std::vector<GramPlan> gps;   // ... and every lane's own plan (dense path)
     int nsplit_at = 0;
     double *A1, *T, *slab, *H, *M, *Mt, *W1, *Sc;
     int *tile_ij, *flag;
@@ -2167,9 +2171,9 @@ struct Solver::Impl {
             xx = XX;
         }
         dim3 g(cdiv(P.Mf, 4));
-        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
-        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
-        else hipLaunchKernelGGL(k_amulti<4>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask);
+        if (NVV == 1) hipLaunchKernelGGL(k_amulti<1>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask, P.dims);
+        else if (NVV == 2) hipLaunchKernelGGL(k_amulti<2>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask, P.dims);
+        else hipLaunchKernelGGL(k_amulti<4>, lane_grid(g, nlanes), dim3(256), 0, st, A1, P.ld, P.Mf, xx, P.LDV, UU, P.Mpad, lane_bytes, P.mask, P.dims);
         hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
     }
     // gout = G v and wout = W^-2 gout - sub; one kernel less than apply_G + winv2 on the lattice path
@@ -2444,21 +2448,22 @@ struct Solver::Impl {
         // (one design: the events bracket the k_gram launches ALONE -- what a kernel trace reports for the kernel north_star
         //  grades; round 3 bracketed the split-K fold and the gaps between the launches too, 0.368 against 0.334 ms in the profile.
         //  Lock-step lanes: around the lanes' products together)
-        if (nlanes == 1) gram_launch(gp, A1, Dw, slab, T, tile_ij, st, g0, g1);
+        if (nlanes == 1) gram_launch(gps[0], A1, Dw, slab, T, tile_ij, st, g0, g1, P.Mpad);
         else {
         if (g0) hipEventRecord(g0, st);
         for (int b = 0; b < nlanes; ++b) {
             if (nlanes > 1 && !lane_live[b]) continue;
             const size_t off = (size_t)b * lane_bytes;
             auto at = [&](double* p) { return reinterpret_cast<double*>(reinterpret_cast<char*>(p) + off); };
-            gram_launch(gp, at(A1), at(Dw), at(slab), at(T), tile_ij, st, nullptr, nullptr);
+            // (a lane's own plan: the split of its frequency rows over the workgroups is that of its single solve)
+            gram_launch(gps[b], at(A1), at(Dw), at(slab), at(T), reinterpret_cast<const int*>(reinterpret_cast<const char*>(tile_ij) + off), st, nullptr, nullptr, P.Mpad);
         }
         if (g1) hipEventRecord(g1, st);
         }
         if (P.Ne > 0) {
             int nvv = P.quad ? 2 * P.Ne : P.Ne;
             atmulti_array(nvv, BB);
-            hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask, (const LaneDims*)nullptr, 1);
+            hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask, P.dims, -AT_ROWS);
         }
         hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
         }
@@ -2705,11 +2710,14 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     std::vector<long> key{long(Q.which), bucket, long(Q.Ne), long(Q.nq3 > 0), long(Q.big > 0), long(Q.quad), long(Lt.ok), tbits};
     // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path; MBFIR_HETERO=0:
     // round 3's rule everywhere), the exact shape: grid, rows, chunks
-    bool exact = !Lt.ok || o.dense_trig;
-    if (const char* ev = std::getenv("MBFIR_HETERO")) exact = exact || std::atoi(ev) == 0;
+    // (round 5: on the dense path the ORDER stays part of the key -- A1's row stride follows it --, the band edges no longer do)
+    const bool dense = !Lt.ok || o.dense_trig;
+    bool exact = false;
+    if (const char* ev = std::getenv("MBFIR_HETERO")) exact = std::atoi(ev) == 0;
+    if (const char* ev = std::getenv("MBFIR_HETERO_DENSE")) exact = exact || (dense && std::atoi(ev) == 0);
     int hetero_orders = 1;
     if (const char* ev = std::getenv("MBFIR_HETERO_ORDERS")) hetero_orders = std::atoi(ev);
-    if (exact || !hetero_orders) {                            // (round 4's rule: one order per unit)
+    if (exact || dense || !hetero_orders) {                   // (round 4's rule: one order per unit)
         const long ord[] = {long(Q.n), long(Q.Nt), long(Q.nq3), long(Q.big), long(pr->c_rows.size()), long(Lt.D1)};
         key.insert(key.end(), std::begin(ord), std::end(ord));
     }
@@ -2861,13 +2869,19 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         if (const char* ev = std::getenv("MBFIR_SEG")) sg = std::max(8, std::min(SEGMAX, std::atoi(ev)));
         return sg;
     };
-    // what the per-lane dimensions do not cover: the dense path (its kernels take Mf from the launch)
-    if (hetero && (!Lt.ok || o.dense_trig)) throw ShapeError("lock-step batch: lanes differ in shape (dense path)");
+    // what the per-lane dimensions do not cover: different ORDERS on the dense path (the row stride of A1 follows the order).
+    // Different band edges are fine there too since round 5: every lane runs its own Gram plan and folds its own split partials.
+    if (orders && (!Lt.ok || o.dense_trig)) throw ShapeError("lock-step batch: lanes differ in order (dense path)");
     if (std::getenv("MBFIR_HETERO") && std::atoi(std::getenv("MBFIR_HETERO")) == 0 && hetero) throw ShapeError("lock-step batch: lanes differ in shape (MBFIR_HETERO=0)");
     // ---- sizes -----------------------------------------------------------------------------
     const int R = R_max, Nt = Nt_max, Ne = Q.Ne, N = Nt_max + Q.Ne, Mf = Mf_max;
     const int nw = Q.quad ? 3 : 1;
     S.gp = gram_plan(Mf, Nt, nw);
+    S.gps.assign(nlanes, S.gp);
+    for (int b = 0; b < nlanes; ++b) {
+        S.gps[b] = gram_plan(LH[b].Q->Mf, Nt, nw);
+        S.gp.Mpad = std::max(S.gp.Mpad, S.gps[b].Mpad); S.gp.slab_doubles = std::max(S.gp.slab_doubles, S.gps[b].slab_doubles);
+    }
     DProg& P = S.P;
     P.trig = Lt.ok ? 1 : 0;
     P.D1 = D1_max; P.tmin = Lt.tmin; P.LDL = int(round_up(std::max(D1_max, 1), 64));
@@ -2894,14 +2908,14 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.ld = S.gp.ld; P.Mpad = S.gp.Mpad; P.np = int(round_up(N, 64));
     P.LDV = int(round_up(std::max(P.ld, P.np), 128)); P.Rp = int(round_up(R, 64));
     P.nyrows = nyrows_max;
-    P.mask = nullptr; P.lane_bytes = 0; P.dims = nullptr;
+    P.mask = nullptr; P.lane_bytes = 0; P.dims = nullptr; P.Mown = P.Mpad;
     P.own = S.shard_rank == 0 ? 1 : 0;                        // (1 when not sharded)
     if (hetero) {
         for (int b = 0; b < nlanes; ++b) {
             const TrigProgram& Qb = *LH[b].Q;
             const int d1 = LH[b].Lt.D1, sg = seg_of(d1);
             S.hostDims[b] = LaneDims{Qb.Mf, Qb.R, Qb.l, int(LH[b].yrows.size()), int(LH[b].Lt.wf.size()), int(LH[b].Lt.ch_start.size()),
-                                     Qb.Nt, Qb.Nt + Qb.Ne, Qb.nq3, Qb.big, d1, sg, LH[b].Lt.ok ? cdiv(d1, sg) : 1, 0, 0, 0};
+                                     Qb.Nt, Qb.Nt + Qb.Ne, Qb.nq3, Qb.big, d1, sg, LH[b].Lt.ok ? cdiv(d1, sg) : 1, S.gps[b].Mpad, 0, 0};
         }
         MBFIR_HIP(hipMemcpyAsync(S.dimsT, S.hostDims, sizeof(LaneDims) * nlanes, hipMemcpyHostToDevice, st));
         P.dims = S.dimsT;
@@ -2913,8 +2927,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     const size_t ld = P.ld, np = P.np, LDV = P.LDV, Rp = P.Rp, Mpad = P.Mpad;
     const int lp = Q.which == DES_AP ? specfact_lp(n_max) : 0;
     for (int b = 0; b < nlanes; ++b) S.lane_n[b] = LH[b].Q->n;
-    std::vector<int> tiles(gram_table_ints(S.gp));
-    gram_tiles_host(S.gp, tiles.data());
+    std::vector<std::vector<int>> tiles(nlanes);
+    for (int b = 0; b < nlanes; ++b) { tiles[b].resize(gram_table_ints(S.gps[b])); gram_tiles_host(S.gps[b], tiles[b].data()); }
     const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
     S.cap_form = o.dd_form == 0;                              // its capacitance form in plain double (capkkt.hip) or the double-double one
     if (const char* ev = std::getenv("MBFIR_DDFORM")) S.cap_form = std::strcmp(ev, "dd") != 0;
@@ -2944,7 +2958,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.beta = UPQ(double, beta); P.ey = UPQ(double, ey); P.h = UPQ(double, h);
     P.f_ptr = UPL(int, f_ptr); P.f_rows = UPL(int, f_rows); P.c_ptr = UPL(int, c_ptr); P.c_rows = UPL(int, c_rows);
     P.yrows = UPL(int, yrows); P.rep = UPL(int, rep);
-    S.tile_ij = S.upload<int>([&](int) -> const std::vector<int>& { return tiles; });
+    S.tile_ij = S.upload<int>([&](int b) -> const std::vector<int>& { return tiles[b]; });
     P.lat = UPL(int, Lt.lat); P.lat_col = UPL(int, Lt.lat_col); P.lat_qcol = UPL(int, Lt.lat_qcol);
     P.lat_scale = UPL(double, Lt.lat_scale); P.lat_qscale = UPL(double, Lt.lat_qscale);
     P.ch_start = UPL(int, Lt.ch_start); P.ch_count = UPL(int, Lt.ch_count); P.ch_w0 = UPL(double, Lt.ch_w0); P.ch_dw = UPL(double, Lt.ch_dw);
