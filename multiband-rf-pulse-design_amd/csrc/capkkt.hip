@@ -23,6 +23,15 @@
 namespace mbfir {
 
 namespace {
+// Lock-step units (round 5): blockIdx.z / gridDim.z carry (split, lane) or the lane; every matrix of lane b sits lane_bytes behind
+// lane b - 1's; kcnt (lane's arena) holds the lane's own number of strong directions -- the launches carry the unit's largest,
+// the padding rows behave as in a single solve padded to that size (zero rows of U, unit diagonal of S).
+struct CapLanes { size_t lane_bytes; const int* mask; const int* kcnt; };
+template <class T>
+__device__ __forceinline__ T* cap_at(T* p, size_t off) { return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + off) : p; }
+__device__ __forceinline__ int cap_k(const CapLanes& L, int lane, int k) {
+    return L.kcnt ? min(*cap_at(L.kcnt, (size_t)lane * L.lane_bytes), 3072) : k;
+}
 constexpr int TB = 64, TLD = 66;
 constexpr int CAP_SPLIT = 4;      // parts of a tile's K range (see k_cap_gemm)
 
@@ -80,9 +89,12 @@ __device__ __forceinline__ void store_tile(double (*S)[TLD], const TileRegs& R, 
 // steps with nothing to overlap them: 0.087 of the fp64 matrix peak.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int np, int ldc,
-                                                  long slab_stride) {
+                                                  long slab_stride, int nsplit, CapLanes L) {
     __shared__ __attribute__((aligned(16))) double As[TB][TLD];
     __shared__ __attribute__((aligned(16))) double Bs[TB][TLD];
+    const int lane_id = blockIdx.z / nsplit;
+    if (L.mask && !L.mask[lane_id]) return;
+    if (lane_id) { const size_t off = (size_t)lane_id * L.lane_bytes; A = cap_at(A, off); B = cap_at(B, off); C = cap_at(C, off); }
     int rb, cb;
     if (MODE == 2) {                                          // lower tiles of the k x k result, one per block
         int t = blockIdx.x;
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, 
     const int nblk = np / TB;
     int j0 = MODE == 1 ? cb : 0, j1 = MODE == 0 ? cb + 1 : nblk;
     {
-        const int span = j1 - j0, z = blockIdx.z, nz = gridDim.z;
+        const int span = j1 - j0, z = blockIdx.z % nsplit, nz = nsplit;
         const int lo = j0 + int((long)span * z / nz), hi = j0 + int((long)span * (z + 1) / nz);
         j0 = lo; j1 = hi;
         C += (long)z * slab_stride;
@@ -138,7 +150,10 @@ __global__ __launch_bounds__(256) void k_cap_gemm(const double* __restrict__ A, 
 // C = sum of the nsplit partial products of the slab (fixed order); MODE 2: the lower tiles only, plus the diagonal term
 template <int MODE>
 __global__ __launch_bounds__(256) void k_cap_fold(const double* __restrict__ part, int nsplit, long slab_stride, double* __restrict__ C, int rows, int ldc,
-                                                  const double* __restrict__ X, int k) {
+                                                  const double* __restrict__ X, int k, CapLanes L) {
+    if (L.mask && !L.mask[blockIdx.z]) return;
+    if (blockIdx.z) { const size_t off = (size_t)blockIdx.z * L.lane_bytes; part = cap_at(part, off); C = cap_at(C, off); X = cap_at(X, off); }
+    if (MODE == 2) k = cap_k(L, blockIdx.z, k);
     const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows || c >= ldc) return;
     if (MODE == 2 && (c / TB) > (r / TB)) return;
@@ -150,7 +165,9 @@ __global__ __launch_bounds__(256) void k_cap_fold(const double* __restrict__ par
 
 // rw = a + b  (NV vectors of np entries, stride ldv; entries past n are zeroed)
 template <int NV>
-__global__ void k_cap_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n, int np, int ldv) {
+__global__ void k_cap_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n, int np, int ldv, CapLanes L) {
+    if (L.mask && !L.mask[blockIdx.z]) return;
+    if (blockIdx.z) { const size_t off = (size_t)blockIdx.z * L.lane_bytes; a = cap_at(a, off); b = cap_at(b, off); out = cap_at(out, off); }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= np) return;
 #pragma unroll
@@ -159,7 +176,10 @@ __global__ void k_cap_add(const double* __restrict__ a, const double* __restrict
 // w[v][r] = U[r] . y[v] - t[v][r]  for r < k (one wave per strong direction), 0 for the padding r in [k, kp)
 template <int NV>
 __global__ __launch_bounds__(256) void k_cap_uy(const double* __restrict__ U, int k, int kp, int n, int np, const double* __restrict__ y, int ldv,
-                                                const double* __restrict__ t, double* __restrict__ w, int ldk) {
+                                                const double* __restrict__ t, double* __restrict__ w, int ldk, CapLanes L) {
+    if (L.mask && !L.mask[blockIdx.z]) return;
+    if (blockIdx.z) { const size_t off = (size_t)blockIdx.z * L.lane_bytes; U = cap_at(U, off); y = cap_at(y, off); t = cap_at(t, off); w = cap_at(w, off); }
+    k = cap_k(L, blockIdx.z, k);
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= kp) return;
     if (r >= k) {
@@ -189,8 +209,11 @@ __global__ __launch_bounds__(256) void k_cap_uy(const double* __restrict__ U, in
 constexpr int DXC = 32, DXG = 32;
 template <int NV>
 __global__ __launch_bounds__(1024) void k_cap_dx(const double* __restrict__ Zt, int k, int n, int np, const double* __restrict__ zeta, int ldk,
-                                                 const double* __restrict__ y, double* __restrict__ dx, int ldv) {
+                                                 const double* __restrict__ y, double* __restrict__ dx, int ldv, CapLanes L) {
     __shared__ double part[NV][DXG][DXC + 1];
+    if (L.mask && !L.mask[blockIdx.z]) return;
+    if (blockIdx.z) { const size_t off = (size_t)blockIdx.z * L.lane_bytes; Zt = cap_at(Zt, off); zeta = cap_at(zeta, off); y = cap_at(y, off); dx = cap_at(dx, off); }
+    k = cap_k(L, blockIdx.z, k);
     const int c = threadIdx.x & (DXC - 1), g = threadIdx.x / DXC, i = blockIdx.x * DXC + c;
     double acc[NV];
 #pragma unroll
@@ -213,37 +236,49 @@ __global__ __launch_bounds__(1024) void k_cap_dx(const double* __restrict__ Zt, 
         }
     }
 }
-__global__ void k_cap_flag_add(int* __restrict__ flag, const int* __restrict__ more) { flag[0] += more[0]; }
+__global__ void k_cap_flag_add(int* __restrict__ flag, const int* __restrict__ more, CapLanes L) {
+    if (L.mask && !L.mask[blockIdx.z]) return;
+    if (blockIdx.z) { const size_t off = (size_t)blockIdx.z * L.lane_bytes; flag = cap_at(flag, off); more = cap_at(more, off); }
+    flag[0] += more[0];
+}
 }  // namespace
 
 // Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1 (lower tiles; padding rows k .. kp-1 get a unit diagonal).  U: kp x np with zero rows from k on;
 // M: the inverse Cholesky factor of H_w (lower triangle valid); S: kp x kp.
 size_t cap_part_doubles(int kmax, int np) { return (size_t)CAP_SPLIT * kmax * (size_t)std::max(np, kmax); }
 void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, double* part,
-                      hipStream_t st) {
+                      hipStream_t st, int nlanes, size_t lane_bytes, const int* mask, const int* kcnt) {
     const int kb = kp / TB;
     const long sA = (long)kp * np, sS = (long)kp * kp;
-    const dim3 g(np / TB, kb, CAP_SPLIT), gf(cdiv(np, 256), kp), gs(cdiv(kp, 256), kp);
-    hipLaunchKernelGGL(k_cap_gemm<0>, g, dim3(256), 0, st, U, M, part, np, np, sA);
-    hipLaunchKernelGGL(k_cap_fold<0>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Yt, kp, np, (const double*)nullptr, 0);
-    hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, part, np, np, sA);
-    hipLaunchKernelGGL(k_cap_fold<1>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Zt, kp, np, (const double*)nullptr, 0);
-    hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2, 1, CAP_SPLIT), dim3(256), 0, st, Yt, (const double*)nullptr, part, np, kp, sS);
-    hipLaunchKernelGGL(k_cap_fold<2>, gs, dim3(256), 0, st, part, CAP_SPLIT, sS, S, kp, kp, X, k);
+    const CapLanes L{lane_bytes, mask, kcnt};
+    const dim3 g(np / TB, kb, CAP_SPLIT * nlanes), gf(cdiv(np, 256), kp, nlanes), gs(cdiv(kp, 256), kp, nlanes);
+    hipLaunchKernelGGL(k_cap_gemm<0>, g, dim3(256), 0, st, U, M, part, np, np, sA, CAP_SPLIT, L);
+    hipLaunchKernelGGL(k_cap_fold<0>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Yt, kp, np, (const double*)nullptr, 0, L);
+    hipLaunchKernelGGL(k_cap_gemm<1>, g, dim3(256), 0, st, Yt, M, part, np, np, sA, CAP_SPLIT, L);
+    hipLaunchKernelGGL(k_cap_fold<1>, gf, dim3(256), 0, st, part, CAP_SPLIT, sA, Zt, kp, np, (const double*)nullptr, 0, L);
+    hipLaunchKernelGGL(k_cap_gemm<2>, dim3(kb * (kb + 1) / 2, 1, CAP_SPLIT * nlanes), dim3(256), 0, st, Yt, (const double*)nullptr, part, np, kp, sS, CAP_SPLIT, L);
+    hipLaunchKernelGGL(k_cap_fold<2>, gs, dim3(256), 0, st, part, CAP_SPLIT, sS, S, kp, kp, X, k, L);
     MBFIR_HIP(hipGetLastError());                         // (a refused launch -- grid, LDS -- would otherwise surface iterations later as a wrong step)
 }
-void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st) {
-    if (nv == 1) hipLaunchKernelGGL(k_cap_add<1>, dim3(cdiv(np, 256)), dim3(256), 0, st, a, b, out, n, np, ldv);
-    else hipLaunchKernelGGL(k_cap_add<2>, dim3(cdiv(np, 256)), dim3(256), 0, st, a, b, out, n, np, ldv);
+void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st, int nlanes, size_t lane_bytes, const int* mask) {
+    const CapLanes L{lane_bytes, mask, nullptr};
+    if (nv == 1) hipLaunchKernelGGL(k_cap_add<1>, dim3(cdiv(np, 256), 1, nlanes), dim3(256), 0, st, a, b, out, n, np, ldv, L);
+    else hipLaunchKernelGGL(k_cap_add<2>, dim3(cdiv(np, 256), 1, nlanes), dim3(256), 0, st, a, b, out, n, np, ldv, L);
 }
-void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st) {
-    if (nv == 1) hipLaunchKernelGGL(k_cap_uy<1>, dim3(cdiv(kp, 4)), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk);
-    else hipLaunchKernelGGL(k_cap_uy<2>, dim3(cdiv(kp, 4)), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk);
+void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st,
+                   int nlanes, size_t lane_bytes, const int* mask, const int* kcnt) {
+    const CapLanes L{lane_bytes, mask, kcnt};
+    if (nv == 1) hipLaunchKernelGGL(k_cap_uy<1>, dim3(cdiv(kp, 4), 1, nlanes), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk, L);
+    else hipLaunchKernelGGL(k_cap_uy<2>, dim3(cdiv(kp, 4), 1, nlanes), dim3(256), 0, st, U, k, kp, n, np, y, ldv, t, w, ldk, L);
 }
-void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st) {
-    if (nv == 1) hipLaunchKernelGGL(k_cap_dx<1>, dim3(np / DXC), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
-    else hipLaunchKernelGGL(k_cap_dx<2>, dim3(np / DXC), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv);
+void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st,
+                   int nlanes, size_t lane_bytes, const int* mask, const int* kcnt) {
+    const CapLanes L{lane_bytes, mask, kcnt};
+    if (nv == 1) hipLaunchKernelGGL(k_cap_dx<1>, dim3(np / DXC, 1, nlanes), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv, L);
+    else hipLaunchKernelGGL(k_cap_dx<2>, dim3(np / DXC, 1, nlanes), dim3(1024), 0, st, Zt, k, n, np, zeta, ldk, y, dx, ldv, L);
 }
-void cap_flag_add_launch(int* flag, const int* more, hipStream_t st) { hipLaunchKernelGGL(k_cap_flag_add, dim3(1), dim3(1), 0, st, flag, more); }
+void cap_flag_add_launch(int* flag, const int* more, hipStream_t st, int nlanes, size_t lane_bytes, const int* mask) {
+    hipLaunchKernelGGL(k_cap_flag_add, dim3(1, 1, nlanes), dim3(1), 0, st, flag, more, CapLanes{lane_bytes, mask, nullptr});
+}
 
 }  // namespace mbfir

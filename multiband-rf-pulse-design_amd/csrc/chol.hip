@@ -2307,13 +2307,16 @@ __global__ __launch_bounds__(256) void k_hsolve(const double* __restrict__ M, in
         for (int v = 0; v < NV; ++v) {
             double a = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) a += m[u].x * bb[v][u].x + m[u].y * bb[v][u].y;
+            // (explicit fused multiply-adds in a fixed order: left to the compiler's contraction the U = 1 and U = 2 instantiations
+            //  rounded a row's products differently -- and a lane of a lock-step unit whose capacitance matrix is padded to the unit's
+            //  largest strong set runs another instantiation than its single solve)
+            for (int u = 0; u < U; ++u) a = fma(m[u].y, bb[v][u].y, fma(m[u].x, bb[v][u].x, a));
             al[v] = __shfl(wave_sum(a), 0, 64);          // (wave_sum leaves the total in lane 0)
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { xa[v][u].x += al[v] * m[u].x; xa[v][u].y += al[v] * m[u].y; }
+            for (int u = 0; u < U; ++u) { xa[v][u].x = fma(al[v], m[u].x, xa[v][u].x); xa[v][u].y = fma(al[v], m[u].y, xa[v][u].y); }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v)

@@ -127,13 +127,17 @@ void dd_trsv_launch(const double* Lh, const double* Ll, const double* Lth, const
 // Capacitance form of the extended-precision solve (capkkt.hip): Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1 on the fp64 matrix cores
 // (U: kp x np with zero rows from k on; M: inverse Cholesky factor of the capped normal matrix, lower triangle; S: kp x kp,
 // lower tiles, unit diagonal on the padding rows), and the vector kernels of its solves
+// (nlanes, lane_bytes, mask: lock-step units; kcnt != null: the lane's own k is read from its arena, `k` and `kp` are the unit's largest)
 void cap_build_launch(const double* U, int k, int kp, int np, const double* M, const double* X, double* Yt, double* Zt, double* S, double* part,
-                      hipStream_t st);
+                      hipStream_t st, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr, const int* kcnt = nullptr);
 size_t cap_part_doubles(int kmax, int np);                // the split-K slab `part` of cap_build_launch
-void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st);
-void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st);
-void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st);
-void cap_flag_add_launch(int* flag, const int* more, hipStream_t st);
+void cap_add_launch(const double* a, const double* b, double* out, int n, int np, int ldv, int nv, hipStream_t st,
+                    int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
+void cap_uy_launch(const double* U, int k, int kp, int n, int np, const double* y, int ldv, const double* t, double* w, int ldk, int nv, hipStream_t st,
+                   int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr, const int* kcnt = nullptr);
+void cap_dx_launch(const double* Zt, int k, int n, int np, const double* zeta, int ldk, const double* y, double* dx, int ldv, int nv, hipStream_t st,
+                   int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr, const int* kcnt = nullptr);
+void cap_flag_add_launch(int* flag, const int* more, hipStream_t st, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
 // In-launch hand-offs between workgroups (chol.hip, ddlin.hip) poll with a bound; a poll that expires adds this to the
 // pivot-replacement counter of the factorisation it belongs to, and the host turns a counter at or above it into an error.
 constexpr int CHOL_SYNC_LOST = 1 << 20;

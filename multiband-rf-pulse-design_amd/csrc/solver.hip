@@ -111,7 +111,10 @@ constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding
                               // whole CU when other units share the chip)
 constexpr int MAX_SWEEPS = 8;
 constexpr int CAP_KMAX = 1024;   // strong directions the capacitance form of the extended-precision solve takes (S is CAP_KMAX^2; the one-pass M'(M b) goes to np = 1024)
-constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 2;
+constexpr int MAX_LANES = 64, MASK_ROWS = MAX_SWEEPS + 4;
+constexpr int ROW_BEST = MAX_SWEEPS + 1;      // mask rows: 0 live, 1 .. MAX_SWEEPS sweep q, then: lanes with a new best iterate,
+constexpr int ROW_DD = MAX_SWEEPS + 2;        // live lanes whose iteration runs the extended-precision solve,
+constexpr int ROW_PL = MAX_SWEEPS + 3;        // live lanes whose iteration runs the plain one (lock-step units with opts.ddkkt: round 5)
 constexpr int WALL_ITERS = 3;
 constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement, oracle/conic_ipm.py */, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4 /* CVX's reduced tolerance eps^(1/4) */;
 
@@ -160,6 +163,12 @@ struct DProg {
     // mask (not shifted; nlanes ints) switches lanes off: finished designs, refinement sweeps a lane does not need.
     size_t lane_bytes;
     const int* mask;
+    // Lock-step units with the extended-precision solve (round 5): the lanes switch to it one by one (each when ITS strong set is
+    // non-empty, as in its single solve), so the kernels that build the normal matrix take the capped weights (D.dlc, D.m3c) on
+    // the lanes flagged in dd_lane (not lane-shifted) and the plain ones (dl_plain, lane-shifted; w3 on the fly) on the others
+    const int* dd_lane;
+    const double* dl_plain;
+    __device__ __forceinline__ bool plain_weights() const { return dd_lane && !dd_lane[blockIdx.z]; }
     // Heterogeneous units (round 4): lanes of one designer and order whose band edges differ have different grids, row
     // counts and chunk lists.  Every array and launch is then sized to the unit's MAXIMA (one arena layout for all lanes,
     // shorter arrays zero-padded) and the kernel prologue replaces the dimensions that differ by the block's lane's own
@@ -184,6 +193,7 @@ struct DProg {
         sh(lat, off); sh(lat_col, off); sh(lat_qcol, off); sh(lat_scale, off); sh(lat_qscale, off);
         sh(ch_start, off); sh(ch_count, off); sh(ch_w0, off); sh(ch_dw, off); sh(fold_pos, off); sh(fold_neg, off); sh(wf, off);
         if (!seeds_shared) { sh(seed_tau, off); sh(seed_h, off); sh(seed_eval, off); }
+        if (dl_plain) sh(dl_plain, off);
     }
 };
 // Kernel prologue: leave if the lane is masked off, then move the program and the listed pointer arguments to
@@ -1543,6 +1553,7 @@ __device__ __forceinline__ void freq_block_at(const DProg& P, const double* __re
 __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                               double* __restrict__ Dw, double* __restrict__ BB, const double* __restrict__ m3c) {
     LANES(P, dl, w3, Dw, BB, m3c);
+    if (P.plain_weights()) { dl = P.dl_plain; m3c = nullptr; }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.Mf) return;
     double v[9];
@@ -1558,6 +1569,7 @@ __global__ void k_freq_blocks(DProg P, const double* __restrict__ dl, const doub
 __global__ __launch_bounds__(256) void k_freq_blocks_fold(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                                                           const double* __restrict__ m3c, int nv, double2* __restrict__ out) {
     LANES(P, dl, w3, m3c, out);
+    if (P.plain_weights()) { dl = P.dl_plain; m3c = nullptr; }
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= P.nfold) return;
     double a[9], b[9];
@@ -1658,6 +1670,7 @@ __device__ __forceinline__ void h_yy_block(const DProg& P, const double* __restr
 __global__ __launch_bounds__(256) void k_H_identity(DProg P, const double* __restrict__ dl, const double* __restrict__ w3,
                                                     double* __restrict__ H, const double* __restrict__ m3c, int yy_too, int summed) {
     LANES(P, dl, w3, H, m3c);
+    if (P.plain_weights()) { dl = P.dl_plain; m3c = nullptr; }
     // summed: the matrix is summed over the ranks afterwards (dense row-sharded path): the y-y block weights the replicated
     // rows, and the identity rows -- all of them replicated -- are added by the owner only
     if (yy_too && blockIdx.x == gridDim.x - 1) { h_yy_block(P, dl, w3, H, (long)P.np, (long)P.Nt, m3c, summed != 0); return; }
@@ -1743,7 +1756,8 @@ __global__ __launch_bounds__(256) void k_pack_tril(const double* __restrict__ H,
         if (unpack) *mat = *tile; else *tile = *mat;
     }
 }
-__global__ void k_zero3(double* __restrict__ a, long na, double* __restrict__ b, long nb, double* __restrict__ c, long nc) {
+__global__ void k_zero3(double* __restrict__ a, long na, double* __restrict__ b, long nb, double* __restrict__ c, long nc, size_t lane_bytes, const int* lane_mask) {
+    LANES_RAW(lane_bytes, lane_mask, a, b, c);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < na) a[i] = 0.0;
     if (i < nb) b[i] = 0.0;
@@ -2314,17 +2328,51 @@ struct Solver::Impl {
     // Extended-precision solve, step 1 (after the NT scaling): eigen data, cap, strong set.  Returns the number of
     // strong eigen-directions (0: nothing above the cap, the plain solve is exact enough).  One host
     // synchronisation (the count decides which solve runs).
+    // Lock-step units (round 5): every live lane selects ITS strong set (its own cap, its own count); ks[b] <- the lane's count,
+    // thetas[b] the lane's cap factor (raised x 100 for a lane whose set does not fit, as in its single solve).  Returns the largest.
+    int dd_prepare_lanes(const double theta0, int* ks, const bool* live) {
+        const int nb = std::max(nbC, 1);
+        hipLaunchKernelGGL(k_dd_prep, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, w3, D, partR);
+        int nbp = nb;
+        if (P.big) {
+            hipLaunchKernelGGL(k_dd_prep_big, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, D, partR);      // (row 0: see k_dd_prep)
+            nbp += 1;
+        }
+        for (int b = 0; b < nlanes; ++b) hostTheta[b] = theta0;
+        const int kmax_fit = cap_form ? CAP_KMAX : DD_KMAX;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            if (attempt > 0) memset_lanes(D.kcnt, sizeof(int));
+            MBFIR_HIP(hipMemcpyAsync(ddtheta, hostTheta, sizeof(double) * nlanes, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_dd_select, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, D, partR, nbp, theta0, (const double*)ddtheta);
+            hipLaunchKernelGGL(k_dd_order, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, D);
+            MBFIR_HIP(hipMemcpy2DAsync(hostFlag + MAX_LANES, sizeof(int), D.kcnt, lane_bytes, sizeof(int), nlanes, hipMemcpyDeviceToHost, st));
+            MBFIR_HIP(hipStreamSynchronize(st));
+            bool fits = true;
+            int kmax = 0;
+            for (int b = 0; b < nlanes; ++b) {
+                ks[b] = live[b] ? hostFlag[MAX_LANES + b] : 0;
+                if (ks[b] > kmax_fit) { fits = false; hostTheta[b] *= 100.0; }
+                kmax = std::max(kmax, ks[b]);
+            }
+            if (fits) return kmax;
+        }
+        throw HipError("extended-precision solve: strong set does not fit");
+    }
+    double hostTheta[MAX_LANES];
+    double* ddtheta = nullptr;          // the lanes' cap factors (lane 0's arena; read unshifted)
+    bool dd_unit = false;               // a lock-step unit on the extended-precision path (some of its lanes, some iterations)
+    int dd_kp = 0;                      // ... the largest strong set of this iteration, rounded up to 64 (the unit's S is dd_kp x dd_kp)
     int dd_prepare(double theta) {
         const int nb = std::max(nbC, 1);
         hipLaunchKernelGGL(k_dd_prep, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, w3, D, partR);
         int nbp = nb;
         if (P.big) {
-            hipLaunchKernelGGL(k_dd_prep_big, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, D, partR + 2L * nb);
+            hipLaunchKernelGGL(k_dd_prep_big, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, wbb, Sc, D, partR);      // (row 0: see k_dd_prep)
             nbp += 1;
         }
         for (int attempt = 0; attempt < 8; ++attempt) {
             if (attempt > 0) hipMemsetAsync(D.kcnt, 0, sizeof(int), st);        // (the first attempt's counter was cleared by k_dd_prep)
-            hipLaunchKernelGGL(k_dd_select, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, D, partR, nbp, theta);
+            hipLaunchKernelGGL(k_dd_select, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, dl, D, partR, nbp, theta, (const double*)nullptr);
             hipLaunchKernelGGL(k_dd_order, dim3(1), dim3(1024), 0, st, P, D);
             MBFIR_HIP(hipMemcpyAsync(hostFlag + 1, D.kcnt, sizeof(int), hipMemcpyDeviceToHost, st));
             MBFIR_HIP(hipStreamSynchronize(st));
@@ -2339,10 +2387,13 @@ struct Solver::Impl {
     template <int NV>
     void kkt_solve_dd(const double* bx, const double* bz, double* dx, double* dz, double* gdx, int slot) {
         const dim3 gC(std::max(nbC, 1)), b256(256);
-        const int k = dd_k;
+        // (lock-step units: the launches carry the unit's largest strong set, every lane reads its own count from its arena)
+        const int k = dd_unit ? dd_kp : dd_k;
+        const int* kcnt = dd_unit ? D.kcnt : nullptr;
         double *Bh = ddB, *Bl = ddB + 2L * P.LDV;
         // (one launch instead of three memsets: the trace of BASELINE config 3's batch held 10 348 fill kernels)
-        hipLaunchKernelGGL(k_zero3, dim3(cdiv(NV * std::max<long>(P.LDV, P.Rp), 256)), dim3(256), 0, st, dx, long(NV) * P.LDV, dz, long(NV) * P.Rp, gdx, long(NV) * P.Rp);
+        hipLaunchKernelGGL(k_zero3, lane_grid(dim3(cdiv(NV * std::max<long>(P.LDV, P.Rp), 256)), nlanes), dim3(256), 0, st, dx, long(NV) * P.LDV, dz, long(NV) * P.Rp, gdx, long(NV) * P.Rp,
+                           lane_bytes, P.mask);
         for (int it = 0; it < dd_passes; ++it) {
             apply_GT<NV>(dz, tmpN);
             hipLaunchKernelGGL(k_resid_norm<NV>, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, bx, tmpN, rhsN, Sc, slot + it);   // r1 = bx - G'dz
@@ -2354,13 +2405,14 @@ struct Solver::Impl {
             if (cap_form) {
                 // y = H_w^-1 rhs_w ; zeta = S^-1 (U y - t) ; dx = y - Zt' zeta   (all double; zeta are the strong directions'
                 // multipliers X (U dx - t) themselves)
-                const int kp = int(round_up(k, 64));
-                cap_add_launch(rhsN, tmpN2, Bl, P.N, P.np, P.LDV, NV, st);                       // rhs_w
+                int kp = int(round_up(k, 64));
+                if (!dd_unit) if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) kp = std::max(kp, std::atoi(ev));     // test hook: pad S as a unit's largest lane would
+                cap_add_launch(rhsN, tmpN2, Bl, P.N, P.np, P.LDV, NV, st, nlanes, lane_bytes, P.mask);                       // rhs_w
                 double* yv = tmpN2;                                                              // (free from here on; yN is hsolve's own intermediate)
                 hsolve<NV>(Bl, yv);                                                              // y
-                cap_uy_launch(D.U, k, kp, P.N, P.np, yv, P.LDV, ddtS, capw, DD_KMAX, NV, st);
-                hsolve_launch(capMs, kp, capw, nullptr, ddzeta, partial, NV, DD_KMAX, st);       // zeta
-                cap_dx_launch(capZt, k, P.N, P.np, ddzeta, DD_KMAX, yv, Bh, P.LDV, NV, st);      // the correction of this pass
+                cap_uy_launch(D.U, k, kp, P.N, P.np, yv, P.LDV, ddtS, capw, DD_KMAX, NV, st, nlanes, lane_bytes, P.mask, kcnt);
+                hsolve_launch(capMs, kp, capw, nullptr, ddzeta, partial, NV, DD_KMAX, st, nlanes, lane_bytes, P.mask);       // zeta
+                cap_dx_launch(capZt, k, P.N, P.np, ddzeta, DD_KMAX, yv, Bh, P.LDV, NV, st, nlanes, lane_bytes, P.mask, kcnt);      // the correction of this pass
             } else {
             hipLaunchKernelGGL(k_dd_rhs<NV>, lane_grid(dim3(cdiv(P.np, 16)), nlanes), b256, 0, st, P, D, k, rhsN, tmpN2, ddtS, Bh, Bl);
             dd_trsv_launch(H, M, Mt, W1, ddri, ddri + P.np, P.np, Bh, Bl, NV, P.LDV, st, ddflags, ++dd_epoch, flag, ddinv);
@@ -2404,6 +2456,10 @@ struct Solver::Impl {
         double* yy_sum = nullptr;
         const double* dlw = ddk > 0 ? D.dlc : dl;
         const double* m3c = ddk > 0 ? D.m3c : nullptr;
+        // (lock-step unit with lanes in both modes: the kernels pick per lane -- DProg::plain_weights)
+        const int* live_mask = P.mask;
+        P.dd_lane = (dd_unit && ddk > 0) ? mask_row(ROW_DD) : nullptr;
+        P.dl_plain = P.dd_lane ? dl : nullptr;
         const int nwv = P.quad ? 3 : 1, nvb = P.quad ? 2 * P.Ne : P.Ne;
         const bool one_pass = P.trig && P.Ne > 0 && P.tmin == 0.0 && nwv + nvb <= 4;
         if (!one_pass) hipLaunchKernelGGL(k_freq_blocks, lane_grid(dim3(cdiv(P.Mf, 256)), nlanes), dim3(256), 0, st, P, dlw, w3, Dw, BB, m3c);
@@ -2487,12 +2543,16 @@ struct Solver::Impl {
             if (P.big && (!summed || shard_rank == 0)) {
                 memset_lanes(qv, sizeof(double) * 3 * P.LDV);
                 if (ddk > 0) {
+                    if (dd_unit) P.mask = mask_row(ROW_DD);
                     hipLaunchKernelGGL(k_big_q_dd, lane_grid(dim3(cdiv(P.big, 256)), nlanes), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV);
                     hipLaunchKernelGGL(k_H_big_dd, lane_grid(dim3(cdiv(P.N, 256), P.N), nlanes), dim3(256), 0, st, P, D, qv, qv + P.LDV, qv + 2L * P.LDV, H);
-                } else {
+                }
+                if (ddk <= 0 || dd_unit) {
+                    if (dd_unit && ddk > 0) P.mask = mask_row(ROW_PL);
                     hipLaunchKernelGGL(k_big_q, lane_grid(dim3(cdiv(P.big, 256)), nlanes), dim3(256), 0, st, P, wbb, qv, qv + P.LDV);
                     hipLaunchKernelGGL(k_H_big, lane_grid(dim3(cdiv(P.N, 256), P.N), nlanes), dim3(256), 0, st, P, qv, qv + P.LDV, Sc, H);
                 }
+                P.mask = live_mask;
             }
         }
         if (!lead_factor() && shard_size > 1) {
@@ -2511,10 +2571,29 @@ struct Solver::Impl {
             hipLaunchKernelGGL(k_pack_tril, dim3((unsigned)ntile), dim3(256), 0, st, H, P.np, M, 1);
         }
         hipEvent_t c0 = timing ? next_event() : nullptr, c1 = timing ? next_event() : nullptr;
-        if (ddk > 0 && cap_form) {
+        P.dd_lane = nullptr; P.dl_plain = nullptr;
+        if (ddk > 0 && cap_form && dd_unit) {
+            // the lanes' H (capped weights on the lanes in the extended-precision mode, plain ones on the others) in one launch, then
+            // the capacitance matrices of the former: launches sized to the unit's largest strong set, a lane's own count read from its
+            // arena, its U / Yt / Zt rows and S rows beyond it zero resp. unit -- what a single solve padded to that size would hold
+            const int kp = dd_kp;
+            const int* mdd = mask_row(ROW_DD);
+            chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, nlanes, lane_bytes, P.mask);
+            P.mask = mdd;
+            hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(kp), nlanes), dim3(256), 0, st, P, D, P.np, -1);
+            P.mask = live_mask;
+            hipEvent_t b0 = timing ? next_cap_event() : nullptr, b1 = timing ? next_cap_event() : nullptr;
+            if (b0) hipEventRecord(b0, st);
+            cap_build_launch(D.U, kp, kp, P.np, M, D.sX, capYt, capZt, capS, capPart, st, nlanes, lane_bytes, mdd, D.kcnt);
+            if (b1) hipEventRecord(b1, st);
+            cap_flop_sum += 2.0 * (double(kp) * P.np * P.np + 0.5 * double(kp) * kp * P.np);
+            chol_inv_launch(capS, capMs, nullptr, capW1, kp, capflag, st, nullptr, nullptr, c1, nlanes, lane_bytes, mdd);
+            cap_flag_add_launch(flag, capflag, st, nlanes, lane_bytes, mdd);
+        } else if (ddk > 0 && cap_form) {
             // capacitance form: the ordinary double-precision factorisation of H_w, then Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1
             // on the matrix cores and the same factorisation routine on S (kp x kp)
-            const int kp = int(round_up(ddk, 64));
+            int kp = int(round_up(ddk, 64));
+            if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) kp = std::max(kp, std::atoi(ev));
             chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, 1, 0, nullptr);
             hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(kp), nlanes), dim3(256), 0, st, P, D, P.np, ddk);      // (rows ddk .. kp-1: zero padding)
             hipEvent_t b0 = timing ? next_cap_event() : nullptr, b1 = timing ? next_cap_event() : nullptr;
@@ -2648,6 +2727,8 @@ struct LaneHost {
     bool live = true, have_best = false;
     double best_merit = 1e300, rx_prev = 0;
     SolveInfo info, best_info;
+    // extended-precision path: strong directions of the current iteration (0: the plain solve), iterations on it, its largest set
+    int dd_k = 0, dd_iters = 0, dd_kmax = 0;
 };
 
 static void index_structures(const TrigProgram& Q, LaneHost& L) {
@@ -2707,6 +2788,8 @@ std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     //  the same power-of-two bucket: a unit runs every lane at the size of its largest)
     long bucket = 64;
     while (bucket < round_up(Q.N(), 64)) bucket *= 2;
+    // (units on the extended-precision path: the split of the capacitance products over K follows np -- lanes of one np only)
+    if (o.ddkkt_theta > 0) bucket = round_up(Q.N(), 64);
     std::vector<long> key{long(Q.which), bucket, long(Q.Ne), long(Q.nq3 > 0), long(Q.big > 0), long(Q.quad), long(Lt.ok), tbits};
     // ... and, where the per-lane dimensions of a heterogeneous unit do not reach (dense path; MBFIR_HETERO=0:
     // round 3's rule everywhere), the exact shape: grid, rows, chunks
@@ -2754,7 +2837,13 @@ void Solver::test_fold(const double* w, int Mf, int fold, long* out) {
 int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
     // lock-step batches exist on the lattice path only; the extended-precision KKT solve (on by default for
     // fir_qp_cvx) and row-sharded solves run one design at a time
-    if (o.shard_size > 1 || o.ddkkt_theta > 0) return 1;
+    if (o.shard_size > 1) return 1;
+    // (round 5: the extended-precision solve takes lock-step units too, in its capacitance form -- every lane switches to it when
+    //  ITS strong set is non-empty, as its single solve does; MBFIR_DD_LANES=0: one design at a time as before)
+    bool dd_lanes = o.ddkkt_theta > 0 && o.dd_form == 0;
+    if (const char* ev = std::getenv("MBFIR_DDFORM")) dd_lanes = dd_lanes && std::strcmp(ev, "dd") != 0;
+    if (const char* ev = std::getenv("MBFIR_DD_LANES")) dd_lanes = dd_lanes && std::atoi(ev) != 0;
+    if (o.ddkkt_theta > 0 && !dd_lanes) return 1;
     long np = round_up(Q.N(), 64);
     if (!(o.dense_trig || !lane_prep(Q, o)->Lt.ok)) {        // (lattice path: designs of one size bucket share units -- shape_key -- and a unit
         long bucket = 64;                                     //  is as large as its largest lane)
@@ -2772,6 +2861,7 @@ int Solver::max_lanes(const TrigProgram& Q, const SolveOpts& o) {
         const double per_lane = 8.0 * (double(gp.Mpad) * gp.ld + double(gp.slab_doubles) + 3.0 * gp.ld * gp.ld);
         cap = std::min<long>(cap, std::max<long>(1, long(2.0e9 / per_lane)));
     }
+    if (o.ddkkt_theta > 0) cap = std::min<long>(cap, 16);                               // (~100 MB of strong rows and capacitance matrices per lane)
     if (const char* ev = std::getenv("MBFIR_MAX_LANES")) cap = std::atol(ev);          // (experiments: tools/sweep_lanes.sh)
     return int(std::max<long>(1, std::min<long>(MAX_LANES, cap)));
 }
@@ -2929,9 +3019,13 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     for (int b = 0; b < nlanes; ++b) S.lane_n[b] = LH[b].Q->n;
     std::vector<std::vector<int>> tiles(nlanes);
     for (int b = 0; b < nlanes; ++b) { tiles[b].resize(gram_table_ints(S.gps[b])); gram_tiles_host(S.gps[b], tiles[b].data()); }
-    const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1 && nlanes == 1;    // extended-precision KKT solve (ddkkt.inc)
     S.cap_form = o.dd_form == 0;                              // its capacitance form in plain double (capkkt.hip) or the double-double one
     if (const char* ev = std::getenv("MBFIR_DDFORM")) S.cap_form = std::strcmp(ev, "dd") != 0;
+    // extended-precision KKT solve (ddkkt.inc); lock-step units: in its capacitance form (round 5; the double-double kernels take one design)
+    if (o.ddkkt_theta > 0 && nlanes > 1 && !S.cap_form) throw ShapeError("lock-step batch: the double-double form of the extended-precision solve runs one design at a time");
+    const bool use_dd = o.ddkkt_theta > 0 && S.shard_size <= 1;
+    S.dd_unit = use_dd && nlanes > 1;
+    S.dd_kp = 0;
     // Refinement passes on the augmented system around the extended-precision solve: two for the double-double form, THREE for the
     // capacitance form.  Measured on BASELINE config 3's family (tools/exp/c3_one_design.py): the first pass takes the residual of
     // the constant system from ||c|| = 1e6 to 1e-8 early and to 1.2e-5 from k ~ 480 strong directions on (the lattice-built H_w
@@ -3002,6 +3096,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         D.dlc = ar.get<double>(Rp); D.m3c = ar.get<double>(6 * (size_t)std::max(P.nq3, 1));
         D.slotl = ar.get<int>(std::max(P.l, 1)); D.slot3 = ar.get<int>(3 * (size_t)std::max(P.nq3, 1)); D.slotb = ar.get<int>(2);
         D.kcnt = ar.get<int>(1); D.skind = ar.get<int>(DD_KMAX); D.sidx = ar.get<int>(DD_KMAX); D.sdir = ar.get<int>(DD_KMAX);
+        S.ddtheta = ar.get<double>(MAX_LANES);
         D.sX = ar.get<double>(DD_KMAX); D.U = ar.get<double>((size_t)DD_KMAX * np);
         S.ddB = ar.get<double>(4 * LDV); S.ddtS = ar.get<double>(2 * (size_t)DD_KMAX); S.ddzeta = ar.get<double>(2 * (size_t)DD_KMAX);
         S.ddri = ar.get<double>(2 * np); S.ddd0 = ar.get<double>(np);
@@ -3038,9 +3133,13 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         for (int b = 0; b < nlanes; ++b) {
             S.hostMask[b] = LH[b].live ? 1 : 0;
             S.lane_live[b] = LH[b].live;
-            for (int q = 1; q <= MAX_SWEEPS; ++q) S.hostMask[q * MAX_LANES + b] = (LH[b].live && LH[b].nsweep >= q) ? 1 : 0;
+            // (a lane whose iteration runs the extended-precision solve takes no part in the plain solve's sweeps)
+            for (int q = 1; q <= MAX_SWEEPS; ++q) S.hostMask[q * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0 && LH[b].nsweep >= q) ? 1 : 0;
+            S.hostMask[ROW_DD * MAX_LANES + b] = (LH[b].live && LH[b].dd_k > 0) ? 1 : 0;
+            S.hostMask[ROW_PL * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0) ? 1 : 0;
         }
         MBFIR_HIP(hipMemcpyAsync(S.maskT, S.hostMask, sizeof(int) * (MAX_SWEEPS + 1) * MAX_LANES, hipMemcpyHostToDevice, st));
+        if (S.dd_unit) MBFIR_HIP(hipMemcpyAsync(S.maskT + ROW_DD * MAX_LANES, S.hostMask + ROW_DD * MAX_LANES, sizeof(int) * 2 * MAX_LANES, hipMemcpyHostToDevice, st));
     };
     push_masks();
     P.mask = S.mask_row(0);
@@ -3140,7 +3239,23 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     auto launch_head = [&]() {
         hipLaunchKernelGGL(k_scaling, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.s, S.z, S.dl, S.wl, S.w3, S.lam, S.bz2, S.wbz);
         if (P.big) hipLaunchKernelGGL(k_big_scaling, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.s, S.z, S.wbb, S.lam, S.Sc);
-        S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
+        if (S.dd_unit) {
+            // every live lane its own strong set; then the masks of the two modes (the sweep rows follow: push_masks)
+            int ks[MAX_LANES];
+            bool lv[MAX_LANES];
+            for (int b = 0; b < nlanes; ++b) lv[b] = LH[b].live;
+            S.dd_k = S.dd_prepare_lanes(o.ddkkt_theta, ks, lv);
+            for (int b = 0; b < nlanes; ++b) {
+                LH[b].dd_k = ks[b];
+                if (ks[b] > 0) { LH[b].dd_iters += 1; LH[b].dd_kmax = std::max(LH[b].dd_kmax, ks[b]); }
+            }
+            S.dd_kp = int(round_up(std::max(S.dd_k, 1), 64));
+            push_masks();
+        } else {
+            S.dd_k = use_dd ? S.dd_prepare(o.ddkkt_theta) : 0;
+            LH[0].dd_k = S.dd_k;
+            if (S.dd_k > 0) { LH[0].dd_iters += 1; LH[0].dd_kmax = std::max(LH[0].dd_kmax, S.dd_k); }
+        }
         if (S.dd_k > 0) { S.dd_iters += 1; S.dd_kmax_seen = std::max(S.dd_kmax_seen, S.dd_k); }
         dd_now = S.dd_k > 0;
         S.build_H(S.dd_k);
@@ -3166,7 +3281,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             last_graph = nullptr;
         }
         bool any_live = false, any_best = false;
-        for (int b = 0; b < nlanes; ++b) S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 0;      // 1: the lane has a new best iterate
+        for (int b = 0; b < nlanes; ++b) S.hostMask[ROW_BEST * MAX_LANES + b] = 0;      // 1: the lane has a new best iterate
         for (int b = 0; b < nlanes; ++b) {
             LaneHost& L = LH[b];
             if (!L.live) continue;
@@ -3176,7 +3291,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             // lost: its bounded poll expired and the block went on with stale data -- the numbers are void
             if (chol_fixes >= CHOL_SYNC_LOST) throw HipError("internal error: an in-launch hand-off of the KKT factorisation timed out (device flag never raised)");
             SolveInfo& info = L.info;
-            if (it > 0 && !dd_now) {                          // (iterations on the extended-precision path keep the count)
+            if (it > 0 && L.dd_k == 0) {                      // (iterations on the extended-precision path keep the count)
                 // refinement-sweep controller (mirrors oracle/conic_ipm.py next_sweeps): the norms were
                 // measured before each sweep of the two KKT solves of the previous iteration
                 const double tol = std::max(REFTOL * hs[S_NRMC], REFETA * L.rx_prev);   // ||rx|| of the iteration the norms belong to
@@ -3198,7 +3313,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 fprintf(stderr, "%s%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d%s\n",
                         nlanes > 1 ? ("[" + std::to_string(b) + "] ").c_str() : "", it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES],
                         hs[S_DRES], hs[S_KAPPA] / hs[S_TAU], hs[S_MU], hs[S_ALPHA], hs[S_SIGMA], L.nsweep, chol_fixes,
-                        dd_now ? [&] { char bf[200]; std::snprintf(bf, sizeof(bf), " | k %d refinement norms %.2e -> %.2e -> %.2e , %.2e -> %.2e -> %.2e", S.dd_k,
+                        L.dd_k > 0 ? [&] { char bf[200]; std::snprintf(bf, sizeof(bf), " | k %d refinement norms %.2e -> %.2e -> %.2e , %.2e -> %.2e -> %.2e", L.dd_k,
                                        hs[S_RNA], hs[S_RNA + 1], S.dd_passes > 2 ? hs[S_RNA + 2] : 0.0, hs[S_RNB], hs[S_RNB + 1], S.dd_passes > 2 ? hs[S_RNB + 2] : 0.0);
                                        return std::string(bf); }().c_str() : "");
             auto finish = [&](int status) { L.status = status; L.live = false; };
@@ -3213,7 +3328,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 double merit = std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol);
                 if (merit < L.best_merit) {
                     L.best_merit = merit; L.best_info = info; L.have_best = true;
-                    S.hostMask[(MAX_SWEEPS + 1) * MAX_LANES + b] = 1;
+                    S.hostMask[ROW_BEST * MAX_LANES + b] = 1;
                     any_best = true;
                 }
             }
@@ -3229,9 +3344,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             // wall) retires in this very iteration: its best_info is this iterate's, so xbest has to be as well (the
             // new-best bits were cleared for every lane above and are set by the merit test alone, not by `live`)
             if (nlanes > 1) {
-                MBFIR_HIP(hipMemcpyAsync(S.maskT + (MAX_SWEEPS + 1) * MAX_LANES, S.hostMask + (MAX_SWEEPS + 1) * MAX_LANES, sizeof(int) * MAX_LANES,
+                MBFIR_HIP(hipMemcpyAsync(S.maskT + ROW_BEST * MAX_LANES, S.hostMask + ROW_BEST * MAX_LANES, sizeof(int) * MAX_LANES,
                                          hipMemcpyHostToDevice, st));
-                P.mask = S.mask_row(MAX_SWEEPS + 1);
+                P.mask = S.mask_row(ROW_BEST);
             }
             hipLaunchKernelGGL(k_finish_x, lane_grid(dim3(S.nbN), nlanes), dim3(256), 0, st, P, S.x, S.Sc, S.xbest);
             P.mask = S.mask_row(0);
@@ -3240,13 +3355,32 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         nsweep_max = 0;
         for (int b = 0; b < nlanes; ++b)
             if (LH[b].live) nsweep_max = std::max(nsweep_max, LH[b].nsweep);
-        push_masks();
+        push_masks();                                         // (a unit with opts.ddkkt pushes them again once the head knows the lanes' modes)
         auto launch_body = [&]() {
         // scaling + H (already on the stream when the head went out ahead of the host)
         if (!head_out) launch_head();
         // constant + affine systems in one batch: [x1 z1], [x2 z2]
-        if (S.dd_k > 0) S.kkt_solve_dd<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, S_RNA);
-        else S.kkt_solve<2>(S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, nsweep_max, S_RNA, true);  // W^-2 bz2 came with k_scaling
+        // (a lock-step unit with opts.ddkkt: the lanes whose strong set is non-empty run the extended-precision solve, the others the
+        //  plain one, each under its mask -- every lane the sequence of its single solve)
+        bool dd_any = S.dd_k > 0, pl_any = S.dd_k == 0;
+        if (S.dd_unit) {
+            pl_any = false;
+            for (int b = 0; b < nlanes; ++b) pl_any = pl_any || (LH[b].live && LH[b].dd_k == 0);
+        }
+        const int* live_row = P.mask;
+        auto solve2 = [&](auto NVc, const double* bx, const double* bz, double* dx, double* dz, double* gdx, int slot) {
+            constexpr int NVX = decltype(NVc)::value;
+            if (dd_any) {
+                if (S.dd_unit) P.mask = S.mask_row(ROW_DD);
+                S.kkt_solve_dd<NVX>(bx, bz, dx, dz, gdx, slot);
+            }
+            if (pl_any) {
+                if (S.dd_unit) P.mask = S.mask_row(ROW_PL);
+                S.kkt_solve<NVX>(bx, bz, dx, dz, gdx, nsweep_max, slot, true);              // W^-2 bz came with k_scaling / k_comb_rhs
+            }
+            P.mask = live_row;
+        };
+        solve2(std::integral_constant<int, 2>(), S.bx2, S.bz2, S.dx2, S.dz2, S.gdx2, S_RNA);
         double *x1 = S.dx2, *x2a = S.dx2 + LDV, *z1 = S.dz2, *z2a = S.dz2 + Rp, *g1 = S.gdx2, *g2a = S.gdx2 + Rp;
         auto dots = [&](const double* xx2, const double* zz2, int mode) -> int {
             hipLaunchKernelGGL(k_dots_r, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.wl, S.w3, z1, zz2, S.partR);
@@ -3290,8 +3424,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         if (P.big)
             hipLaunchKernelGGL(k_big_comb_rhs, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, S.dssa, S.wdza, S.rz, S.Sc, S.lds, S.bzc,
                                S.scratch);
-        if (S.dd_k > 0) S.kkt_solve_dd<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
-        else S.kkt_solve<1>(S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, nsweep_max, S_RNB, true);
+        solve2(std::integral_constant<int, 1>(), S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
         const int nd1 = dots(S.dxc, S.dzc, 1);
         dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
         hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
@@ -3387,7 +3520,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
         info.collective_bytes = S.collective_bytes;
-        info.dd_iters = S.dd_iters; info.dd_kmax = S.dd_kmax_seen;
+        info.dd_iters = LH[b].dd_iters; info.dd_kmax = LH[b].dd_kmax;
         info.dd_form = S.cap_form ? 0 : 1; info.cap_flop = S.cap_flop_sum; info.ms_cap = ms_cap;
         info.chol_launches = int(S.chol_launch_count);
         info.chol_flop = 2.0 / 3.0 * double(P.np) * double(P.np) * double(P.np);

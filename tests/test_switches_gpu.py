@@ -8,6 +8,7 @@ environment switch (read at solve time), and the switched-off form is the refere
   MBFIR_POISON=1       NaN in the diagonal-block images before every build (a stale read shows deterministically)
   MBFIR_HSOLVE=0       the preconditioner M'(M b) as two triangular GEMVs on M and the stored M' instead of one pass over M
   MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
+  MBFIR_DD_LANES=0     designs with the extended-precision solve (fir_qp_cvx's default) one per stream (rounds 2-4) instead of lock-step units
   MBFIR_FUSE=0         round 4's separate launches: k_freq_fold in front of the moment kernel, k_hsolve_fold and k_cg_start behind
                        the one-pass M'(M b), ... (round 5 fused them into their neighbours; the sums and their order are unchanged)
 """
@@ -284,3 +285,18 @@ def test_fused_launches_change_no_bit_in_a_lock_step_batch():
     assert any(i["lanes"] == 5 for _, _, i in out["1"])
     for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
         assert s1 == s0 and i1["iters"] == i0["iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
+
+
+def test_extended_precision_units_against_one_design_per_stream():
+    """MBFIR_DD_LANES=0: the batch front end hands fir_qp_cvx designs (extended-precision solve on) out one per stream as before round 5;
+    the lock-step units give the same results bit for bit."""
+    base = ("fir_qp_cvx", (40, [-0.5, -0.3, -0.1, 0.1, 0.3, 0.5], [0, 0, 1, 1, 0, 0], [0.05, 0.05, 0.05], 5.0, 1e6))
+    jobs = [(base[0], base[1][:3] + ([v * (1 + 0.05 * q) for v in base[1][3]],) + base[1][4:]) for q in range(5)]
+    out = {}
+    for mode in ("0", "1"):
+        with env(MBFIR_DD_LANES=mode):
+            out[mode] = mbfir.solve_batch(jobs, info=True, opts=mbfir.make_opts(lanes=5))
+    assert all(i["lanes"] == 1 for _, _, i in out["0"]) and all(i["lanes"] == 5 for _, _, i in out["1"])
+    assert any(i["dd_iters"] > 0 for _, _, i in out["1"])
+    for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
+        assert s1 == s0 and i1["iters"] == i0["iters"] and i1["dd_iters"] == i0["dd_iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
