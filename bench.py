@@ -184,10 +184,17 @@ def other_configs(mbfir, ctxs):
     except Exception as e:                                  # noqa: BLE001
         out["heterogeneous_64"] = {"error": "%s: %s" % (type(e).__name__, e)}
     f, a, d = mbfir.spec.spec_h1_dualband(512)
-    jobs3 = [("fir_qp_cvx", (512, f, a, [x * (1.0 + 0.02 * q) for x in d], 120.0, 1e6)) for q in range(8)]
+    jobs16 = [("fir_qp_cvx", (512, f, a, [x * (1.0 + 0.02 * q) for x in d], 120.0, 1e6)) for q in range(16)]
+    jobs3 = jobs16[:8]
     o3 = mbfir.make_opts(grid_m=16384)
     pool = list(ctxs) + [mbfir.Context(ctxs[0].device) for _ in range(max(0, 8 - len(ctxs)))]
     try:
+        # round 5: the extended-precision solve takes lock-step units -- 16 designs over the bench's own streams (the library forms
+        # units of 16 / streams lanes); the batch of 8 on 8 streams (one design per stream: rounds 2-4's figure) stays beside it
+        mbfir.solve_batch(jobs16, ctxs=ctxs, opts=o3)
+        t = time.perf_counter()
+        res16 = mbfir.solve_batch(jobs16, ctxs=ctxs, opts=o3, info=True)
+        dt16 = time.perf_counter() - t
         mbfir.solve_batch(jobs3[:len(pool)], ctxs=pool, opts=o3)
         t = time.perf_counter()
         res = mbfir.solve_batch(jobs3, ctxs=pool, opts=o3, info=True)
@@ -196,6 +203,8 @@ def other_configs(mbfir, ctxs):
         _, st1, i1 = mbfir.fir_qp_cvx(*jobs3[0][1], opts=o3, ctx=pool[0], info=True)
         dt1 = time.perf_counter() - t
         out["config3_fir_qp_cvx_h1_dualband_n512_m16384"] = {
+            "designs_per_s_batch16": 16 / dt16, "batch16_streams": len(ctxs), "batch16_lanes_per_unit": sorted({r[2]["lanes"] for r in res16}),
+            "batch16_solved": sum(1 for r in res16 if r[1] == "Solved"),
             "designs_per_s": 8 / dt, "batch": 8, "streams": len(pool), "solved": sum(1 for r in res if r[1] == "Solved"),
             "ipm_iters": [r[2]["iters"] for r in res], "extended_precision_iters": [r[2]["dd_iters"] for r in res],
             "one_design_alone_s": dt1, "one_design_status": st1,

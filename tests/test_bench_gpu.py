@@ -41,6 +41,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c4, c3 = oc["config4_sweep_256_designs_n200_m4096"], oc["config3_fir_qp_cvx_h1_dualband_n512_m16384"]
     assert c4["solved"] == 256 and c4["designs_per_s"] > 100 and c4["lanes"] == 32
     assert c3["solved"] == 8 and c3["designs_per_s"] > 1 and min(c3["extended_precision_iters"]) > 0 and c3["one_design_status"] == "Solved"
+    # (round 5: 16 such designs as lock-step units on the extended-precision path)
+    assert c3["batch16_solved"] == 16 and c3["designs_per_s_batch16"] > 1 and max(c3["batch16_lanes_per_unit"]) > 1
 
 
 def test_bench_full_convergence_cpu_leg_and_distinct_designs():
