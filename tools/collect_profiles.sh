@@ -35,9 +35,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dense_pmc_wr
 #    8 streams, extended-precision path; one HSA queue per stream under the profiler, see above)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/hetero_trace -o hetero -- python3 tools/gpu_hetero64.py > $OUT/hetero_trace.log 2>&1 || exit 1
 GPU_MAX_HW_QUEUES=8 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/c3_trace -o c3 -- python3 tools/gpu_config3_batch.py 8 8 > $OUT/c3_trace.log 2>&1 || exit 1
+# (round 5: the same designer in lock-step units on the extended-precision path: 16 designs, units of 4 on 4 streams)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/c3u_trace -o c3u -- python3 tools/gpu_config3_batch.py 16 4 > $OUT/c3u_trace.log 2>&1 || exit 1
 # the traces are hundreds of MB: condense them here, keep only the summaries (gpurun copies back <= 64 MiB)
 MBFIR_PROFILE_DST=gpurun_out/${ROUND}_profiles python3 tools/rocprof_summary.py > $OUT/summary.log 2>&1
 cp $OUT/bench.json $OUT/summary.log gpurun_out/${ROUND}_profiles/ 2>/dev/null
-grep -h "designs/s\|config 3" $OUT/hetero_trace.log $OUT/c3_trace.log > gpurun_out/${ROUND}_profiles/${ROUND}_hetero_c3_under_trace.txt 2>/dev/null
+grep -h "designs/s\|config 3" $OUT/hetero_trace.log $OUT/c3_trace.log $OUT/c3u_trace.log > gpurun_out/${ROUND}_profiles/${ROUND}_hetero_c3_under_trace.txt 2>/dev/null
 rm -rf $OUT
 ls -la gpurun_out/${ROUND}_profiles

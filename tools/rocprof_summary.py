@@ -66,7 +66,8 @@ def main():
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     for d, out in (("bench_trace", ROUND + "_bench_kernel_stats.csv"), ("unit_trace", ROUND + "_unit16_kernel_stats.csv"),
                    ("unit8_trace", ROUND + "_unit8_kernel_stats.csv"), ("dense_trace", ROUND + "_dense_kernel_stats.csv"),
-                   ("hetero_trace", ROUND + "_hetero64_kernel_stats.csv"), ("c3_trace", ROUND + "_c3_batch8_kernel_stats.csv")):
+                   ("hetero_trace", ROUND + "_hetero64_kernel_stats.csv"), ("c3_trace", ROUND + "_c3_batch8_kernel_stats.csv"),
+                   ("c3u_trace", ROUND + "_c3_units16_kernel_stats.csv")):
         kernel_stats(d, out)
     if os.path.exists(os.path.join(SRC, "bench.json")):
         with open(os.path.join(SRC, "bench.json")) as fh, open(os.path.join(DST, ROUND + "_bench.json"), "w") as out:
