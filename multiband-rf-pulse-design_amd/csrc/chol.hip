@@ -2270,7 +2270,7 @@ __global__ __launch_bounds__(256) void k_trigemv(const double* __restrict__ T, i
 // triangle are unequal: dealt cyclically), reduces its four waves' slices through LDS and writes one partial vector;
 // k_hsolve_fold adds the HS_G partials in a fixed order.  M is read ONCE per application (the two triangular GEMVs read
 // M and its stored transpose: twice the bytes), and the transpose need not be stored at all.  np <= 1024 (U = ceil(np / 128) <= 8).
-constexpr int HS_G = 32;
+constexpr int HS_G = HS_PARTS;
 template <int NV, int U>
 __global__ __launch_bounds__(256) void k_hsolve(const double* __restrict__ M, int np, const double* __restrict__ b,
                                                 const double* __restrict__ b2, double* __restrict__ part, int ldv,
@@ -2348,7 +2348,7 @@ bool hsolve_fused_ok(int np, int nv) { return np % 64 == 0 && np <= 1024 && (nv 
 size_t hsolve_part_doubles(int np) { return (size_t)HS_G * 2 * np; }
 // out = M'M (b + b2); part: hsolve_part_doubles(np) doubles of scratch per lane
 void hsolve_launch(const double* M, int np, const double* b, const double* b2, double* out, double* part, int nv, int ldv,
-                   hipStream_t st, int nlanes, size_t lane_bytes, const int* mask) {
+                   hipStream_t st, int nlanes, size_t lane_bytes, const int* mask, bool fold) {
     if (!hsolve_fused_ok(np, nv)) throw HipError("hsolve_launch: unsupported size");
     const dim3 grid(HS_G, nlanes), gf(cdiv(np, 256), nlanes);
     const int U = (np + 127) / 128;
@@ -2358,11 +2358,11 @@ void hsolve_launch(const double* M, int np, const double* b, const double* b2, d
     if (nv == 1) {
         switch (U) { case 1: HS_CASE(1, 1) break; case 2: HS_CASE(1, 2) break; case 3: HS_CASE(1, 3) break; case 4: HS_CASE(1, 4) break;
                      case 5: HS_CASE(1, 5) break; case 6: HS_CASE(1, 6) break; case 7: HS_CASE(1, 7) break; default: HS_CASE(1, 8) break; }
-        hipLaunchKernelGGL(k_hsolve_fold<1>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
+        if (fold) hipLaunchKernelGGL(k_hsolve_fold<1>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
     } else {
         switch (U) { case 1: HS_CASE(2, 1) break; case 2: HS_CASE(2, 2) break; case 3: HS_CASE(2, 3) break; case 4: HS_CASE(2, 4) break;
                      case 5: HS_CASE(2, 5) break; case 6: HS_CASE(2, 6) break; case 7: HS_CASE(2, 7) break; default: HS_CASE(2, 8) break; }
-        hipLaunchKernelGGL(k_hsolve_fold<2>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
+        if (fold) hipLaunchKernelGGL(k_hsolve_fold<2>, gf, dim3(256), 0, st, part, np, out, ldv, lane_bytes, mask);
     }
 #undef HS_CASE
     if (lds > 64 * 1024) MBFIR_HIP(hipGetLastError());    // (a launch above 64 KB of LDS is rejected on a device whose attribute was never set)

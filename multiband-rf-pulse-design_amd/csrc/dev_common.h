@@ -107,8 +107,11 @@ void trigemv_launch(const double* T, int np, int upper, const double* b, double*
 // hsolve_part_doubles(np) doubles per lane
 bool hsolve_fused_ok(int np, int nv);
 size_t hsolve_part_doubles(int np);
+// fold = false (round 5): the HS_PARTS partial vectors stay in `part` ([g][v][np]) for a consumer that adds them itself (solver.hip
+// k_fold_cg_start: one launch instead of k_hsolve_fold + k_cg_start)
+constexpr int HS_PARTS = 32;
 void hsolve_launch(const double* M, int np, const double* b, const double* b2, double* out, double* part, int nv, int ldv,
-                   hipStream_t st, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr);
+                   hipStream_t st, int nlanes = 1, size_t lane_bytes = 0, const int* mask = nullptr, bool fold = true);
 
 // Double-double dense kernels (ddlin.hip): H(dd) = Hh + sum_{r < *kcount} X[r] U[r] U[r]' on the lower-triangle
 // tiles; in-place dd Cholesky (L in the lower triangle of (Hh, Hl), L' in (Lth, Ltl), 1/diag(L) in (rih, ril),

@@ -101,6 +101,7 @@ enum {
     S_RT, S_PCOST, S_DCOST, S_GAP, S_RELGAP, S_PRES, S_DRES, S_PINF, S_DINF, S_CX, S_HZ, S_SZ,
     S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
     S_CHOLFIX /* pivots the last factorisation replaced (copied from the counter so that one D2H copy serves the host) */,
+    S_TAU0 /* tau, kappa of the iterate the step is taken from: k_update's blocks read these while block 0 publishes the new ones */, S_KAP0,
     S_RNA = 40 /* 9 residual norms, batch solve */, S_RNB = 49 /* 9 residual norms, combined solve */,
     S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */, S_COUNT = 64
 };
@@ -1098,6 +1099,49 @@ __global__ __launch_bounds__(1024) void k_cg_start(DProg P, double* __restrict__
         if (threadIdx.x == 0) Sc[S_CG_RZ + v] = rz_new;
     }
 }
+// The same behind the one-pass z = M'M r (round 5: one launch instead of k_hsolve_fold + k_cg_start): 1024 threads add the
+// HS_PARTS partial vectors of k_hsolve in k_hsolve_fold's order (thread (w, t) the entry j = t + 256 w), then the first 256 do
+// k_cg_start's sums -- thread t over its four entries in w order, the block sum of 256 threads -- with z from LDS: the same bits.
+template <int NV>
+__global__ __launch_bounds__(1024) void k_fold_cg_start(DProg P, double* __restrict__ Sc, const double* __restrict__ r,
+                                                        const double* __restrict__ part, double* __restrict__ p, int first) {
+    LANES(P, Sc, r, part, p);
+    __shared__ double zs[NV][1024];
+    __shared__ double sh[17];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double x[HS_PARTS];
+#pragma unroll
+        for (int g = 0; g < HS_PARTS; ++g) x[g] = t < P.np ? part[((long)g * NV + v) * P.np + t] : 0.0;
+        double s = 0;
+#pragma unroll
+        for (int g = 0; g < HS_PARTS; ++g) s += x[g];
+        zs[v][t] = s;
+    }
+    __syncthreads();
+    const bool act = t < SCAL_T;                              // (the 768 others only keep the barriers company)
+    const int lane = t & 63, wv = t >> 6;
+    for (int v = 0; v < NV; ++v) {
+        double a = 0;
+        if (act) for (int j = t; j < P.N; j += SCAL_T) a += r[(long)v * P.LDV + j] * zs[v][j];
+        a = wave_sum(a);                                      // block_sum of the first 256 threads
+        __syncthreads();
+        if (act && lane == 0) sh[wv] = a;
+        __syncthreads();
+        if (t == 0) { double q = 0; for (int i = 0; i < SCAL_T / 64; ++i) q += sh[i]; sh[16] = q; }
+        __syncthreads();
+        const double rz_new = sh[16];
+        const double rz_old = Sc[S_CG_RZ + v];
+        const double beta = first ? 0.0 : (rz_old > 0 ? rz_new / rz_old : 0.0);
+        if (act) for (int j = t; j < P.N; j += SCAL_T) {
+            const long o = (long)v * P.LDV + j;
+            p[o] = first ? zs[v][j] : zs[v][j] + beta * p[o];
+        }
+        __syncthreads();
+        if (t == 0) Sc[S_CG_RZ + v] = rz_new;
+    }
+}
 // CG: alpha = rz / p'Hp (0 if p'Hp <= 0) ; dx += alpha p ; r -= alpha Hp ; Sc[slot] = max_v ||r_v||
 template <int NV>
 __global__ __launch_bounds__(1024) void k_cg_step(DProg P, double* __restrict__ Sc, const double* __restrict__ p,
@@ -1302,6 +1346,7 @@ __global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restr
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             Sc[mode == 0 ? S_DTAU_A : S_DTAU] = dtau;
             Sc[mode == 0 ? S_DKAP_A : S_DKAP] = (dkc - kap * dtau) / tau;
+            if (mode == 1) { Sc[S_TAU0] = tau; Sc[S_KAP0] = kap; }
         }
     } else {
         dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
@@ -1493,11 +1538,26 @@ __global__ __launch_bounds__(1024) void k_big_comb_rhs(DProg P, const double* __
     for (int i = threadIdx.x; i < P.big; i += blockDim.x) bz[ob + i] = -(1 - sigma) * rz[ob + i] - scratch[i];
 }
 // x += alpha (x2 + dtau x1) ; s += alpha ds ; z += alpha dz
-__global__ void k_update(DProg P, const double* __restrict__ Sc, const double* __restrict__ x1,
+// part != null (round 5: one launch less): the step length is formed HERE -- k_scal_step's fold of the k_dir_post partials and its
+// scalar arithmetic (mode 1), by every block for itself; block 0 publishes alpha and the new tau, kappa (the blocks read the old
+// ones from the snapshot k_dir_post left: S_TAU0, S_KAP0)
+__global__ __launch_bounds__(256) void k_update(DProg P, double* __restrict__ Sc, const double* __restrict__ x1,
                          const double* __restrict__ x2, double* __restrict__ x, const double* __restrict__ ds,
-                         const double* __restrict__ dz, double* __restrict__ s, double* __restrict__ z) {
-    LANES(P, Sc, x1, x2, x, ds, dz, s, z);
+                         const double* __restrict__ dz, double* __restrict__ s, double* __restrict__ z,
+                         const double* __restrict__ part, int nb) {
+    LANES(P, Sc, x1, x2, x, ds, dz, s, z, part);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (part) {
+        __shared__ double sh[17];
+        const double ts = fold_partials(part, nb, 2, 0, true, sh), tz = fold_partials(part, nb, 2, 1, true, sh);
+        const double tau = Sc[S_TAU0], kap = Sc[S_KAP0], dtau = Sc[S_DTAU], dkap = Sc[S_DKAP];
+        const double tm = fmax(0.0, fmax(fmax(ts, tz), fmax(-dtau / tau, -dkap / kap)));
+        const double a = tm == 0.0 ? 1.0 : fmin(1.0, STEP / tm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { Sc[S_TMAX] = tm; Sc[S_ALPHA] = a; Sc[S_TAU] = tau + a * dtau; Sc[S_KAPPA] = kap + a * dkap; }
+        if (t < P.N) x[t] += a * (x2[t] + dtau * x1[t]);
+        if (t < P.R) { s[t] += a * ds[t]; z[t] += a * dz[t]; }
+        return;
+    }
     const double a = Sc[S_ALPHA], dtau = Sc[S_DTAU];
     if (t < P.N) x[t] += a * (x2[t] + dtau * x1[t]);
     if (t < P.R) { s[t] += a * ds[t]; z[t] += a * dz[t]; }
@@ -2309,10 +2369,20 @@ struct Solver::Impl {
         if (nsweep <= 0) return;
         const int* live = P.mask;
         P.mask = mask_row(1);
-        hsolve<NV>(r, tmpN2);                                                               // z = M'M r
+        // z = M'M r and the start of the sweep (rz, beta, p): the partial vectors of the one-pass product are added by the kernel
+        // that starts the sweep (fuse_fold; otherwise k_hsolve_fold writes z and k_cg_start reads it)
+        auto z_and_start = [&](int first) {
+            if (fuse_fold && fused_hsolve) {
+                hsolve_launch(M, P.np, r, nullptr, tmpN2, partial, NV, P.LDV, st, nlanes, lane_bytes, P.mask, false);
+                hipLaunchKernelGGL(k_fold_cg_start<NV>, g1, dim3(1024), 0, st, P, Sc, r, partial, pN, first);
+            } else {
+                hsolve<NV>(r, tmpN2);
+                hipLaunchKernelGGL(k_cg_start<NV>, g1, dim3(SCAL_T), 0, st, P, Sc, r, tmpN2, pN, first);
+            }
+        };
+        z_and_start(1);
         for (int it = 0; it < nsweep; ++it) {
             P.mask = mask_row(it + 1);
-            hipLaunchKernelGGL(k_cg_start<NV>, g1, dim3(SCAL_T), 0, st, P, Sc, r, tmpN2, pN, it == 0 ? 1 : 0);   // rz, beta, p
             apply_G_winv2<NV>(pN, tmpR, nullptr, wpR);                                      // G p, W^-2 G p
             apply_GT<NV>(wpR, tmpN);                                                        // H p
             if (shard_size == 1) {
@@ -2321,7 +2391,7 @@ struct Solver::Impl {
                 hipLaunchKernelGGL(k_cg_step<NV>, g1, dim3(SCAL_T), 0, st, P, Sc, pN, tmpN, dx, r, slot + it + 1);   // alpha, dx, r, n_{it+1}
                 hipLaunchKernelGGL(k_cg_update_r<NV>, gR, b256, 0, st, P, Sc, tmpR, wpR, gdx, dz);
             }
-            if (it + 1 < nsweep) { P.mask = mask_row(it + 2); hsolve<NV>(r, tmpN2); }
+            if (it + 1 < nsweep) { P.mask = mask_row(it + 2); z_and_start(0); }
         }
         P.mask = live;
     }
@@ -3411,10 +3481,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 0);
                 S.allreduce(S.RB, 2, 1);
                 hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
-            } else if (mode == 1) {
+            } else if (mode == 1 && !S.fuse_fold) {
                 hipLaunchKernelGGL(k_scal_step, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
             }
-            return nb;
+            return nb;                                     // (fuse_fold: k_update forms the step length itself)
         };
         const int nd0 = dots(x2a, z2a, 0);
         const int ns0 = dir_post(x2a, z2a, g2a, S.dssa, S.wdza, 0, nd0);
@@ -3426,8 +3496,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                                S.scratch);
         solve2(std::integral_constant<int, 1>(), S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
         const int nd1 = dots(S.dxc, S.dzc, 1);
-        dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
-        hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z);
+        const int ns1 = dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
+        hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z,
+                           (!sharded && S.fuse_fold) ? (const double*)S.partR2 : (const double*)nullptr, ns1);
         };
         if (use_graph) {
             auto g = graphs.find(nsweep_max);

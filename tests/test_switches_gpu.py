@@ -9,8 +9,9 @@ environment switch (read at solve time), and the switched-off form is the refere
   MBFIR_HSOLVE=0       the preconditioner M'(M b) as two triangular GEMVs on M and the stored M' instead of one pass over M
   MBFIR_CGRP=1         one chunk per block in the moment kernel (no interleaved pair)
   MBFIR_DD_LANES=0     designs with the extended-precision solve (fir_qp_cvx's default) one per stream (rounds 2-4) instead of lock-step units
-  MBFIR_FUSE=0         round 4's separate launches: k_freq_fold in front of the moment kernel, k_hsolve_fold and k_cg_start behind
-                       the one-pass M'(M b), ... (round 5 fused them into their neighbours; the sums and their order are unchanged)
+  MBFIR_FUSE=0         round 4's separate launches: k_freq_fold in front of the moment kernel, k_resid_norm behind k_gt_finish,
+                       k_hsolve_fold + k_cg_start behind the one-pass M'(M b), k_scal_step in front of k_update (round 5 fused them
+                       into their neighbours; the sums and their order are unchanged)
 """
 import os
 
