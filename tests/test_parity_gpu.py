@@ -687,6 +687,27 @@ def test_heterogeneous_units_on_the_extended_precision_path():
         ctx.close()
 
 
+def test_config3_as_written_in_one_lock_step_unit_equals_the_single_solves():
+    """BASELINE config 3 at size (H-1 dual band, n=512, m=16384, fir_qp_cvx obj=1e6; dzrf_mb.m:210-213): the eight designs of the bench's
+    batch as ONE unit on the extended-precision path -- strong sets of 588 ... 1020 directions, so every lane but the largest carries a
+    padded capacitance matrix -- against the same designs solved one by one: bit for bit."""
+    n, m = 512, 16384
+    f, a, d = mbfir.spec.spec_h1_dualband(n)
+    jobs = [("fir_qp_cvx", (n, f, a, [x * (1.0 + 0.02 * q) for x in d], 120.0, 1e6)) for q in range(8)]
+    ctx = mbfir.Context(0)
+    try:
+        res = mbfir.solve_batch(jobs, ctxs=[ctx], info=True, opts=mbfir.make_opts(grid_m=m, lanes=8))
+        assert all(r[1] == "Solved" and r[2]["lanes"] == 8 for r in res)
+        assert len({r[2]["dd_kmax"] for r in res}) >= 4
+        for q in (0, 2, 5):                                       # (three single solves of 0.1 - 0.15 s each)
+            h1, s1, i1 = mbfir.fir_qp_cvx(*jobs[q][1], ctx=ctx, info=True, opts=mbfir.make_opts(grid_m=m))
+            h, st, i = res[q]
+            assert s1 == st and i1["iters"] == i["iters"] and i1["dd_iters"] == i["dd_iters"] and i1["dd_kmax"] == i["dd_kmax"]
+            assert i1["pcost"] == i["pcost"] and np.array_equal(h, h1), q
+    finally:
+        ctx.close()
+
+
 def test_padding_the_capacitance_matrix_changes_no_bit():
     """A lane of a unit carries its capacitance matrix S padded (unit diagonal) to the unit's largest strong set; the single solve pads
     to its own count only.  MBFIR_TEST_CAP_KP pads the SINGLE solve's S further: same bits.  (Found on the way: the one-pass M'(M b)
