@@ -439,10 +439,13 @@ __device__ __forceinline__ void gt_resid_tail(const DProg& P, const GtResid& F, 
     // The hand-over between workgroups WITHOUT a device-wide fence: __threadfence() writes back and invalidates the XCD's whole L2
     // on this chip (the eight L2s are not coherent with each other) -- with four units in flight that cost 12 % of the batch.  The
     // values handed over are stored write-through and loaded past the caches instead (agent-scope relaxed atomics: sc1), the
-    // stores are drained (workgroup fence: s_waitcnt only) before the counter moves.
+    // stores are drained (s_waitcnt vmcnt(0)) before the counter moves.
     __shared__ int s_last;
     const int tid = threadIdx.y * GTC + threadIdx.x;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // (every storing wave drains its write-through stores before the barrier behind which ONE lane moves the counter: a
+    //  workgroup-scope release fence does NOT emit the s_waitcnt vmcnt(0) this needs -- found by the lock-step fuzz: 1 of 720
+    //  jobs differed in the last bits from run to run until the wait was explicit)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = __hip_atomic_fetch_add(F.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
