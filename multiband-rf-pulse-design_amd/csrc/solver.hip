@@ -3201,18 +3201,29 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     P.lane_bytes = S.lane_bytes;
     S.memset_lanes(zero_from, zero_bytes);
     // ---- lane masks ------------------------------------------------------------------------
+    std::vector<int> dev_mask(size_t(MASK_ROWS) * MAX_LANES, -1), new_mask(size_t(MASK_ROWS) * MAX_LANES, 0);      // what the device holds / is to hold
     auto push_masks = [&]() {                                 // row 0 = live lanes, rows q = 1..MAX_SWEEPS: lanes that run CG sweep q
         if (nlanes == 1) return;
         for (int b = 0; b < nlanes; ++b) {
-            S.hostMask[b] = LH[b].live ? 1 : 0;
+            new_mask[b] = LH[b].live ? 1 : 0;
             S.lane_live[b] = LH[b].live;
             // (a lane whose iteration runs the extended-precision solve takes no part in the plain solve's sweeps)
-            for (int q = 1; q <= MAX_SWEEPS; ++q) S.hostMask[q * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0 && LH[b].nsweep >= q) ? 1 : 0;
-            S.hostMask[ROW_DD * MAX_LANES + b] = (LH[b].live && LH[b].dd_k > 0) ? 1 : 0;
-            S.hostMask[ROW_PL * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0) ? 1 : 0;
+            for (int q = 1; q <= MAX_SWEEPS; ++q) new_mask[q * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0 && LH[b].nsweep >= q) ? 1 : 0;
+            new_mask[ROW_DD * MAX_LANES + b] = (LH[b].live && LH[b].dd_k > 0) ? 1 : 0;
+            new_mask[ROW_PL * MAX_LANES + b] = (LH[b].live && LH[b].dd_k == 0) ? 1 : 0;
         }
-        MBFIR_HIP(hipMemcpyAsync(S.maskT, S.hostMask, sizeof(int) * (MAX_SWEEPS + 1) * MAX_LANES, hipMemcpyHostToDevice, st));
-        if (S.dd_unit) MBFIR_HIP(hipMemcpyAsync(S.maskT + ROW_DD * MAX_LANES, S.hostMask + ROW_DD * MAX_LANES, sizeof(int) * 2 * MAX_LANES, hipMemcpyHostToDevice, st));
+        // (most iterations change nothing: the copy is a launch of its own on the stream -- skipped then)
+        const size_t sweep_ints = size_t(MAX_SWEEPS + 1) * MAX_LANES, dd_off = size_t(ROW_DD) * MAX_LANES, dd_ints = 2 * size_t(MAX_LANES);
+        if (std::memcmp(new_mask.data(), dev_mask.data(), sizeof(int) * sweep_ints) != 0) {
+            std::memcpy(S.hostMask, new_mask.data(), sizeof(int) * sweep_ints);
+            MBFIR_HIP(hipMemcpyAsync(S.maskT, S.hostMask, sizeof(int) * sweep_ints, hipMemcpyHostToDevice, st));
+            std::memcpy(dev_mask.data(), new_mask.data(), sizeof(int) * sweep_ints);
+        }
+        if (S.dd_unit && std::memcmp(new_mask.data() + dd_off, dev_mask.data() + dd_off, sizeof(int) * dd_ints) != 0) {
+            std::memcpy(S.hostMask + dd_off, new_mask.data() + dd_off, sizeof(int) * dd_ints);
+            MBFIR_HIP(hipMemcpyAsync(S.maskT + dd_off, S.hostMask + dd_off, sizeof(int) * dd_ints, hipMemcpyHostToDevice, st));
+            std::memcpy(dev_mask.data() + dd_off, new_mask.data() + dd_off, sizeof(int) * dd_ints);
+        }
     };
     push_masks();
     P.mask = S.mask_row(0);
