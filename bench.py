@@ -183,6 +183,21 @@ def other_configs(mbfir, ctxs):
             out["heterogeneous_64"] = {"error": "only %d of %d S-RAND draws solved" % (len(keep), tried)}
     except Exception as e:                                  # noqa: BLE001
         out["heterogeneous_64"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the DENSE path in lock-step units: north_star's own formulation -- materialised trig matrix, A'DA on the
+    # fp64 matrix cores per build -- as throughput, beside the dense CPU baseline's throughput (main() forms the ratio)
+    try:
+        jd = sweep_jobs(mbfir, 512, 16)
+        od = mbfir.make_opts(grid_m=16384, dense_trig=1, lanes=8)
+        mbfir.solve_batch(jd, ctxs=ctxs, opts=od)
+        t = time.perf_counter()
+        res = mbfir.solve_batch(jd, ctxs=ctxs, opts=od, info=True)
+        dt = time.perf_counter() - t
+        out["dense_batch16"] = {"designs_per_s": 16 / dt, "ms_per_batch": dt * 1e3, "solved": sum(1 for r in res if r[1] == "Solved"),
+                                "lanes_per_unit": sorted({r[2]["lanes"] for r in res}), "streams": len(ctxs), "lattice": sorted({r[2]["lattice"] for r in res}),
+                                "ipm_iters_per_design": sum(r[2]["iters"] for r in res) / 16.0,
+                                "workload": "the first 16 designs of the headline sweep with opts.dense_trig=1 (k_build_A1, k_gram per build, k_amulti / k_atmulti per product)"}
+    except Exception as e:                                  # noqa: BLE001
+        out["dense_batch16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     f, a, d = mbfir.spec.spec_h1_dualband(512)
     jobs16 = [("fir_qp_cvx", (512, f, a, [x * (1.0 + 0.02 * q) for x in d], 120.0, 1e6)) for q in range(16)]
     jobs3 = jobs16[:8]
@@ -578,6 +593,11 @@ def main():
                        "parallelism": "independent designs x%d" % world},
             "ipm_iters_per_design": iters / ndesign,
             "ipm_iters_per_s": world * iters / elapsed,
+            # passes over the frequency rows per iteration of a lock-step unit (mbfir_info.gv_passes / gtv_passes: G v and G'v launches,
+            # a two-vector pass counts once) and the centrality corrector's share (round 6)
+            "gv_passes_per_iter": sum(i["gv_passes"] / max(1, i["iters"]) for i in infos) / len(infos),
+            "gtv_passes_per_iter": sum(i["gtv_passes"] / max(1, i["iters"]) for i in infos) / len(infos),
+            "corrected_directions_taken_frac": sum(i["correctors_taken"] for i in infos) / max(1, sum(i["correctors"] for i in infos)),
             "ms_breakdown_single_stream": {"assemble": solo["ms_assemble"], "solve": solo["ms_solve"], "normal_matrix": solo["ms_gram"],
                                            "cholesky_inverse": solo["ms_chol"], "spectral_factor": solo["ms_post"], "iters": solo["iters"]},
             "ms_breakdown_lockstep_unit": {"lanes": ul, "solve": uinfo["ms_solve"], "normal_matrix": uinfo["ms_gram"],
@@ -600,6 +620,11 @@ def main():
                 out["cpu_baseline"]["gpu_dense_path_designs_per_s"] = 1e3 / dense_info["ms_total"]
                 out["cpu_baseline"]["gpu_dense_path_over_cpu"] = 1e3 / dense_info["ms_total"] / cb["value"]
                 out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["gpu_dense_path_over_cpu"]       # dense vs dense, one design each
+                # ... and throughput against throughput: the dense path in lock-step units (other_baseline_configs.dense_batch16)
+                db = out.get("other_baseline_configs", {}).get("dense_batch16") if isinstance(out.get("other_baseline_configs"), dict) else None
+                if db and "designs_per_s" in db:
+                    out["cpu_baseline"]["gpu_dense_batch16_designs_per_s"] = db["designs_per_s"]
+                    out["cpu_baseline"]["gpu_dense_batch16_over_cpu"] = db["designs_per_s"] / cb["value"]
                 if cb["pcost"] is not None:
                     out["cpu_baseline"]["pcost_gpu_vs_cpu"] = [infos[0]["pcost"], cb["pcost"]]
             out["cpu_baseline"]["s_lp_config1"] = s_lp_baseline(mbfir, ctx)

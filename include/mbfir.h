@@ -84,14 +84,15 @@ typedef struct mbfir_info {
     double ms_gram;      /* device time (HIP events on the solver stream), summed over the builds, of the
                             normal-matrix products: dense mode = the k_gram launches alone; lattice mode =
                             moment kernels + fold + H assembly                                          */
-    double ms_chol;      /* device time of the k_chol_step launches (Cholesky + inverse), summed          */
+    double ms_chol;      /* device time of the factorisation launches (Cholesky + triangular inverse), summed */
     double gram_flop;    /* algorithmic flop of ONE build: dense nw * Mf * Nt * (Nt+1); lattice: the
                             moment recurrences, (3 D - 1) * Mf * (4 + 4 nw)                              */
     int gram_launches;   /* k_gram launches behind ms_gram (= builds * nw; builds = iterations + 1); 0 in
                             lattice mode                                                                */
     int lattice;         /* 1 if the solve ran in lattice (matrix-free) mode                             */
     double chol_flop;    /* flop of one factorisation + triangular inverse: 2/3 np^3                      */
-    int chol_launches;   /* k_chol_step launches behind ms_chol (= builds * (np/64 + 1))                  */
+    int chol_launches;   /* factorisation launches behind ms_chol: ONE k_chol_dag launch per build for lock-step units and
+                            from np = 4096 on (round 3); builds * (np/64 + 1) k_chol_step launches for one or two smaller designs */
     int builds;          /* normal-matrix builds (= iterations + 1)                                       */
     int dd_iters;        /* iterations that ran the extended-precision KKT solve (opts.ddkkt)              */
     int dd_kmax;         /* largest number of strong eigen-directions it carried                          */
@@ -105,6 +106,11 @@ typedef struct mbfir_info {
     double cap_flop;     /* ... and their flop, summed over the builds                                     */
     double collective_bytes;   /* bytes the all-reduces of a row-sharded solve carried on this rank (dense path: the PACKED lower
                                   triangle of the normal matrix per build, N (N + 1) / 2 doubles rounded up to 64 x 64 tiles)    */
+    int correctors;      /* centrality-corrector solves (one per iteration for programs with orthant rows; 0 with
+                            MBFIR_CORRECTOR=0) ...                                                                     */
+    int correctors_taken;/* ... and the iterations that took the corrected direction (its step was 1 % longer)         */
+    int gv_passes;       /* passes over the frequency rows the solve launched, all iterations: row responses G v ...    */
+    int gtv_passes;      /* ... and transposed products G'v (a two-vector pass counts once; a lock-step unit's count)    */
 } mbfir_info;
 
 /* All-reduce hook for row-sharded solves (one process per GPU).  `buf` is a DEVICE pointer to

@@ -53,7 +53,8 @@ class Info(C.Structure):
                 ("chol_flop", C.c_double), ("chol_launches", C.c_int), ("builds", C.c_int),
                 ("dd_iters", C.c_int), ("dd_kmax", C.c_int), ("collectives", C.c_int), ("lanes", C.c_int),
                 ("dd_form", C.c_int), ("ms_cap", C.c_double), ("cap_flop", C.c_double),
-                ("collective_bytes", C.c_double)]
+                ("collective_bytes", C.c_double), ("correctors", C.c_int), ("correctors_taken", C.c_int),
+                ("gv_passes", C.c_int), ("gtv_passes", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

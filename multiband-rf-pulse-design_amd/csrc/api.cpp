@@ -85,6 +85,7 @@ void fill_info(mbfir_info* info, const TrigProgram& P, const SolveInfo& si, int 
     info->dd_iters = si.dd_iters; info->dd_kmax = si.dd_kmax; info->lanes = si.lanes; info->collectives = si.collectives;
     info->collective_bytes = si.collective_bytes;
     info->ms_cap = si.ms_cap; info->cap_flop = si.cap_flop; info->dd_form = si.dd_iters > 0 ? si.dd_form : -1;
+    info->correctors = si.correctors; info->correctors_taken = si.correctors_taken; info->gv_passes = si.gv_passes; info->gtv_passes = si.gtv_passes;
 }
 
 // Solution vector -> taps, per designer.  lane: which design of the solver's last lock-step batch (fir_ap_cvx runs

@@ -49,6 +49,8 @@ struct SolveInfo {
     double collective_bytes = 0;   // ... and the bytes they carried (per rank)
     int lanes = 1;          // designs that shared the lock-step batch (ms_* are those of the whole batch)
     int lattice = 0;        // 1: lattice (matrix-free) mode; gram_flop then counts the moment recurrences
+    int correctors = 0, correctors_taken = 0;   // centrality-corrector solves of this design, and how many of the corrected directions were taken
+    int gv_passes = 0, gtv_passes = 0;          // row-response passes G v and transposed passes G'v the solve launched (all iterations; a lock-step unit's count)
 };
 
 class Solver {

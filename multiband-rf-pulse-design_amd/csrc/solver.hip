@@ -102,11 +102,21 @@ enum {
     S_DEN, S_ETAB, S_NRMH, S_NRMC, S_DEG, S_DKC, S_WB0, S_TMAX, S_BAD,
     S_CHOLFIX /* pivots the last factorisation replaced (copied from the counter so that one D2H copy serves the host) */,
     S_TAU0 /* tau, kappa of the iterate the step is taken from: k_update's blocks read these while block 0 publishes the new ones */, S_KAP0,
+    // centrality corrector (round 6): step of the uncorrected direction, dtau / dkappa of the corrected one, 1 when the corrected
+    // direction is the one taken, and the lane's counts (corrector solves, corrected directions taken)
+    S_ALPHA0, S_DTAU_C, S_DKAP_C, S_PICK, S_NCORR, S_NPICK,
     S_RNA = 40 /* 9 residual norms, batch solve */, S_RNB = 49 /* 9 residual norms, combined solve */,
-    S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */, S_COUNT = 64
+    S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */,
+    S_RNC = 64 /* 9 residual norms, corrector solve */, S_COUNT = 80
 };
 constexpr double STEP = 0.99;
 constexpr double SIGMA_MAX = 0.25;   // cap of Mehrotra's centring parameter (oracle/conic_ipm.py SIGMA_MAX)
+// one centrality corrector per iteration on the orthant rows (oracle/conic_ipm.py CORR_*)
+constexpr double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEPT = 1.01, CORR_ETA = 1.0;
+// end game: an iterate that meets the stopping rule is kept and the iteration goes on until the gap measures are POLISH times below
+// the tolerances, at most POLISH_MAX more iterations (oracle/conic_ipm.py POLISH*)
+constexpr double POLISH = 1e-2;
+constexpr int POLISH_MAX = 3;
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding kernels (a 1024-thread block has to wait for a
                               // whole CU when other units share the chip)
@@ -1301,12 +1311,13 @@ __global__ __launch_bounds__(1024) void k_scal_dtau(DProg P, double* __restrict_
             double dkc = -kap * tau, bt = -Sc[S_RT];
             Sc[S_DTAU_A] = (dkc / tau - bt + cx2 + hz2) / den;
             Sc[S_DKAP_A] = (dkc - kap * Sc[S_DTAU_A]) / tau;
-        } else {
+        } else {                                          // (mode 3: the corrected direction -- same system, its own slots)
             double sigma = Sc[S_SIGMA];
             double dkc = sigma * Sc[S_MU] - kap * tau - Sc[S_DKAP_A] * Sc[S_DTAU_A];
             double bt = -(1 - sigma) * Sc[S_RT];
-            Sc[S_DTAU] = (dkc / tau - bt + cx2 + hz2) / den;
-            Sc[S_DKAP] = (dkc - kap * Sc[S_DTAU]) / tau;
+            const double dt = (dkc / tau - bt + cx2 + hz2) / den;
+            Sc[mode == 3 ? S_DTAU_C : S_DTAU] = dt;
+            Sc[mode == 3 ? S_DKAP_C : S_DKAP] = (dkc - kap * dt) / tau;
         }
     }
 }
@@ -1347,12 +1358,12 @@ __global__ __launch_bounds__(256) void k_dir_post(DProg P, const double* __restr
         }
         dtau = (dkc / tau - bt + cx2 + hz2) / den;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            Sc[mode == 0 ? S_DTAU_A : S_DTAU] = dtau;
-            Sc[mode == 0 ? S_DKAP_A : S_DKAP] = (dkc - kap * dtau) / tau;
+            Sc[mode == 0 ? S_DTAU_A : mode == 3 ? S_DTAU_C : S_DTAU] = dtau;
+            Sc[mode == 0 ? S_DKAP_A : mode == 3 ? S_DKAP_C : S_DKAP] = (dkc - kap * dtau) / tau;
             if (mode == 1) { Sc[S_TAU0] = tau; Sc[S_KAP0] = kap; }
         }
     } else {
-        dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+        dtau = mode == 0 ? Sc[S_DTAU_A] : mode == 3 ? Sc[S_DTAU_C] : Sc[S_DTAU];
     }
     const double oms = mode == 0 ? 1.0 : 1.0 - Sc[S_SIGMA];
     double v[2] = {-1e300, -1e300};
@@ -1389,7 +1400,7 @@ __global__ __launch_bounds__(1024) void k_big_dir_post(DProg P, const double* __
     LANES(P, wbb, lam, z1, z2, g1, g2, rz, Sc, outA, outB, scratch, part_row);
     __shared__ double sh[17];
     const long ob = P.l + 3L * P.nq3;
-    const double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
+    const double dtau = mode == 0 ? Sc[S_DTAU_A] : mode == 3 ? Sc[S_DTAU_C] : Sc[S_DTAU];
     const double oms = mode == 0 ? 1.0 : 1.0 - Sc[S_SIGMA];
     double* dzv = scratch;                 // big
     double* dsv = scratch + P.big;         // big
@@ -1429,8 +1440,8 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
     }
     if (threadIdx.x == 0) {
         double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
-        double dtau = mode == 0 ? Sc[S_DTAU_A] : Sc[S_DTAU];
-        double dkap = mode == 0 ? Sc[S_DKAP_A] : Sc[S_DKAP];
+        double dtau = mode == 0 ? Sc[S_DTAU_A] : mode >= 3 ? Sc[S_DTAU_C] : Sc[S_DTAU];
+        double dkap = mode == 0 ? Sc[S_DKAP_A] : mode >= 3 ? Sc[S_DKAP_C] : Sc[S_DKAP];
         double t = fmax(0.0, fmax(fmax(ts, tz), fmax(-dtau / tau, -dkap / kap)));
         Sc[S_TMAX] = t;
         if (mode == 0) {
@@ -1438,8 +1449,21 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
             Sc[S_ALPHA_A] = a;
             Sc[S_SIGMA] = fmin((1 - a) * (1 - a) * (1 - a), SIGMA_MAX);
             sh[16] = Sc[S_SIGMA];
+        } else if (mode == 2) {                           // the uncorrected direction's step, kept for the corrector: nothing moves yet
+            Sc[S_ALPHA0] = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
         } else {
             double a = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
+            if (mode >= 3) {                              // corrected against uncorrected direction (oracle/conic_ipm.py CORR_ACCEPT; mode 4, a diagnostic: without the residual guard)
+                // (its solve ran without refinement sweeps; what it leaves of the dual equation, ||G'dzk|| in S_RNC, must not exceed
+                //  CORR_ETA times the iterate's own ||rx|| = dres tau ||c|| -- or the absolute floor of the refinement)
+                const double a0 = Sc[S_ALPHA0];
+                const double tolk = fmax(REFTOL * Sc[S_NRMC], CORR_ETA * Sc[S_DRES] * tau * Sc[S_NRMC]);
+                const bool pick = a >= CORR_ACCEPT * a0 && (mode == 4 || Sc[S_RNC] <= tolk);
+                Sc[S_PICK] = pick ? 1.0 : 0.0;
+                Sc[S_NCORR] += 1.0;
+                if (pick) { Sc[S_DTAU] = dtau; Sc[S_DKAP] = dkap; Sc[S_NPICK] += 1.0; }
+                else { a = a0; dtau = Sc[S_DTAU]; dkap = Sc[S_DKAP]; }
+            }
             Sc[S_ALPHA] = a;
             Sc[S_TAU] = tau + a * dtau;
             Sc[S_KAPPA] = kap + a * dkap;
@@ -1564,6 +1588,53 @@ __global__ __launch_bounds__(256) void k_update(DProg P, double* __restrict__ Sc
     const double a = Sc[S_ALPHA], dtau = Sc[S_DTAU];
     if (t < P.N) x[t] += a * (x2[t] + dtau * x1[t]);
     if (t < P.R) { s[t] += a * ds[t]; z[t] += a * dz[t]; }
+}
+// the same after a centrality corrector: k_scal_step (mode 3) has chosen between the two directions (S_PICK), set alpha, dtau
+// and moved tau, kappa
+__global__ __launch_bounds__(256) void k_update_pick(DProg P, const double* __restrict__ Sc, const double* __restrict__ x1,
+                         const double* __restrict__ x2, const double* __restrict__ x2k, double* __restrict__ x,
+                         const double* __restrict__ ds, const double* __restrict__ dz, const double* __restrict__ dsk,
+                         const double* __restrict__ dzk, double* __restrict__ s, double* __restrict__ z) {
+    LANES(P, Sc, x1, x2, x2k, x, ds, dz, dsk, dzk, s, z);
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a = Sc[S_ALPHA], dtau = Sc[S_DTAU];
+    const bool pick = Sc[S_PICK] != 0.0;
+    if (t < P.N) x[t] += a * ((pick ? x2k[t] : x2[t]) + dtau * x1[t]);
+    if (t < P.R) { s[t] += a * (pick ? dsk[t] : ds[t]); z[t] += a * (pick ? dzk[t] : dz[t]); }
+}
+// Centrality corrector, right-hand side (oracle/conic_ipm.py solve(): CORR_*).  (ds, dz) is the predictor-corrector direction,
+// S_ALPHA0 its step.  On the orthant rows the products at the trial step  at = min(1, alpha0 + CORR_DELTA),
+//   v = (lam + at W^-1 ds)(lam + at W dz),
+// are projected onto [CORR_BMIN, CORR_BMAX] sigma mu; t = projection - v, bounded below by -CORR_BMAX sigma mu;
+//   bz = -W (lam \ t),  wbz = W^-2 bz;   the cone rows get zeros (their products are left alone).
+__global__ __launch_bounds__(256) void k_corr_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ dl,
+                                                  const double* __restrict__ lam, const double* __restrict__ ds,
+                                                  const double* __restrict__ dz, const double* __restrict__ Sc,
+                                                  double* __restrict__ bz, double* __restrict__ wbz) {
+    LANES(P, wl, dl, lam, ds, dz, Sc, bz, wbz);
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.R) return;
+    double b = 0.0, wb = 0.0;
+    if (t < P.l) {
+        const double at = fmin(1.0, Sc[S_ALPHA0] + CORR_DELTA), mut = Sc[S_SIGMA] * Sc[S_MU];
+        const double l = lam[t], w = wl[t];
+        const double dss = ds[t] / w, wdz = w * dz[t];
+        const double v = (l + at * dss) * (l + at * wdz);
+        double tt = fmin(fmax(v, CORR_BMIN * mut), CORR_BMAX * mut) - v;
+        tt = fmax(tt, -CORR_BMAX * mut);
+        b = -w * (tt / l);
+        wb = dl[t] * b;
+    }
+    bz[t] = b; wbz[t] = wb;
+}
+// candidate = predictor-corrector solution + corrector solution, in place in the corrector's arrays
+__global__ __launch_bounds__(256) void k_corr_add(DProg P, const double* __restrict__ x2, const double* __restrict__ z2,
+                                                  const double* __restrict__ g2, double* __restrict__ xk, double* __restrict__ zk,
+                                                  double* __restrict__ gk) {
+    LANES(P, x2, z2, g2, xk, zk, gk);
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P.N) xk[t] = x2[t] + xk[t];
+    if (t < P.R) { zk[t] = z2[t] + zk[t]; gk[t] = g2[t] + gk[t]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2069,6 +2140,7 @@ struct Solver::Impl {
     int comm_size = 0, comm_rank = 0;
     long n_collectives = 0;      // issued by the current solve
     double collective_bytes = 0; // ... and the bytes they carried
+    long n_gv = 0, n_gtv = 0;    // passes over the frequency rows of the current solve: G v (apply_G / apply_G_winv2, the residual's row response), G'v (apply_GT)
     void allreduce(double* buf, long count, int op) {
         if (shard_size <= 1) return;
         ++n_collectives;
@@ -2115,6 +2187,9 @@ struct Solver::Impl {
     double *tmpN, *tmpN2, *rhsN, *yN, *tmpR, *wbz, *pN, *wpR;
     double *bx2, *bz2, *dx2, *dz2, *gdx2, *gdxc, *xbest, *rx, *rz, *GTz, *Gx;
     double *dssa, *wdza, *lds, *bxc, *bzc, *dxc, *dzc, *ds, *dz, *scratch;
+    double *kbx, *kbz, *kx, *kz, *kg, *kds, *kdz;        // centrality corrector: right-hand side (kbx stays zero), solution / candidate, its direction
+    bool corrector = true;       // one centrality corrector per iteration (MBFIR_CORRECTOR=0: off; programs without orthant rows never run it)
+    bool corr_plain = true;      // ... its solve is the Cholesky solve alone (MBFIR_CORR_PLAIN=0, a diagnostic: with the refinement sweeps of the other solves)
     double *partR, *partR2, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
     // extended-precision KKT solve (ddkkt.inc): H = H_w + U'XU and its Cholesky factor in double-double.
@@ -2237,6 +2312,7 @@ struct Solver::Impl {
     template <int NV>
     void apply_G(const double* v, double* out) {
         const int NVV = P.quad ? 2 * NV : NV;
+        ++n_gv;
         if (P.trig) {
             hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
             hipLaunchKernelGGL(k_rows_G<NV>, lane_grid(dim3(cdiv(P.R, 256)), nlanes), dim3(256), 0, st, P, UU, v, out);
@@ -2258,6 +2334,7 @@ struct Solver::Impl {
     template <int NV>
     void apply_G_winv2(const double* v, double* gout, const double* sub, double* wout) {
         if (P.trig && !P.big) {
+            ++n_gv;
             hipLaunchKernelGGL(k_trig_eval<NV>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, v, UU);
             hipLaunchKernelGGL(k_rows_winv2<NV>, lane_grid(dim3(cdiv(P.l + P.nq3, 256)), nlanes), dim3(256), 0, st, P, UU, v, dl, w3, sub, gout, wout);
             return;
@@ -2298,6 +2375,7 @@ struct Solver::Impl {
     // rn_bx != null: the residual r = rn_bx - G'v and its norm (Sc[rn_slot]) ride in k_gt_finish (unsharded solves)
     template <int NV>
     void apply_GT(const double* val, double* out, int tail = 0, const double* rn_bx = nullptr, double* rn_r = nullptr, int rn_slot = 0) {
+        ++n_gtv;
         if (P.trig) {
             dim3 g(cdiv(P.D1, MPTS), cdiv(P.nchunk, P.cgrp)), b(256);
             const dim3 gf(cdiv(P.nfold, 256));
@@ -2800,6 +2878,11 @@ struct LaneHost {
     bool live = true, have_best = false;
     double best_merit = 1e300, rx_prev = 0;
     SolveInfo info, best_info;
+    // end game (oracle/conic_ipm.py POLISH): the first iteration whose iterate met the stopping rule, the best such iterate's merit and report
+    // (its x / tau is in xbest: once an iterate has met the rule the reduced-accuracy candidate that buffer held is of no use)
+    int first_opt = -1;
+    double opt_merit = 1e300;
+    SolveInfo opt_info;
     // extended-precision path: strong directions of the current iteration (0: the plain solve), iterations on it, its largest set
     int dd_k = 0, dd_iters = 0, dd_kmax = 0;
 };
@@ -2964,6 +3047,11 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (S.comm && S.shard_size > 1 && (S.comm_size != S.shard_size || S.comm_rank != S.shard_rank))
         throw HipError("row-sharded solve: shard_rank / shard_size differ from the RCCL communicator's");
     S.n_collectives = 0; S.collective_bytes = 0;
+    S.n_gv = 0; S.n_gtv = 0;
+    S.corrector = true;
+    if (const char* ev = std::getenv("MBFIR_CORRECTOR")) S.corrector = std::atoi(ev) != 0;
+    S.corr_plain = true;
+    if (const char* ev = std::getenv("MBFIR_CORR_PLAIN")) S.corr_plain = std::atoi(ev) != 0;
     if (S.shard_size > 1 && nlanes > 1) throw ShapeError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
@@ -3158,6 +3246,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     S.rz = ar.get<double>(Rp); S.Gx = ar.get<double>(Rp); S.dssa = ar.get<double>(Rp); S.wdza = ar.get<double>(Rp);
     S.lds = ar.get<double>(Rp); S.bzc = ar.get<double>(Rp); S.dzc = ar.get<double>(Rp); S.ds = ar.get<double>(Rp);
     S.dz = ar.get<double>(Rp); S.scratch = ar.get<double>(4 * (size_t)std::max(P.big, 1) + 8);
+    S.kbx = ar.get<double>(LDV); S.kbz = ar.get<double>(Rp); S.kx = ar.get<double>(LDV); S.kz = ar.get<double>(Rp); S.kg = ar.get<double>(Rp);
+    S.kds = ar.get<double>(Rp); S.kdz = ar.get<double>(Rp);
     S.UU = ar.get<double>(4 * Mpad * (size_t)P.useg); S.PP = ar.get<double>(4 * Mpad); S.PPf = ar.get<double2>(6 * Mpad); S.Dw = ar.get<double>(9 * Mpad); S.BB = S.Dw + (size_t)nw * Mpad;       // border vectors right behind the nw weight vectors
     S.partial = ar.get<double>(std::max(P.trig ? (size_t)cdiv(P.nchunk, P.cgrp) * 12 * P.LDM : (size_t)S.nsplit_at * 6 * ld,
                                         std::max(hsolve_part_doubles(int(np)), hsolve_part_doubles(CAP_KMAX))));   // (also the partial vectors of the one-pass M'(M b), of H and of the capacitance matrix)
@@ -3274,6 +3364,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
 
     int it = 0;
     bool dd_now = false;
+    const bool use_corr = S.corrector && P.l > 0;             // (every lane of a unit is the same designer: orthant rows in all of them or in none)
     // MBFIR_TRACE_HOST=1: where the host thread of this unit spends the solve -- issuing launches, or waiting in the one
     // synchronisation per iteration (a stream whose host thread issues most of the time is launch-bound, not GPU-bound)
     const bool trace_host = std::getenv("MBFIR_TRACE_HOST") != nullptr;
@@ -3285,6 +3376,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         // summed over the ranks by the same all-reduce (they do not depend on G'z)
         double* rmail = sharded ? S.GTz + LDV : S.RB;
         if (P.trig) {                                     // G x rows are formed inside k_resid_rows
+            ++S.n_gv;
             hipLaunchKernelGGL(k_trig_eval<1>, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), nlanes), dim3(256), 0, st, P, S.x, S.UU);
             hipLaunchKernelGGL(k_resid_rows, lane_grid(dim3(S.nbR), nlanes), dim3(256), 0, st, P, nullptr, S.s, S.z, S.Sc, S.rz, S.bz2, S.partR, S.UU, S.x);
         } else {
@@ -3381,7 +3473,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                 const double tol = std::max(REFTOL * hs[S_NRMC], REFETA * L.rx_prev);   // ||rx|| of the iteration the norms belong to
                 int need = 0;
                 bool unconverged = false;
-                for (int slot : {int(S_RNA), int(S_RNB)}) {
+                for (int slot : {int(S_RNA), int(S_RNB)}) {        // (the corrector's solve runs without sweeps and reports no norms)
                     int k = -1;
                     for (int q = 0; q <= std::min(L.nsweep, MAX_SWEEPS); ++q)      // n_0 .. n_nsweep
                         if (hs[slot + q] <= tol) { k = q; break; }
@@ -3393,6 +3485,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             L.rx_prev = hs[S_DRES] * hs[S_TAU] * hs[S_NRMC];
             info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
             info.relgap = hs[S_RELGAP]; info.pres = hs[S_PRES]; info.dres = hs[S_DRES];
+            info.correctors = int(hs[S_NCORR]); info.correctors_taken = int(hs[S_NPICK]);
             if (o.verbose)
                 fprintf(stderr, "%s%3d pcost % .10e dcost % .10e gap %.2e pres %.1e dres %.1e k/t %.1e mu %.1e a %.3f sig %.1e sweeps %d chol %d%s\n",
                         nlanes > 1 ? ("[" + std::to_string(b) + "] ").c_str() : "", it, hs[S_PCOST], hs[S_DCOST], hs[S_GAP], hs[S_PRES],
@@ -3401,12 +3494,25 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                                        hs[S_RNA], hs[S_RNA + 1], S.dd_passes > 2 ? hs[S_RNA + 2] : 0.0, hs[S_RNB], hs[S_RNB + 1], S.dd_passes > 2 ? hs[S_RNB + 2] : 0.0);
                                        return std::string(bf); }().c_str() : "");
             auto finish = [&](int status) { L.status = status; L.live = false; };
-            if (!(std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0)) { finish(ST_NUMERICAL); continue; }
-            if (hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) { finish(ST_OPTIMAL); continue; }
+            const bool finite = std::isfinite(hs[S_PRES]) && std::isfinite(hs[S_DRES]) && std::isfinite(hs[S_GAP]) && hs[S_TAU] > 0;
+            if (finite && hs[S_PRES] <= o.feastol && hs[S_DRES] <= o.feastol && (hs[S_GAP] <= o.abstol || hs[S_RELGAP] <= o.reltol)) {
+                // end game (mirrors oracle/conic_ipm.py): the iterate meets the stopping rule -- keep the best such iterate (xbest) and
+                // go on until the gap measures are POLISH times below the tolerances or POLISH_MAX more iterations have passed; the
+                // best iterate is the answer however the end game ends
+                const double merit_o = std::min(hs[S_RELGAP] / o.reltol, hs[S_GAP] / std::max(o.abstol, 1e-300));
+                if (L.first_opt < 0 || merit_o < L.opt_merit) {
+                    L.opt_merit = merit_o; L.opt_info = info;
+                    S.hostMask[ROW_BEST * MAX_LANES + b] = 1;
+                    any_best = true;
+                }
+                if (L.first_opt < 0) L.first_opt = it;
+                if (hs[S_GAP] <= POLISH * o.abstol || hs[S_RELGAP] <= POLISH * o.reltol || it >= L.first_opt + POLISH_MAX) { finish(ST_OPTIMAL); continue; }
+            }
+            if (!finite) { finish(ST_NUMERICAL); continue; }
             const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
-            if (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5)) { finish(ST_PRIMAL_INFEASIBLE); continue; }
-            if (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5)) { finish(ST_DUAL_INFEASIBLE); continue; }
-            if (hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
+            if (L.first_opt < 0 && (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5))) { finish(ST_PRIMAL_INFEASIBLE); continue; }
+            if (L.first_opt < 0 && (hs[S_DINF] <= o.feastol || (collapsed && hs[S_DINF] <= 1e-5))) { finish(ST_DUAL_INFEASIBLE); continue; }
+            if (L.first_opt < 0 && hs[S_PRES] <= INACC_FEAS && hs[S_DRES] <= INACC_FEAS) {
                 // best iterate for the reduced-accuracy exit: residuals within the reduced tolerance,
                 // smallest gap measure (mirrors oracle/conic_ipm.py)
                 double merit = std::min(hs[S_RELGAP], hs[S_GAP] / std::max(o.abstol, 1e-300) * o.reltol);
@@ -3452,7 +3558,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             for (int b = 0; b < nlanes; ++b) pl_any = pl_any || (LH[b].live && LH[b].dd_k == 0);
         }
         const int* live_row = P.mask;
-        auto solve2 = [&](auto NVc, const double* bx, const double* bz, double* dx, double* dz, double* gdx, int slot) {
+        auto solve2 = [&](auto NVc, const double* bx, const double* bz, double* dx, double* dz, double* gdx, int slot, bool nosweep = false) {
             constexpr int NVX = decltype(NVc)::value;
             if (dd_any) {
                 if (S.dd_unit) P.mask = S.mask_row(ROW_DD);
@@ -3460,7 +3566,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             }
             if (pl_any) {
                 if (S.dd_unit) P.mask = S.mask_row(ROW_PL);
-                S.kkt_solve<NVX>(bx, bz, dx, dz, gdx, nsweep_max, slot, true);              // W^-2 bz came with k_scaling / k_comb_rhs
+                S.kkt_solve<NVX>(bx, bz, dx, dz, gdx, nosweep ? 0 : nsweep_max, slot, true);  // W^-2 bz came with k_scaling / k_comb_rhs / k_corr_rhs
             }
             P.mask = live_row;
         };
@@ -3510,9 +3616,48 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                                S.scratch);
         solve2(std::integral_constant<int, 1>(), S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
         const int nd1 = dots(S.dxc, S.dzc, 1);
-        const int ns1 = dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
-        hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z,
-                           (!sharded && S.fuse_fold) ? (const double*)S.partR2 : (const double*)nullptr, ns1);
+        if (!use_corr) {
+            const int ns1 = dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
+            hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z,
+                               (!sharded && S.fuse_fold) ? (const double*)S.partR2 : (const double*)nullptr, ns1);
+            return;
+        }
+        // ---- one centrality corrector (round 6; oracle/conic_ipm.py solve(): CORR_*) -------------------------------------------
+        // the step of the predictor-corrector direction is measured but not taken (k_scal_step mode 2); the orthant rows' products
+        // at the trial step alpha0 + CORR_DELTA, projected onto the box around sigma mu, give one more right-hand side for the
+        // factorisation at hand; the candidate (predictor-corrector + corrector solution) gets its own direction and step
+        // (mode 3: own dtau / dkappa slots), k_scal_step picks the longer step by CORR_ACCEPT and moves tau, kappa, k_update_pick
+        // moves x, s, z along the direction picked.  Every lane decides for itself.
+        auto scal_step = [&](int mode, int nb) {
+            if (sharded) {
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 0);
+                S.allreduce(S.RB, 2, 1);
+                hipLaunchKernelGGL(k_scal_step, dim3(1), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 1);
+            } else {
+                hipLaunchKernelGGL(k_scal_step, lane_grid(dim3(1), nlanes), dim3(SCAL_T), 0, st, P, S.Sc, S.partR2, nb, mode, S.rx, S.bxc, S.RB, 2);
+            }
+        };
+        auto dir_post_c = [&](const double* xx2, const double* zz2, const double* gg2, double* outA, double* outB, int mode, int ndots) -> int {
+            int nb = std::max(S.nbC, 1);
+            hipLaunchKernelGGL(k_dir_post, lane_grid(dim3(nb), nlanes), dim3(256), 0, st, P, S.wl, S.w3, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+                               S.partR2, mode, sharded ? nullptr : S.partR, ndots, xx2);
+            if (P.big) {
+                hipLaunchKernelGGL(k_big_dir_post, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, z1, zz2, g1, gg2, S.rz, S.Sc, outA, outB,
+                                   S.scratch, S.partR2, mode);
+                nb += 1;
+            }
+            return nb;
+        };
+        const int nsA = dir_post_c(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
+        scal_step(2, nsA);
+        hipLaunchKernelGGL(k_corr_rhs, lane_grid(dim3(cdiv(R, 256)), nlanes), dim3(256), 0, st, P, S.wl, S.dl, S.lam, S.ds, S.dz, S.Sc, S.kbz, S.wbz);
+        solve2(std::integral_constant<int, 1>(), S.kbx, S.kbz, S.kx, S.kz, S.kg, S_RNC, S.corr_plain);     // the Cholesky solve and its residual norm (S_RNC), no sweeps (lanes on the extended-precision path: their usual passes)
+        hipLaunchKernelGGL(k_corr_add, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.dxc, S.dzc, S.gdxc, S.kx, S.kz, S.kg);
+        const int ndC = dots(S.kx, S.kz, 3);
+        const int nsC = dir_post_c(S.kx, S.kz, S.kg, S.kds, S.kdz, 3, ndC);
+        scal_step(std::getenv("MBFIR_CORR_GUARD") && std::atoi(std::getenv("MBFIR_CORR_GUARD")) == 0 ? 4 : 3, nsC);
+        hipLaunchKernelGGL(k_update_pick, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.kx, S.x, S.ds, S.dz,
+                           S.kds, S.kdz, S.s, S.z);
         };
         if (use_graph) {
             auto g = graphs.find(nsweep_max);
@@ -3559,7 +3704,14 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         LaneHost& L = LH[b];
         if (L.live) L.status = ST_MAXIT;
         char* xo = reinterpret_cast<char*>(S.xout) + (size_t)b * S.lane_bytes;
-        if ((L.status == ST_MAXIT || L.status == ST_NUMERICAL) && L.have_best && L.best_info.pres <= INACC_FEAS &&
+        if (L.first_opt >= 0) {
+            // an iterate met the stopping rule: the best of them (xbest) is the answer, however the end game ended -- its target,
+            // its iteration cap, max_iter, the numerical wall, a non-finite iterate
+            const SolveInfo last = L.info;
+            L.info = L.opt_info; L.info.iters = last.iters; L.info.correctors = last.correctors; L.info.correctors_taken = last.correctors_taken;
+            L.status = ST_OPTIMAL;
+            MBFIR_HIP(hipMemcpyAsync(xo, reinterpret_cast<char*>(S.xbest) + (size_t)b * S.lane_bytes, sizeof(double) * LDV, hipMemcpyDeviceToDevice, st));
+        } else if ((L.status == ST_MAXIT || L.status == ST_NUMERICAL) && L.have_best && L.best_info.pres <= INACC_FEAS &&
             L.best_info.dres <= INACC_FEAS && (L.best_info.relgap <= INACC_GAP || L.best_info.gap <= o.abstol)) {
             // the reference accepts CVX's 'Inaccurate/Solved' (fir_ap_cvx.m:176): reduced tolerances
             const int keep_it = L.info.iters;
@@ -3605,6 +3757,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         info.lanes = nlanes;
         info.collectives = int(S.n_collectives);
         info.collective_bytes = S.collective_bytes;
+        info.gv_passes = int(S.n_gv); info.gtv_passes = int(S.n_gtv);
         info.dd_iters = LH[b].dd_iters; info.dd_kmax = LH[b].dd_kmax;
         info.dd_form = S.cap_form ? 0 : 1; info.cap_flop = S.cap_flop_sum; info.ms_cap = ms_cap;
         info.chol_launches = int(S.chol_launch_count);

@@ -21,6 +21,9 @@
 namespace {
 
 typedef std::vector<double> vec;
+const double POLISH = 1e-2;      // conic_ipm.py: the end game
+const int POLISH_MAX = 3;
+const double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEPT = 1.01, CORR_ETA = 1.0;      // conic_ipm.py: the centrality corrector
 const double STEP = 0.99, SIGMA_MAX = 0.25, REFTOL = 1e-11, REFETA = 1e-1, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
 const int MAX_SWEEPS = 8, WALL_ITERS = 3, NB = 64;
 enum { ST_OPTIMAL = 0, ST_PINF = 1, ST_DINF = 2, ST_MAXIT = 3, ST_NUMERICAL = 4, ST_INACC = 5 };
@@ -398,7 +401,8 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         t_factor += omp_get_wtime() - t0;
     };
     // [0 G'; G -W^2][dx; dz] = [bx; bz] for ONE right-hand side; dz explicit, refined by PCG on the exact operator
-    auto kkt_solve = [&](const double* bx, const double* bz, double* dx, double* dz, double* gdx) {
+    double plain_norm = 0;               // ||bx - G'dz|| of the last plain solve (the corrector's residual guard)
+    auto kkt_solve = [&](const double* bx, const double* bz, double* dx, double* dz, double* gdx, bool plain = false) {
         vec wbz(R), rhs(N), r(N), zz(N), p(N), Gp(R), Wp(R), Hp(N);
         winv2(bz, wbz.data());
         D.mulT(wbz.data(), rhs.data());
@@ -409,6 +413,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         for (int i = 0; i < R; ++i) dz[i] -= wbz[i];
         D.mulT(dz, r.data());
         for (int j = 0; j < N; ++j) r[j] = bx[j] - r[j];
+        if (plain) { plain_norm = nrm2(r.data(), N); return; }       // (the corrector's solve: no sweeps, nothing for the controller)
         vec norms{nrm2(r.data(), N)};
         if (nsweep > 0) {
             cho_solve(H.data(), N, r.data(), zz.data());
@@ -458,8 +463,12 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
     double pcost = 0, dcost = 0, gap = 0, relgap = 0, pres = 0, dres = 0, best_merit = 1e300;
     double best_info[6] = {0, 0, 0, 0, 0, 0};
     vec xbest;
+    int first_opt = -1;                  // end game: the first iteration whose iterate met the stopping rule ...
+    double opt_merit = 1e300, opt_info[6] = {0, 0, 0, 0, 0, 0};
+    vec xopt;                            // ... and the best such iterate
     vec rx(N), rz(R), lam(R), x1(N), z1(R), g1(R), x2(N), z2(R), g2(R), bxa(N), bza(R), wz1(R), dsa(R), dza(R), dssa(R), wdza(R),
-        ll(R), dsc(R), lds(R), wlds(R), bxc(N), bzc(R), ds(R), dz(R), dss(R), wdz(R), dxv(N), pr(R);
+        ll(R), dsc(R), lds(R), wlds(R), bxc(N), bzc(R), ds(R), dz(R), dss(R), wdz(R), dxv(N), pr(R), bzk(R), xk(N), zk(R), gk(R), dsk(R), dzk(R),
+        dssk(R), wdzk(R);
     for (it = 0; it <= max_iter; ++it) {
         D.mulT(z.data(), rx.data());
         for (int j = 0; j < N; ++j) rx[j] += c[j] * tau;
@@ -475,11 +484,25 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         for (int j = 0; j < N; ++j) { const double v = rx[j] - c[j] * tau; hresx += v * v; }
         for (int i = 0; i < R; ++i) { const double v = rz[i] + h[i] * tau; hresz += v * v; }
         const double pinf = hz < 0 ? std::sqrt(hresx) / (-hz) : 1e300, dinf = cx < 0 ? std::sqrt(hresz) / (-cx) : 1e300;
-        if (!(std::isfinite(pres) && std::isfinite(dres) && std::isfinite(gap) && tau > 0)) { status = ST_NUMERICAL; break; }
-        if (pres <= feastol && dres <= feastol && (gap <= abstol || relgap <= reltol)) { status = ST_OPTIMAL; break; }
+        const bool finite = std::isfinite(pres) && std::isfinite(dres) && std::isfinite(gap) && tau > 0;
+        if (finite && pres <= feastol && dres <= feastol && (gap <= abstol || relgap <= reltol)) {
+            // end game (conic_ipm.py): keep the best iterate that meets the rule, go on until the gap measures are POLISH times
+            // below the tolerances or POLISH_MAX more iterations have passed
+            const double merit_o = std::min(relgap / reltol, gap / std::max(abstol, 1e-300));
+            if (first_opt < 0 || merit_o < opt_merit) {
+                opt_merit = merit_o;
+                xopt.assign(N, 0.0);
+                for (int j = 0; j < N; ++j) xopt[j] = x[j] / tau;
+                const double oi[6] = {pcost, dcost, gap, relgap, pres, dres};
+                std::memcpy(opt_info, oi, sizeof(oi));
+            }
+            if (first_opt < 0) first_opt = it;
+            if (gap <= POLISH * abstol || relgap <= POLISH * reltol || it >= first_opt + POLISH_MAX) { status = ST_OPTIMAL; break; }
+        }
+        if (!finite) { status = ST_NUMERICAL; break; }
         const bool collapsed = kappa / tau >= 1e6;
-        if (pinf <= feastol || (collapsed && pinf <= 1e-5)) { status = ST_PINF; break; }
-        if (dinf <= feastol || (collapsed && dinf <= 1e-5)) { status = ST_DINF; break; }
+        if (first_opt < 0 && (pinf <= feastol || (collapsed && pinf <= 1e-5))) { status = ST_PINF; break; }
+        if (first_opt < 0 && (dinf <= feastol || (collapsed && dinf <= 1e-5))) { status = ST_DINF; break; }
         if (pres <= INACC_FEAS && dres <= INACC_FEAS) {
             const double merit = std::min(relgap, gap / std::max(abstol, 1e-300) * reltol);
             if (merit < best_merit) {
@@ -539,7 +562,29 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         for (int i = 0; i < R; ++i) bzc[i] = -(1 - sigma) * rz[i] - wlds[i];
         kkt_solve(bxc.data(), bzc.data(), x2.data(), z2.data(), g2.data());
         direction(sigma, dk_c, x2.data(), z2.data(), g2.data(), ds.data(), dz.data(), dss.data(), wdz.data());
-        const double alpha = step_of(dss.data(), wdz.data(), STEP);
+        double alpha = step_of(dss.data(), wdz.data(), STEP);
+        if (K.l > 0) {
+            // one centrality corrector on the orthant rows (conic_ipm.py: CORR_*): trial step alpha + CORR_DELTA, the rows'
+            // products projected onto [CORR_BMIN, CORR_BMAX] sigma mu, one more solve with the factorisation at hand, the
+            // corrected direction taken when its step is CORR_ACCEPT times longer
+            const double at = std::min(1.0, alpha + CORR_DELTA), mut = sigma * mu, dtau0 = dtau, dkap0 = dkap;
+            for (int i = 0; i < R; ++i) bzk[i] = 0.0;
+            for (int i = 0; i < K.l; ++i) {
+                const double v = (lam[i] + at * dss[i]) * (lam[i] + at * wdz[i]);
+                double tt = std::min(std::max(v, CORR_BMIN * mut), CORR_BMAX * mut) - v;
+                tt = std::max(tt, -CORR_BMAX * mut);
+                bzk[i] = -W.wl[i] * (tt / lam[i]);
+            }
+            kkt_solve(zero_n.data(), bzk.data(), xk.data(), zk.data(), gk.data(), true);
+            for (int j = 0; j < N; ++j) xk[j] += x2[j];
+            for (int i = 0; i < R; ++i) { zk[i] += z2[i]; gk[i] += g2[i]; }
+            direction(sigma, dk_c, xk.data(), zk.data(), gk.data(), dsk.data(), dzk.data(), dssk.data(), wdzk.data());
+            const double alpha_c = step_of(dssk.data(), wdzk.data(), STEP);
+            if (plain_norm <= std::max(REFTOL * nrm_c, CORR_ETA * nrm2(rx.data(), N)) && alpha_c >= CORR_ACCEPT * alpha) {
+                alpha = alpha_c;
+                x2.swap(xk); ds.swap(dsk); dz.swap(dzk);
+            } else { dtau = dtau0; dkap = dkap0; }
+        }
         nsweep = next_sweeps(std::max(REFTOL * nrm_c, REFETA * nrm2(rx.data(), N)));   // forcing term, see conic_ipm.py
         for (int j = 0; j < N; ++j) x[j] += alpha * (x2[j] + dtau * x1[j]);
         for (int i = 0; i < R; ++i) { s[i] += alpha * ds[i]; z[i] += alpha * dz[i]; }
@@ -548,7 +593,11 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
     }
     for (int j = 0; j < N; ++j) x_out[j] = x[j] / tau;
     double out[6] = {pcost, dcost, gap, relgap, pres, dres};
-    if ((status == ST_MAXIT || status == ST_NUMERICAL) && !xbest.empty() && best_info[4] <= INACC_FEAS && best_info[5] <= INACC_FEAS &&
+    if (first_opt >= 0) {                // an iterate met the stopping rule: the best of them is the answer, however the end game ended
+        status = ST_OPTIMAL;
+        std::memcpy(out, opt_info, sizeof(out));
+        std::memcpy(x_out, xopt.data(), sizeof(double) * N);
+    } else if ((status == ST_MAXIT || status == ST_NUMERICAL) && !xbest.empty() && best_info[4] <= INACC_FEAS && best_info[5] <= INACC_FEAS &&
         (best_info[3] <= INACC_GAP || best_info[2] <= abstol)) {
         status = ST_INACC;
         std::memcpy(out, best_info, sizeof(out));

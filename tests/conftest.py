@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # the oracle's BLAS calls are small (n <= 200 in the CPU suite): more than four threads only oversubscribe the cores the
+    # C++ twin's OpenMP team and the test workers share (8 cores here: 277 s with the default team, 62 s with four threads)
+    try:
+        from threadpoolctl import threadpool_limits
+        config._mbfir_blas_limit = threadpool_limits(limits=min(4, os.cpu_count() or 1), user_api="blas")
+    except Exception:                                       # noqa: BLE001  (threadpoolctl missing: the defaults stay)
+        pass
 
 
 # ---- shared specs ---------------------------------------------------------

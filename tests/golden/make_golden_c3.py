@@ -7,7 +7,7 @@ and two independent parts:
   * the HiGHS optimum of the LP relaxation (scipy.optimize.linprog, spike cones dropped, 1e-10 tolerances), which IS
     the SOCP optimum when its point leaves every spike cone slack (`highs_cones_slack`): an unrelated solver's value of
     the same program.  (The dense LP is 32788 x 1024; HiGHS needs its time.)
-Run:  python tests/golden/make_golden_c3.py [--no-highs]      (rewrites c3_golden.json)
+Run:  python tests/golden/make_golden_c3.py [--no-highs | --twin-only]      (rewrites c3_golden.json; --twin-only: the second record alone)
 """
 import json
 import os
@@ -24,11 +24,29 @@ from conftest import c13  # noqa: E402
 from oracle import assemble, conic_ipm, specfact  # noqa: E402
 
 
+def twin_only(n, m, P):
+    G, h, c, l = P["G"], P["h"], P["c"], P["l"]
+    path = os.path.join(HERE, "c3_golden.json")
+    with open(path) as fh:
+        rec = json.load(fh)["c3_ap_512_16384"]
+    t = time.time()
+    r0 = conic_ipm.solve(c, G, h, l, P["nq3"], P["big"], corrector=False)
+    taps0 = specfact.fmp2(specfact.x_to_r(r0["x"][: 2 * n - 1], n))
+    rec0 = dict(n=n, grid_m=m, status=int(r0["status"]), iters=int(r0["iters"]), pcost=float(r0["pcost"]), gap=float(r0["gap"]), relgap=float(r0["relgap"]),
+                pres=float(r0["pres"]), dres=float(r0["dres"]), seconds=time.time() - t, x=[float(v) for v in r0["x"]],
+                h_re=[float(v) for v in taps0.real], h_im=[float(v) for v in taps0.imag])
+    print({k: v for k, v in rec0.items() if k not in ("x", "h_re", "h_im")}, flush=True)
+    with open(path, "w") as fh:
+        json.dump({"c3_ap_512_16384": rec, "c3_ap_512_16384_no_corrector": rec0}, fh)
+
+
 def main():
     n, m = 512, 16384
     f, a, d = c13(n, "duration")
     P = assemble.assemble_fir_ap_cvx(n, f, a, d, 0.1, 1e-3, m)
     G, h, c, l = P["G"], P["h"], P["c"], P["l"]
+    if "--twin-only" in sys.argv:                            # (keep the first record as it is on file, redo the second)
+        return twin_only(n, m, P)
     t = time.time()
     r = conic_ipm.solve(c, G, h, l, P["nq3"], P["big"])
     secs = time.time() - t
@@ -59,8 +77,20 @@ def main():
             rec["highs_cones_slack"] = bool((qh[:, 0] - np.hypot(qh[:, 1], qh[:, 2])).min() > 0)
             rec["highs_x_maxdiff"] = float(np.abs(rh.x - x).max())
         print({k: v for k, v in rec.items() if k.startswith("highs")}, flush=True)
-    with open(os.path.join(HERE, "c3_golden.json"), "w") as fh:
-        json.dump({"c3_ap_512_16384": rec}, fh)
+    # Second record (round 6): the same instance WITHOUT the centrality corrector (conic_ipm.solve(corrector=False); the device:
+    # MBFIR_CORRECTOR=0).  The corrector's take-or-leave decisions amplify rounding differences until device and oracle walk
+    # different paths to the same optimum (they end 6e-8 apart in x here: the distance of either endpoint from the optimum); without
+    # it the device follows the oracle step for step, which is what pins the KERNELS' arithmetic at this size (x to 1e-9, taps to 1e-6).
+    path = os.path.join(HERE, "c3_golden.json")
+    t = time.time()
+    r0 = conic_ipm.solve(c, G, h, l, P["nq3"], P["big"], corrector=False)
+    taps0 = specfact.fmp2(specfact.x_to_r(r0["x"][: 2 * n - 1], n))
+    rec0 = dict(n=n, grid_m=m, status=int(r0["status"]), iters=int(r0["iters"]), pcost=float(r0["pcost"]), gap=float(r0["gap"]), relgap=float(r0["relgap"]),
+                pres=float(r0["pres"]), dres=float(r0["dres"]), seconds=time.time() - t, x=[float(v) for v in r0["x"]],
+                h_re=[float(v) for v in taps0.real], h_im=[float(v) for v in taps0.imag])
+    print({k: v for k, v in rec0.items() if k not in ("x", "h_re", "h_im")}, flush=True)
+    with open(path, "w") as fh:
+        json.dump({"c3_ap_512_16384": rec, "c3_ap_512_16384_no_corrector": rec0}, fh)
 
 
 if __name__ == "__main__":

@@ -110,7 +110,9 @@ def test_h1_dual_band_qp_form_where_double_precision_hits_the_wall():
     f, a, d = mbfir.spec.spec_h1_dualband(n)
     P = assemble.assemble_fir_qp_cvx(n, f, a, d, 120.0, 1e6, m)
     plain = conic_ipm.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"])
-    assert plain["status"] == conic_ipm.STATUS_NUMERICAL and plain["relgap"] > 1.22e-4
+    # (how far the plain solve gets before its numerical exit moves with the BLAS thread count -- relgap 6e-4 or 4e-6 with dres 2e2 --:
+    #  what is asserted is the exit and that not even the reduced-accuracy rule is met)
+    assert plain["status"] == conic_ipm.STATUS_NUMERICAL and (plain["relgap"] > 1.22e-4 or max(plain["pres"], plain["dres"]) > 1e-6)
     # both forms of the extended-precision solve: the double-double factorisation of the whole normal matrix and (round 4) the
     # capacitance form in plain double -- strong directions as nearly-equality constraints, a k x k Schur complement
     sol = {}

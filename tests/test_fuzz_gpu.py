@@ -101,3 +101,16 @@ def test_random_lock_step_units_equal_their_single_solves(mode):
     assert r.returncode == 0, r.stderr[-2000:]
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("lock-step fuzz")]
     assert last and " 240 jobs, 0 mismatches" in last[-1], r.stdout[-1500:]
+
+
+def test_batches_reproduce_themselves_run_to_run():
+    """tools/gpu_determinism.py inside the suite: the bench's batch (64 headline designs, units of 16 on 4
+    streams), BASELINE config 3 in lock-step units and a heterogeneous batch, each solved three times -- every repetition must
+    reproduce the first bit for bit (verdicts, iterations, objective, taps): nothing in a solve may depend on the order in which
+    workgroups or streams happen to run."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_determinism.py"), "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "repetitions:" in ln]
+    assert len(lines) == 3 and all(ln.rstrip().endswith(" 0 results differ from the first run") for ln in lines), r.stdout[-1500:]

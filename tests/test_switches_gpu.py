@@ -47,6 +47,29 @@ def relinf(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
 
 
+# Two forms of one solve whose sums run in another ORDER (folded / unfolded lattice kernels, one-pass / two-pass preconditioner, chunk
+# grouping) differ by rounding, and since round 6 the iteration no longer damps such differences: the centrality corrector's
+# take-or-leave decisions amplify them (~2-3 x per iteration), so the two forms may need a different number of iterations.  What
+# makes them comparable all the same is the end game (oracle/conic_ipm.py POLISH): both end well inside the stopping tolerances -- the
+# conic solution agrees to 1e-6 whatever the path (1e-9 ... 1e-7 measured on these cases).  The TAPS of fir_ap_cvx are that solution seen through the spectral
+# factorisation (log of a spectrum that touches 1e-20: fir_ap_cvx.m:281,296), which amplifies by 1e1 ... 1e9 depending on the
+# instance (the n = 40 case below: 7e8, measured in the oracle), so the taps are held at 1e-6 where the instance allows it.
+ITER_SLACK = 4
+
+
+def same_optimum(h0, i0, h1, i1, z0=None, z1=None, tap_tol=1e-6):
+    assert abs(i0["iters"] - i1["iters"]) <= ITER_SLACK, (i0["iters"], i1["iters"])
+    assert abs(i0["pcost"] - i1["pcost"]) <= 1e-9 * max(1.0, abs(i0["pcost"]))
+    if z0 is not None:
+        assert relinf(z1, z0) <= 1e-6
+    if tap_tol is not None:
+        assert relinf(h1, h0) <= tap_tol
+
+
+def solution_of(info):
+    return mbfir.get_context().last_solution(info["n_unknowns"])
+
+
 CASES = [
     ("fir_ap_cvx", (33, F6, A6, D3, 0.1, 1e-2), {}),                                   # symmetric grid: every point has a partner
     ("fir_ap_cvx", (40, F6, A6, D3, 0.1, 1e-2), dict(grid_m=1201)),                    # odd grid: w = 0 pairs with itself
@@ -61,12 +84,12 @@ def test_folded_lattice_kernels_equal_the_unfolded_ones(which, args, okw):
     opts = mbfir.make_opts(**okw) if okw else None
     with env(MBFIR_FOLD=0):
         h0, s0, i0 = fn(*args, info=True, opts=opts)
+        z0 = solution_of(i0)
     with env(MBFIR_FOLD=1):
         h1, s1, i1 = fn(*args, info=True, opts=opts)
+        z1 = solution_of(i1)
     assert s0 == s1 == "Solved" and i0["lattice"] == i1["lattice"] == 1
-    assert abs(i0["iters"] - i1["iters"]) <= 1
-    assert abs(i0["pcost"] - i1["pcost"]) <= 1e-9 * max(1.0, abs(i0["pcost"]))
-    assert relinf(h1, h0) <= 1e-7
+    same_optimum(h0, i0, h1, i1, z0, z1, tap_tol=None if okw.get("grid_m") == 1201 else 1e-6)      # (n = 40 on 1201 points: taps ill-conditioned, see above)
 
 
 def _batch(**envkw):
@@ -100,7 +123,7 @@ def test_single_chunk_blocks_agree_to_rounding():
     base = _batch()
     other = _batch(MBFIR_CGRP=1)
     for (h0, _, i0), (h1, _, i1) in zip(base, other):
-        assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+        same_optimum(h0, i0, h1, i1)
 
 
 def test_one_pass_preconditioner_application_agrees_with_the_two_triangular_products():
@@ -110,14 +133,16 @@ def test_one_pass_preconditioner_application_agrees_with_the_two_triangular_prod
     base = _batch()
     other = _batch(MBFIR_HSOLVE=0)
     for (h0, _, i0), (h1, _, i1) in zip(base, other):
-        assert abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+        same_optimum(h0, i0, h1, i1)
     for which, args, okw in CASES[:2]:
         fn = getattr(mbfir, which)
         opts = mbfir.make_opts(**okw) if okw else None
         with env(MBFIR_HSOLVE=0):
             h0, s0, i0 = fn(*args, info=True, opts=opts)
+            z0 = solution_of(i0)
         h1, s1, i1 = fn(*args, info=True, opts=opts)
-        assert s0 == s1 == "Solved" and abs(i0["iters"] - i1["iters"]) <= 1 and relinf(h1, h0) <= 1e-7
+        assert s0 == s1 == "Solved"
+        same_optimum(h0, i0, h1, i1, z0, solution_of(i1), tap_tol=None if okw.get("grid_m") == 1201 else 1e-6)
 
 
 def test_dense_path_runs_lock_step_batches_too():
@@ -301,3 +326,42 @@ def test_extended_precision_units_against_one_design_per_stream():
     assert any(i["dd_iters"] > 0 for _, _, i in out["1"])
     for (h1, s1, i1), (h0, s0, i0) in zip(out["1"], out["0"]):
         assert s1 == s0 and i1["iters"] == i0["iters"] and i1["dd_iters"] == i0["dd_iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
+
+
+@pytest.mark.parametrize("which,args,okw", CASES[:3])
+def test_centrality_corrector_is_the_oracles_twin_on_and_off(which, args, okw):
+    """MBFIR_CORRECTOR=0 is round 5's iteration (no corrector solve); either way the device follows the oracle run with the same
+    setting -- iteration count, number of corrected directions taken, taps -- and both settings end at the same optimum (the end
+    game makes the answer independent of the path: oracle/conic_ipm.py POLISH)."""
+    from oracle import designers
+    out = {}
+    for corr in (1, 0):
+        with env(MBFIR_CORRECTOR=corr):
+            h, st, i = getattr(mbfir, which)(*args, info=True, opts=mbfir.make_opts(**okw))
+        ho, so, io = getattr(designers, which)(*args, info=True, corrector=bool(corr), **okw)
+        assert st == so == "Solved"
+        # (short runs: the device's path IS the oracle's -- same iterations, same take-or-leave decisions)
+        assert i["iters"] == io["iters"] and i["correctors"] == io["correctors"] and i["correctors_taken"] == io["correctors_taken"], (corr, i["iters"], io["iters"])
+        z = solution_of(i)
+        assert relinf(z, io["x"]) <= 1e-9
+        if okw.get("grid_m") != 1201:
+            assert relinf(h, ho) <= 1e-6
+        out[corr] = (h, i, z)
+    assert out[1][1]["correctors"] == out[1][1]["iters"] and out[0][1]["correctors"] == 0
+    assert out[1][1]["iters"] < out[0][1]["iters"]                       # (what it is for)
+    same_optimum(out[0][0], dict(out[0][1], iters=0), out[1][0], dict(out[1][1], iters=0), out[0][2], out[1][2], tap_tol=None if okw.get("grid_m") == 1201 else 1e-6)
+    assert out[1][1]["gv_passes"] > 0 and out[1][1]["gtv_passes"] > out[1][1]["gv_passes"]
+
+
+def test_centrality_corrector_in_a_lock_step_batch_every_lane_picks_for_itself():
+    """Lanes take or leave the corrected direction independently (S_PICK per lane): a unit equals the single solves bit for bit."""
+    jobs = [("fir_ap_cvx", (33, F6, A6, [0.01 * (1 + 0.2 * q), 0.02, 0.01], 0.1, 1e-2 * (1 + q))) for q in range(6)]
+    res = mbfir.solve_batch(jobs, streams=1, info=True, opts=mbfir.make_opts(lanes=6))
+    assert res[0][2]["lanes"] == 6
+    taken = set()
+    for job, (h, st, i) in zip(jobs, res):
+        h1, s1, i1 = mbfir.fir_ap_cvx(*job[1], info=True)
+        assert s1 == st == "Solved" and i1["iters"] == i["iters"] and i1["correctors_taken"] == i["correctors_taken"] and i1["pcost"] == i["pcost"]
+        assert np.array_equal(h, h1)
+        taken.add(i["correctors_taken"])
+    assert len(taken) >= 2                                               # (the lanes did decide differently)

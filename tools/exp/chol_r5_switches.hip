@@ -107,11 +107,28 @@ __device__ __forceinline__ void stb_sc1(rsrc_t r, unsigned voff, unsigned soff, 
     v.x = unsigned(__double2loint(x)); v.y = unsigned(__double2hiint(x));
     __builtin_amdgcn_raw_buffer_store_b64(v, r, int(voff), int(soff), 16);
 }
-// ---- hand-offs of the single-launch factorisation (k_chol_dag) ------------------------------------------------------------------
-// write-through stores (aux 16 = sc1) and agent-scope counters.  An XCD-local form (every lane owned by one XCD, plain stores kept in
-// its L2, L2 atomics) was built and measured in round 5: bit-identical and slower (16 lanes alone 562 -> 610 us); it lives on in
-// tools/exp/chol_r5_switches.hip (-DCHOL_XCD_LOCAL=1), not here.
-constexpr int DAG_AUX = 16;
+// ---- hand-offs of the single-launch factorisation (k_chol_dag), XCD-LOCAL form (round 5) -----------------------------------
+// MI355X has eight XCDs with an L2 each; the L2s are not coherent with one another, which is why the hand-offs above write
+// through to memory (sc1 stores drop the line from the writer's L2) and every consumer's load misses its L2 and goes out to the
+// fabric -- the factorisation's 480 tasks per lane are a chain of such round trips (measured: with the tile products' MFMA loops
+// compiled out the build takes 57 % of its time).  But inside ONE XCD the L2 IS the point of coherence: if every task of a lane
+// runs on the same XCD, a plain store (write-through L1, line KEPT in the L2) is visible to every CU of that XCD as soon as it is
+// acknowledged, the consumer's sc1 load (past its L1) hits the L2, and the dependency counters can be L2 atomics.  So k_chol_dag
+// gives every lane an OWNER XCD -- the XCD of the first workgroup that asks, claimed by an agent-scope compare-and-swap -- and a
+// workgroup only ever draws tickets of lanes its own XCD owns (it reads HW_REG_XCC_ID; nothing is assumed about the dispatcher's
+// placement, which HIP does not promise: under the observed round-robin placement workgroup (lane, task) simply finds its own lane
+// owned by its XCD).  Correctness rests on "one XCD, one L2" alone; completeness (every ticket drawn) is checked by k_chol_check.
+// MEASURED AND NOT ADOPTED (round 5, tools/exp/r5_xcd.sh; the switch stays for the record, default 0 = the write-through form):
+// bit-identical on every size and lane count tried (0 words differ, alone and with four staggered units in flight; the placement
+// probe tools/exp/xcc_probe.hip shows the round-robin deal, so every workgroup found its own column's lane), and SLOWER: 16 lanes
+// alone 562 -> 610 us, four units in flight 32.0 -> 36.3 us per design and build, two lanes of np = 4096 on two XCDs 3.3 -> 13.3 ms.
+// The tasks' phase stamps do not move (operands landed 7.4 -> 7.6 us per inverse-row task, drain 0.83 -> 0.84): what a task waits
+// for after its polls is not the fabric round trip of an L2 miss, and confining a lane to the 64 slots of one XCD costs more
+// than L2-served hand-offs return.
+#ifndef CHOL_XCD_LOCAL
+#define CHOL_XCD_LOCAL 0
+#endif
+constexpr int DAG_AUX = CHOL_XCD_LOCAL ? 0 : 16;          // buffer-store cache policy of the hand-off stores: plain | sc1
 __device__ __forceinline__ void dag_st2(rsrc_t r, unsigned byte_off, double2 x) {
     v4u v;
     v.x = unsigned(__double2loint(x.x)); v.y = unsigned(__double2hiint(x.x));
@@ -124,10 +141,21 @@ __device__ __forceinline__ void dag_stb(rsrc_t r, unsigned voff, unsigned soff, 
     __builtin_amdgcn_raw_buffer_store_b64(v, r, int(voff), int(soff), DAG_AUX);
 }
 __device__ __forceinline__ void dag_st(double* p, double v) {
+#if CHOL_XCD_LOCAL
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
-__device__ __forceinline__ int dag_add(int* word, int n) { return __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void dag_set(int* word, int v) { __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the dependency counters: adds and flag stores in the owner XCD's L2 (workgroup scope: no sc1) -- the polls stay sc1 loads, which
+// pass the poller's L1 and read that L2
+#if CHOL_XCD_LOCAL
+#define DAG_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#else
+#define DAG_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ __forceinline__ int dag_add(int* word, int n) { return __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, DAG_SCOPE); }
+__device__ __forceinline__ void dag_set(int* word, int v) { __hip_atomic_store(word, v, __ATOMIC_RELAXED, DAG_SCOPE); }
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -483,16 +511,24 @@ __device__ int g_chol_spin_limit = CHOL_SPIN_LIMIT_DEFAULT;
 __device__ int g_chol_lose_step = -1;
 #define CHOL_SPIN_LIMIT g_chol_spin_limit
 
-// (vmcnt counts stores on the gfx9 family only -- gfx10 and later count them in vscnt: this file is gfx942 / gfx950 code)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
-#error "drain_stores(): s_waitcnt vmcnt(0) drains stores on gfx942 / gfx950 only"
-#endif
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // the thread index as a value of its own per task: the compiler then cannot merge the address arithmetic of different task kinds
 // and hoist it to the top of the single-launch kernel, where it would have to live -- or spill -- through every task's branch
 __device__ __forceinline__ int task_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
-// pause between two polls (a back-off that grows with the wait was measured in round 5: no gain)
-__device__ __forceinline__ void poll_pause(int) { __builtin_amdgcn_s_sleep(4); }
+// pause between two polls: short at first (a hand-off on the chain is noticed quickly), longer when the wait drags on --
+// hundreds of resident workgroups polling a handful of cache lines every 0.1 us slow down the very atomics they wait for
+#ifndef CHOL_BACKOFF
+#define CHOL_BACKOFF 0
+#endif
+__device__ __forceinline__ void poll_pause(int spins) {
+#if CHOL_BACKOFF
+    if (spins < 8) __builtin_amdgcn_s_sleep(4);
+    else if (spins < 32) __builtin_amdgcn_s_sleep(16);
+    else __builtin_amdgcn_s_sleep(64);
+#else
+    __builtin_amdgcn_s_sleep(4);
+#endif
+}
 
 // ONE lane polls ONE word (relaxed, agent scope: an sc1 load) until it reaches `want`; false + sentinel on expiry
 #ifdef CHOL_DAG_STATS
@@ -552,15 +588,18 @@ __device__ __forceinline__ void dag_signal_add(int* word) {
 //                  nblk = 32 the inverse rows accumulate their updates themselves -- minv_strip)   (0 .. i - j - 1)
 //   img[k]         1 once the image of L_kk and 1 / diag(L_kk) are in Dfac / dinvG;   ticket: the lane's task counter
 struct DagCnt {
-    int *rowdone, *tver, *msdone, *ruver, *img, *ticket;
+    int *rowdone, *tver, *msdone, *ruver, *img, *ticket, *done, *owner;
     int nblk;
     __device__ DagCnt(int* base, int nb) : nblk(nb) {
         rowdone = base; tver = base + nb * nb; msdone = base + 2 * nb * nb; ruver = base + 3 * nb * nb; img = base + 4 * nb * nb;
         ticket = img + nb;
+        done = ticket + 1;                                // tasks of the lane that have finished (k_chol_check)
+        owner = ticket + 64;                              // 1 + the XCD that owns the lane in this launch (0: nobody yet); a cache line of its own:
+                                                          // the one word here that XCDs contend for (agent-scope compare-and-swap)
     }
     __device__ int* at(int* arr, int a, int b) const { return arr + a * nblk + b; }
 };
-__host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4; }
+__host__ __device__ inline int dag_cnt_ints(int nblk) { return 4 * nblk * nblk + nblk + 4 + 96; }
 __host__ __device__ inline bool dag_ruform(int nblk) { return nblk > 32; }     // see dag_step
 
 template <bool FROM_IMAGE, bool DAG = false>
@@ -909,6 +948,9 @@ __global__ __launch_bounds__(256) void k_chol_step(CholStep a) {
 // and drain are serial phases of 1-2 us each, and the chip's 512 slots were full (425 busy on average) -- the
 // factorisation was bound by slot-time, not by its chain.  So a task now walks a STRIP of up to four tiles that share
 // an operand, with the next tile's loads in flight behind the current product and ONE drain + signal at the end.
+#ifndef CHOL_DAG_MS_EARLY
+#define CHOL_DAG_MS_EARLY 1      /* ticket order inside a step: 0: D | LA | T | MS | RU | R ; 1: D | LA | MS | T | RU | R */
+#endif
 #ifndef CHOL_STRIP
 #define CHOL_STRIP 4
 #endif
@@ -1089,6 +1131,113 @@ __device__ __forceinline__ void row_tile_block(const CholStep& a, int irow, int 
     drain_stores();
     __syncthreads();
     if (tid == 0) dag_add(dc.at(dc.rowdone, k, irow), 4);
+    PH(6)
+}
+
+// Row blocks of the tiles (i, k) and (i + 1, k), all 128 rows, as ONE task (round 5; the single-tile form above remains for an odd
+// last tile): L_k,k-1 goes through LDS once and the image of L_kk is loaded once for both tiles; a wave owns the rows
+// 16 w .. 16 w + 15 of both tiles and all 64 columns, its rows of L_i,k-1 and L_i+1,k-1 in registers in the matrix cores' operand
+// layout (see trail_left2).  Same arithmetic per row as row_tile_block / panel_block<true>.
+__device__ __forceinline__ void row_tile_block2(const CholStep& a, int irow, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
+    const int k = a.k, np = a.np;
+    const long kk = (long)k * CB, r0 = (long)irow * CB;
+    double(*X)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);     // L_k,k-1, later the staging tile Y
+    double* Y = smem + R0;
+    double* Lz = smem + R1;
+    double* dinv = smem + R3 + CB;
+    const DagCnt dc(a.cnt, a.nblk);
+    wait_many(5, [&](int t, const int*& w, int& want) {
+        if (t < 2) { w = k >= 2 ? dc.at(dc.tver, irow + t, k) : nullptr; want = k - 1; }
+        else if (t == 2) { w = k >= 1 ? dc.at(dc.rowdone, k - 1, k) : nullptr; want = 4; }
+        else { w = k >= 1 ? dc.at(dc.rowdone, k - 1, irow + t - 3) : nullptr; want = 4; }
+    }, a.flag);
+    PH(1)
+    const rsrc_t rA = make_rsrc(a.H + r0 * np);
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8), voX = unsigned(((16 * wv + g4) * np + m16) * 8);
+    const unsigned row1 = unsigned(CB * np * 8);
+    v4d x0[4], x1[4];                                     // the tiles themselves (accumulator layout): the accumulators of the panel k-1 update
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x0[b][r] = ldb_sc1(rA, voX + 128 * b, unsigned((4 * r * np + kk) * 8));
+            x1[b][r] = ldb_sc1(rA, voX + 128 * b, row1 + unsigned((4 * r * np + kk) * 8));
+        }
+    if (k > 0) {
+        const long km = kk - CB;
+        double a0[16], a1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = ldb_sc1(rA, voA + 32 * q, unsigned(km * 8)); a1[q] = ldb_sc1(rA, voA + 32 * q, row1 + unsigned(km * 8)); }
+        load_block<true>(X, a.H + kk * np + km, np);
+        __syncthreads();
+        PH(2)
+        double bf[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[0][b] = X[16 * b + m16][g4];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q + 1 < 16) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = X[16 * b + m16][4 * (q + 1) + g4];
+            }
+            const double na0 = -a0[q], na1 = -a1[q];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
+                x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
+            }
+        }
+    }
+    PH(3)
+    if (tid == 0) wait_flag(dc.img + k, 1, a.flag);
+    __syncthreads();                                      // also: everybody is done with X
+    PH(1)
+    {                                                     // the image of L_kk
+        const rsrc_t ri = make_rsrc(a.Dfac + kk * CB);
+        double2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = 2 * (tid + 256 * u);
+            *reinterpret_cast<double2*>(&Lz[(e >> 6) * ZLD + (e & 63)]) = t[u];
+        }
+    }
+    if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kk + tid);
+    const int rho = tid >> 4, lam = tid & 15;
+    const unsigned voS = unsigned((rho * np + lam) * 8);  // substitution layout: row 16 q + rho, columns lam + 16 i
+#pragma unroll 1
+    for (int tile = 0; tile < 2; ++tile) {                // (one copy of the passes' code: the second tile moves into x0)
+        if (tile) {
+            __syncthreads();                              // the first tile's passes are done with Y
+#pragma unroll
+            for (int b = 0; b < 4; ++b) x0[b] = x1[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Y[(16 * wv + g4 + 4 * r) * YLD + 16 * b + m16] = x0[b][r];
+        __syncthreads();
+        if (!tile) { PH(2) }
+        const unsigned trow = tile ? row1 : 0u;
+#pragma unroll 1
+        for (int q = 0; q < 4; q += 2) {                  // rows 16 q + rho and 16 (q + 1) + rho: two interleaved substitutions
+            double va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va[i] = Y[(16 * q + rho) * YLD + lam + 16 * i]; vb[i] = Y[(16 * q + 16 + rho) * YLD + lam + 16 * i]; }
+            subst16x2(Lz, dinv, va, vb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dag_stb(rA, voS + 128 * i, trow + unsigned((16 * q * np + kk) * 8), va[i]);
+                dag_stb(rA, voS + 128 * i, trow + unsigned(((16 * q + 16) * np + kk) * 8), vb[i]);
+            }
+        }
+    }
+    PH(5)
+    drain_stores();
+    __syncthreads();
+    if (tid < 2) dag_add(dc.at(dc.rowdone, k, irow + tid), 4);
     PH(6)
 }
 
@@ -1408,6 +1557,179 @@ __device__ __forceinline__ void minv_strip(const CholStep& a, int j, double* sme
     PH(6)
 }
 
+// (-DCHOL_MS_PAIR=1 only: measured and not adopted, see the switch)
+// Inverse rows r and r + 1, tile j <= r, as ONE task (round 5; nblk <= 32): both rows accumulate their updates by the rows
+// p = j .. r-1 of the inverse against the SAME operand M_pj, which goes through LDS once for the two of them (a wave owns the rows
+// 16 w .. 16 w + 15 of both tiles and all 64 columns, its rows of L_rp, L_r+1,p in registers in the matrix cores' operand layout
+// with the rolling prefetch of trail_left2); row r is then finished (two 32-column passes of two interleaved substitutions against
+// the image of L_rr), its tile -- still in the staging array of the pass -- is the operand of row r + 1's last update
+// (L_r+1,r M_rj: no hand-off through memory between the two rows of the inverse), and row r + 1 is finished the same way.
+// Half the inverse's tasks, polls and operand traffic, half the links of the inverse's row-after-row chain.  Per element the
+// same MFMA chains in the same order as minv_strip / minv_block: bit-identical.
+__device__ __forceinline__ void minv_pair(const CholStep& a, int r, int j, double* smem) {
+    const int tid = task_tid(), lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4, np = a.np;
+    const long kr = (long)r * CB;
+    double* M = a.M;
+    double(*Q)[CLD] = reinterpret_cast<double(*)[CLD]>(smem + R0);         // M_pj ([k][column]); later the image of L_rr, L_r+1,r+1
+    double* Lz = smem + R0;
+    double* Ct = smem + R1;                                                // staging [column][row], stride YLD, 32 columns
+    double* dinv = smem + R3;
+    const DagCnt dc(a.cnt, a.nblk);
+    const int npan = r - j;
+    {
+        // (the image of L_r+1,r+1 is this step's diagonal block's: polled when row r + 1 is finished, below; the rows r - 2 and
+        //  r - 1 of the inverse are the pair task's before this one in the row-after-row chain of the inverse: polled when the
+        //  accumulation gets to them -- every earlier panel is done by then -- not up front)
+        const int nw = 2 + 3 * npan;
+        for (int w0 = 0; w0 < nw; w0 += 64)
+            wait_many(min(64, nw - w0), [&](int t, const int*& w, int& want) {
+                const int q = w0 + t;
+                if (q == 0) { w = dc.img + r; want = 1; }
+                else if (q == 1) { w = dc.at(dc.rowdone, r, r + 1); want = 4; }
+                else {
+                    const int pq = j + (q - 2) / 3, kind = (q - 2) % 3;
+                    w = kind == 2 ? (pq >= r - 2 ? nullptr : dc.at(dc.msdone, pq, j)) : dc.at(dc.rowdone, pq, r + kind);
+                    want = 4;
+                }
+            }, a.flag);
+    }
+    PH(1)
+    const rsrc_t rL = make_rsrc(a.H + kr * np);                            // tile rows r (and r + 1) of L
+    const unsigned voA = unsigned(((16 * wv + m16) * np + g4) * 8), row1 = unsigned(CB * np * 8);
+    v4d x0[4], x1[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x0[b][q] = (j == r && 16 * wv + g4 + 4 * q == 16 * b + m16) ? 1.0 : 0.0;      // R_rr starts as the identity
+            x1[b][q] = 0.0;
+        }
+    double a0[16], a1[16];
+    if (npan > 0) {
+        double2 bt[8];
+        auto fetchB = [&](int p) {
+            const rsrc_t rb = make_rsrc(M + (long)p * CB * np + (long)j * CB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; bt[u] = ld2_sc1(rb, unsigned(((e >> 5) * np + 2 * (e & 31)) * 8)); }
+        };
+        bool chained = false;                                              // the rows r - 2, r - 1 of the inverse have been polled
+        auto chain_poll = [&]() {
+            if (tid == 0) wait_flags(r - 2 >= j ? dc.at(dc.msdone, r - 2, j) : nullptr, 4, dc.at(dc.msdone, r - 1, j), 4, nullptr, 0, a.flag);
+            __syncthreads();
+            chained = true;
+            PH(1)
+        };
+        if (j >= r - 2) chain_poll();
+        fetchB(j);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = ldb_sc1(rL, voA + 32 * q, unsigned(j * CB * 8)); a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + unsigned(j * CB * 8)); }
+#pragma unroll 1
+        for (int p = j; p < r; ++p) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = tid + 256 * u; *reinterpret_cast<double2*>(&Q[e >> 5][2 * (e & 31)]) = bt[u]; }
+            __syncthreads();
+            PH(2)
+            const bool more = p + 1 < r;
+            if (!chained && p + 1 >= r - 2) chain_poll();
+            fetchB(more ? p + 1 : p);                                      // (see trail_left2)
+            const unsigned pn0 = unsigned((more ? p + 1 : p) * CB * 8), pn1 = unsigned((p + 1) * CB * 8);      // row r + 1 goes on to L_r+1,r
+            double bf[2][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[0][b] = Q[g4][16 * b + m16];
+#pragma unroll
+            for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+                if (q + 1 < 16) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) bf[(q + 1) & 1][b] = Q[4 * (q + 1) + g4][16 * b + m16];
+                }
+                const double na0 = -a0[q], na1 = -a1[q];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    x0[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na0, bf[q & 1][b], x0[b], 0, 0, 0);
+                    x1[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, bf[q & 1][b], x1[b], 0, 0, 0);
+                }
+                a0[q] = ldb_sc1(rL, voA + 32 * q, pn0);
+                a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + pn1);
+            }
+            PH(3)
+            __syncthreads();                                               // everybody is done reading Q
+            PH(4)
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a0[q] = 0.0; a1[q] = ldb_sc1(rL, voA + 32 * q, row1 + unsigned(r * CB * 8)); }
+    }
+    // ---- row r: L_rr M_rj = R_rj, 32 columns per pass; each pass's columns then update row r + 1 (a1 = L_r+1,r)
+    const int rho = tid >> 4, lam = tid & 15;
+#pragma unroll 1
+    for (int row = 0; row < 2; ++row) {
+        if (row) {
+            if (tid == 0) wait_flag(dc.img + r + 1, 1, a.flag);
+            __syncthreads();
+            PH(1)
+        }
+        {
+            const rsrc_t ri = make_rsrc(a.Dfac + (kr + row * CB) * CB);
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = ld2_sc1(ri, unsigned(2 * (tid + 256 * u) * 8));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                *reinterpret_cast<double2*>(Lz + (e >> 5) * ZLD + 2 * (e & 31)) = t[u];
+            }
+        }
+        if (tid < CB) dinv[tid] = ld_sc1(a.dinvG + kr + row * CB + tid);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ct[(16 * h + m16) * YLD + 16 * wv + g4 + 4 * q] = pass ? x0[2 + h][q] : x0[h][q];
+            __syncthreads();                                               // Ct (and, first pass, the image) in place
+            PH(2)
+            double va[4], vb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va[i] = Ct[rho * YLD + lam + 16 * i]; vb[i] = Ct[(16 + rho) * YLD + lam + 16 * i]; }
+            subst16x2(Lz, dinv, va, vb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Ct[rho * YLD + lam + 16 * i] = va[i]; Ct[(16 + rho) * YLD + lam + 16 * i] = vb[i]; }
+            __syncthreads();
+            {
+                const int t = tid >> 2, c8 = (tid & 3) * 8;               // row t of the tile, columns 32 pass + c8 .. + 7
+                const rsrc_t rm = make_rsrc(M + (kr + row * CB) * np + (long)j * CB + 32 * pass);
+#pragma unroll
+                for (int u = 0; u < 8; u += 2)
+                    dag_st2(rm, unsigned((t * np + c8 + u) * 8), make_double2(Ct[(c8 + u) * YLD + t], Ct[(c8 + u + 1) * YLD + t]));
+            }
+            if (a.Mt) {                                                    // the transpose for the second triangular GEMV (np > 1024)
+                const int cr = tid >> 3, t8 = (tid & 7) * 8;
+                double* dt = a.Mt + ((long)j * CB + 32 * pass + cr) * np + kr + row * CB + t8;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dt[u] = Ct[cr * YLD + t8 + u];
+            }
+            if (row == 0) {                                                // R_r+1,j (these 32 columns) -= L_r+1,r M_rj
+                v4d y0 = pass ? x1[2] : x1[0], y1 = pass ? x1[3] : x1[1];
+#pragma unroll
+                for (int q = 0; q < CHOL_KSTEPS(16); ++q) {
+                    const int kx = 4 * q + g4;
+                    const double na1 = -a1[q];
+                    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, Ct[m16 * YLD + kx], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(na1, Ct[(16 + m16) * YLD + kx], y1, 0, 0, 0);
+                }
+                if (pass) { x1[2] = y0; x1[3] = y1; } else { x1[0] = y0; x1[1] = y1; }
+            }
+            __syncthreads();                                               // everybody is done with Ct (and, last pass, with the image)
+            PH(5)
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x0[b] = x1[b];                         // second trip: row r + 1
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid < 2) dag_add(dc.at(dc.msdone, r + tid, j), 4);
+    PH(6)
+}
 
 // =================================================================================================
 // The whole factorisation (and inverse) in ONE launch: every block of the seventeen k_chol_step launches above becomes
@@ -1440,6 +1762,15 @@ __host__ __device__ inline int strips_of(int tiles) { return (tiles + STRIP - 1)
 #ifndef CHOL_TCHUNK
 #define CHOL_TCHUNK 8
 #endif
+#ifndef CHOL_MS_PAIR
+#define CHOL_MS_PAIR 0 /* two inverse rows per task (minv_pair).  Measured in round 5 (tools/exp/chol_dag_exp.hip, np = 1024): bit-identical,
+                          72 tasks of 64 us instead of 136 of 37 (-10 % of the inverse's workgroup-time) -- and SLOWER: 16 lanes alone 570 ->
+                          658 us, four units in flight 31.1 -> 32.4 us per design and build; the inverse's row-after-row chain gets the
+                          longer links.  Kept for the record, off */
+#endif
+#ifndef CHOL_R2
+#define CHOL_R2 0      /* two row tiles per row-block task (row_tile_block2): needs more registers than two workgroups per CU leave */
+#endif
 constexpr int TCHUNK = CHOL_TCHUNK;
 __host__ __device__ inline bool dag_leftT(int nblk) { return nblk <= 32; }
 // sum over c = 1 .. m of ceil(c / 2): the two-row tasks of columns with 1 .. m tiles
@@ -1467,9 +1798,15 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
         const int m = nrem - 1, q = m / STRIP, r = m % STRIP;      // sum over c = 1 .. nrem - 1 of ceil(c / STRIP), in closed form
         s.nT = STRIP * q * (q + 1) / 2 + r * (q + 1);
     }
-    // inverse rows (two rows per task -- minv_pair, tools/exp/chol_r5_switches.hip -DCHOL_MS_PAIR=1 -- was measured in round 5 and
-    // is slower: the row-after-row chain of the inverse gets links twice as long)
+    // inverse rows.  nblk <= 32: the rows k - 1 and k together in the odd steps k < nblk (minv_pair: k tasks for the tiles j <= k - 1 of
+    // both rows -- they accumulate while the diagonal block of step k, whose image row k waits for, is being eliminated -- and one
+    // for the diagonal tile of row k), the last row of an odd nblk alone in step nblk.  nblk > 32:
+#if CHOL_MS_PAIR
+    s.nMS = dag_ruform(nblk) ? (k >= 1 ? k : 0)
+          : ((k & 1) && k < nblk) ? k + 1 : (k == nblk && (nblk & 1)) ? k : 0;
+#else
     s.nMS = k >= 1 ? k : 0;
+#endif
                                                           // the k tiles of inverse row k - 1, one task each (its updates by the
                                                           // panels before, then two 32-column passes): row r of the inverse waits
                                                           // for row r - 1, so more tiles per task would be a longer chain (measured:
@@ -1479,7 +1816,11 @@ __host__ __device__ inline DagStep dag_step(int nblk, int k) {
     s.nRU1 = (ru && k >= 2 && k < nblk) ? k - 1 : 0;      // inverse updates of row i = k (the next inverse row waits for them): single tiles
     s.nRU = (ru && k >= 2 && k < nblk) ? (nblk - k - 1) * s.ruc : 0;        // rows i > k: strips
     s.nRq = (k < nblk && nrem >= 1) ? 4 : 0;              // tile (k + 1, k) as four 16-row blocks (on the chain)
+#if CHOL_R2
+    s.nRt = (k < nblk && nrem >= 2) ? (nrem - 1 + 1) / 2 : 0;      // the other tiles of panel k, two per task (row_tile_block2)
+#else
     s.nRt = (k < nblk && nrem >= 2) ? nrem - 1 : 0;       // the other tiles of panel k, one block each
+#endif
     return s;
 }
 __host__ __device__ inline int dag_step_tasks(const DagStep& s) { return s.nD + s.nLA + s.nT + s.nTc + s.nMS + s.nRU1 + s.nRU + s.nRq + s.nRt; }
@@ -1498,6 +1839,9 @@ __device__ int g_dag_log_tasks;        // tasks per lane
 #define DAG_STAT_END(kind)
 #endif
 
+#ifndef CHOL_PROBE_LDS_PAD
+#define CHOL_PROBE_LDS_PAD 0     /* experiment (tools/exp): extra doubles of LDS per workgroup, to lower the workgroups per CU */
+#endif
 // one task: `a` is the lane's own (pointers shifted), tk its ticket, incl the running task totals of the steps (lane q of the wave:
 // steps 0 .. q; see k_chol_dag)
 __device__ __forceinline__ void dag_task(CholStep a, const int lane, const int tk, const int incl, double* smem, int& s_ticket) {
@@ -1528,15 +1872,24 @@ __device__ __forceinline__ void dag_task(CholStep a, const int lane, const int t
         return;
     }
     t -= st.nLA;
+#if CHOL_DAG_MS_EARLY
     // inverse row k - 1 right behind the tiles on the chain: its inputs are all from earlier steps, so these tasks hardly wait -- and
     // they give the row blocks of panel k - 1 (the last tickets of the step before) time to finish before the trailing tiles that
     // need them poll
     if (t < st.nMS) {
+#if CHOL_MS_PAIR
+        if (!dag_ruform(a.nblk) && k < a.nblk) {
+            if (t < k) minv_pair(a, k - 1, t, smem);      // rows k - 1 and k, tile t
+            else { a.k = k + 1; minv_strip(a, k, smem); a.k = k; }      // the diagonal tile of row k
+        } else minv_strip(a, t, smem);                    // (the last row of an odd nblk; nblk > 32: row k - 1)
+#else
         minv_strip(a, t, smem);                           // row k - 1, tile t
+#endif
         DAG_STAT_END(2)
         return;
     }
     t -= st.nMS;
+#endif
     if (dag_leftT(a.nblk)) {
         if (t < st.nT + st.nTc) {
             // left-looking trailing tiles: column k + 2 gets its last chunk of panels (.. k - 1), and in the steps that are
@@ -1577,6 +1930,21 @@ __device__ __forceinline__ void dag_task(CholStep a, const int lane, const int t
         DAG_STAT_END(5)
         return;
     } else t -= st.nT;
+#if !CHOL_DAG_MS_EARLY
+    if (t < st.nMS) {
+#if CHOL_MS_PAIR
+        if (!dag_ruform(a.nblk) && k < a.nblk) {
+            if (t < k) minv_pair(a, k - 1, t, smem);      // rows k - 1 and k, tile t
+            else { a.k = k + 1; minv_strip(a, k, smem); a.k = k; }      // the diagonal tile of row k
+        } else minv_strip(a, t, smem);                    // (the last row of an odd nblk; nblk > 32: row k - 1)
+#else
+        minv_strip(a, t, smem);                           // row k - 1, tile t
+#endif
+        DAG_STAT_END(2)
+        return;
+    }
+    t -= st.nMS;
+#endif
     if (t < st.nRU1 + st.nRU) {
         // (nblk > 32 only)  R_ij -= L_i,k-2 M_k-2,j  (i >= k, j <= k-2); a tile's first update, by panel j = k - 2, WRITES it.
         // Row i = k tile by tile (inverse row k, one step on, waits for it), the rows below in strips.
@@ -1602,7 +1970,12 @@ __device__ __forceinline__ void dag_task(CholStep a, const int lane, const int t
     t -= st.nRq;
     {
         const int pfirst = dag_leftT(a.nblk) ? max(0, k - 2) : max(0, k - 1);      // (left-looking form: the look-ahead update rides here)
+#if CHOL_R2
+        if (k + 2 + 2 * t + 1 < a.nblk && !dag_leftT(a.nblk)) row_tile_block2(a, k + 2 + 2 * t, smem);    // tiles (i, k), (i + 1, k), i >= k + 2
+        else row_tile_block(a, k + 2 + 2 * t, pfirst, smem);
+#else
         row_tile_block(a, k + 2 + t, pfirst, smem);       // tiles (i, k), i >= k + 2
+#endif
     }
     DAG_STAT_END(4)
 }
@@ -1610,11 +1983,15 @@ __device__ __forceinline__ void dag_task(CholStep a, const int lane, const int t
 #ifndef CHOL_DAG_WPS
 #define CHOL_DAG_WPS 2
 #endif
-// Grid (lanes, tasks per lane): x runs fastest, so the lanes' workgroups are dealt out alternately.  A workgroup serves ONE ticket of
-// the lane of its column.  (Lane ownership by XCD with sweeper workgroups -- round 5, measured and slower -- is in
-// tools/exp/chol_r5_switches.hip.)
+constexpr int DAG_SWEEP_ROWS = 2;      // the workgroups of the last task rows of the grid go on drawing tickets until their XCD's lanes have none left
+// Grid (lanes rounded up to a multiple of 8, tasks per lane): x runs fastest, so under the observed round-robin placement of
+// consecutive workgroups on the eight XCDs the workgroups of one lane all land on one XCD -- which then owns the lane (see the
+// XCD-local hand-offs at the top of this file).  Nothing depends on that placement for correctness: a workgroup reads its XCD from
+// HW_REG_XCC_ID and only draws tickets of lanes its XCD owns (its own column's lane first, then the others); where the placement
+// leaves an XCD short of workgroups for its lanes' tasks, the sweepers of the last rows finish them, and k_chol_check holds every
+// lane to its task count.
 __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
-    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS];
+    __shared__ __attribute__((aligned(16))) double smem[STEP_LDS + CHOL_PROBE_LDS_PAD];
     __shared__ int s_ticket, s_lane;
     // ticket -> (step, task of the step): lane q of every wave counts the tasks of step q, a wave scan gives the running totals --
     // all of it while the ticket's atomic is in flight (a scalar loop over the steps took 1-2.5 us per task)
@@ -1624,16 +2001,39 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
     for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (sl >= d) incl += u; }
     const int nl = a.nlanes;
     int pref = int(blockIdx.x) < nl ? int(blockIdx.x) : int(blockIdx.x) % nl;
+#if CHOL_XCD_LOCAL
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15) + 1;
+    const bool sweeper = int(blockIdx.y) + DAG_SWEEP_ROWS >= int(gridDim.y);
+#else
     if (int(blockIdx.x) >= nl) return;
-    // one ticket: draw, run the task
+#endif
+    // one ticket: choose the lane, draw, run the task; false when this workgroup's XCD has no ticket left
     auto serve = [&]() -> bool {
         if (threadIdx.x == 0) {
             int got_lane = -1, got_t = 0;
+#if CHOL_XCD_LOCAL
+            for (int q = 0; q < nl && got_lane < 0; ++q) {
+                const int l = pref + q < nl ? pref + q : pref + q - nl;
+                if (a.mask && !a.mask[l]) continue;
+                const DagCnt dl(lane_at(a.cnt, (size_t)l * a.lane_bytes), a.nblk);
+                int o = __hip_atomic_load(dl.owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o == 0) {                                 // nobody's yet: the first XCD to ask owns the lane for this launch
+                    int expect = 0;
+                    o = __hip_atomic_compare_exchange_strong(dl.owner, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? xcc : expect;
+                }
+                if (o != xcc) continue;
+                const int t = dag_add(dl.ticket, 1);
+                if (t < a.ntasks) { got_lane = l; got_t = t; }
+            }
+#else
             // the ticket is drawn whether or not the lane is switched off (a switched-off lane's counter is nobody's: k_chol_init
             // clears it when the lane runs again)
             const DagCnt dl(lane_at(a.cnt, (size_t)pref * a.lane_bytes), a.nblk);
             const int t = dag_add(dl.ticket, 1);
             if (!(a.mask && !a.mask[pref]) && t < a.ntasks) { got_lane = pref; got_t = t; }
+#endif
             s_lane = got_lane; s_ticket = got_t;
         }
         __syncthreads();
@@ -1649,12 +2049,29 @@ __global__ __launch_bounds__(256, CHOL_DAG_WPS) void k_chol_dag(CholStep a) {
         }
         dag_task(al, lane, tk, incl, smem, s_ticket);
         __syncthreads();                                  // everybody is done with the task's LDS and with s_lane / s_ticket
+#if CHOL_XCD_LOCAL
+        if (threadIdx.x == 0) dag_add(DagCnt(al.cnt, a.nblk).done, 1);
+#endif
         pref = lane;
         return true;
     };
-    // (one call, not a loop over tickets: inside a loop the compiler hoists every task kind's per-thread address arithmetic in
-    //  front of it and spills what it hoisted -- the persistent-workgroup variant of round 4 measured slower for it)
+    // (the first task outside the sweepers' loop: inside a loop the compiler hoists every task kind's per-thread address arithmetic
+    //  in front of it and spills what it hoisted)
     if (!serve()) return;
+#if CHOL_XCD_LOCAL
+    if (!sweeper) return;
+#pragma unroll 1
+    while (serve()) {}
+#endif
+}
+
+// every live lane has run all its tasks (a lane whose XCD never received a workgroup would otherwise go unnoticed: the ticket scheme
+// guarantees that a drawn ticket is served, not that every ticket is drawn); a shortfall raises CHOL_SYNC_LOST like a lost hand-off
+__global__ void k_chol_check(int* cnt, int nblk, int ntasks, int* flag, size_t lane_bytes, const int* mask, int nlanes) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlanes || (mask && !mask[l])) return;
+    const DagCnt dc(lane_at(cnt, (size_t)l * lane_bytes), nblk);
+    if (*dc.done != ntasks) atomicAdd(lane_at(flag, (size_t)l * lane_bytes), CHOL_SYNC_LOST);
 }
 
 // nsync: ints to clear at sync (the panel flags of the split step, or the counters of the single-launch form);
@@ -1776,8 +2193,10 @@ int chol_inv_launch(double* H, double* M, double* Mt, double* W1, int np, int* f
         for (int k = 0; k <= nblk; ++k) ntasks += dag_step_tasks(dag_step(nblk, k));
         a.k = 0; a.phase = 1; a.nP = a.nMS = a.nT = a.nR = 0;
         a.ntasks = ntasks;
-        // (x runs fastest: the lanes' workgroups are dealt out alternately)
-        hipLaunchKernelGGL(k_chol_dag, dim3(nlanes, ntasks), dim3(256), 0, st, a);
+        // (x runs fastest: the lanes' workgroups are dealt out alternately; x padded to a multiple of 8 so that a column of the grid
+        //  keeps its XCD under round-robin placement -- the surplus columns help the lanes their XCD owns)
+        hipLaunchKernelGGL(k_chol_dag, dim3(CHOL_XCD_LOCAL ? (nlanes + 7) / 8 * 8 : nlanes, ntasks), dim3(256), 0, st, a);
+        if (CHOL_XCD_LOCAL) hipLaunchKernelGGL(k_chol_check, dim3(1), dim3(64), 0, st, a.cnt, nblk, ntasks, flag, lane_bytes, mask, nlanes);
         if (e1) hipEventRecord(e1, st);
         if (Lcopy) hipLaunchKernelGGL(k_extract_L, dim3(cdiv((long)np * np, 256)), dim3(256), 0, st, H, np, a.Dfac, a.dinvG, Lcopy);
         return 1;
