@@ -93,7 +93,10 @@ typedef struct mbfir_info {
     double chol_flop;    /* flop of one factorisation + triangular inverse: 2/3 np^3                      */
     int chol_launches;   /* factorisation launches behind ms_chol: ONE k_chol_dag launch per build for lock-step units and
                             from np = 4096 on (round 3); builds * (np/64 + 1) k_chol_step launches for one or two smaller designs */
-    int builds;          /* normal-matrix builds (= iterations + 1)                                       */
+    int builds;          /* normal-matrix builds (= iterations + 1; + 1 more when the head of the next iteration --
+                            scaling, normal matrix, factorisation -- went to the stream before the host had seen the
+                            final iterate: that last build is never used, its pivot counter never read; ms_gram,
+                            ms_chol and chol_launches count it too)                                               */
     int dd_iters;        /* iterations that ran the extended-precision KKT solve (opts.ddkkt)              */
     int dd_kmax;         /* largest number of strong eigen-directions it carried                          */
     int collectives;     /* all-reduces a row-sharded solve issued (0 otherwise)                                   */

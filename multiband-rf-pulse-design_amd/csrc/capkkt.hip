@@ -30,7 +30,9 @@ struct CapLanes { size_t lane_bytes; const int* mask; const int* kcnt; };
 template <class T>
 __device__ __forceinline__ T* cap_at(T* p, size_t off) { return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + off) : p; }
 __device__ __forceinline__ int cap_k(const CapLanes& L, int lane, int k) {
-    return L.kcnt ? min(*cap_at(L.kcnt, (size_t)lane * L.lane_bytes), 3072) : k;
+    // (clamped to the size the launch carries -- `k` is the unit's largest count, what Yt / Zt / S are laid out for: a lane's count above it
+    //  could index past them; the host's retry loop keeps every count <= CAP_KMAX, this keeps the kernel safe by itself -- ADVICE r5)
+    return L.kcnt ? min(*cap_at(L.kcnt, (size_t)lane * L.lane_bytes), k) : k;
 }
 constexpr int TB = 64, TLD = 66;
 constexpr int CAP_SPLIT = 4;      // parts of a tile's K range (see k_cap_gemm)

@@ -483,11 +483,7 @@ __device__ int g_chol_spin_limit = CHOL_SPIN_LIMIT_DEFAULT;
 __device__ int g_chol_lose_step = -1;
 #define CHOL_SPIN_LIMIT g_chol_spin_limit
 
-// (vmcnt counts stores on the gfx9 family only -- gfx10 and later count them in vscnt: this file is gfx942 / gfx950 code)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
-#error "drain_stores(): s_waitcnt vmcnt(0) drains stores on gfx942 / gfx950 only"
-#endif
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// (drain_stores(): dev_common.h)
 // the thread index as a value of its own per task: the compiler then cannot merge the address arithmetic of different task kinds
 // and hoist it to the top of the single-launch kernel, where it would have to live -- or spill -- through every task's branch
 __device__ __forceinline__ int task_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_dd_trsv_mw(const double* __restrict__ L
         st_dev(Bh + (long)wv * ldv + b0 + lane, y.h);
         st_dev(Bl + (long)wv * ldv + b0 + lane, y.l);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave: its sc1 stores have left the CU ...
+    drain_stores();                                                           // every storing wave: its sc1 stores have left the CU ...
     __syncthreads();                                              // ... before the one lane that signals for all of them does
     if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void k_dd_trsv_bi(const double* __restrict__ L
             st_dev(Bl + (long)v * ldv + b0 + r, y.l);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave: its sc1 stores have left the CU ...
+    drain_stores();                                                           // every storing wave: its sc1 stores have left the CU ...
     __syncthreads();                                              // ... before the one lane that signals for all of them does
     if (tid == 0) __hip_atomic_store(flags + pass * nb + bb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -61,6 +61,16 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     return sh[16];
 }
 
+// Drain of a wave's outstanding stores, in front of the barrier behind which one lane hands data over to ANOTHER workgroup of the same
+// launch (chol.hip k_chol_dag, ddlin.hip k_dd_trsv_mw, solver.hip gt_resid_tail: write-through stores, then a counter / flag).  A
+// workgroup-scope release fence emits no such wait (found as a run-to-run difference in 1 of 720 fuzz jobs in round 5).  vmcnt counts
+// stores on the gfx9 family only -- gfx10 and later count them in vscnt -- so this file refuses to build the wait for anything else
+// (ADVICE r5).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "drain_stores(): s_waitcnt vmcnt(0) drains stores on gfx942 / gfx950 only"
+#endif
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 inline int cdiv(long a, long b) { return int((a + b - 1) / b); }
 inline long round_up(long a, long b) { return ((a + b - 1) / b) * b; }
 

@@ -455,7 +455,7 @@ __device__ __forceinline__ void gt_resid_tail(const DProg& P, const GtResid& F, 
     // (every storing wave drains its write-through stores before the barrier behind which ONE lane moves the counter: a
     //  workgroup-scope release fence does NOT emit the s_waitcnt vmcnt(0) this needs -- found by the lock-step fuzz: 1 of 720
     //  jobs differed in the last bits from run to run until the wait was explicit)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain_stores();
     __syncthreads();
     if (tid == 0) s_last = __hip_atomic_fetch_add(F.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
@@ -1458,6 +1458,11 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
                 //  CORR_ETA times the iterate's own ||rx|| = dres tau ||c|| -- or the absolute floor of the refinement)
                 const double a0 = Sc[S_ALPHA0];
                 const double tolk = fmax(REFTOL * Sc[S_NRMC], CORR_ETA * Sc[S_DRES] * tau * Sc[S_NRMC]);
+                // NOTE (ROCm 7.2 / gfx950): written as `a >= ... && Sc[S_RNC] <= tolk` alone, this select was MISCOMPILED -- the backend emitted
+                // v_cmp_le_f64 vcc, ... ; s_cselect_b32 s12, 0x3ff00000, 0 with no SCC definition in between (s_cselect reads SCC, v_cmp
+                // writes VCC), so S_PICK held a stale condition while S_ALPHA / S_NPICK followed the real one: the update then took the
+                // corrected direction's step along the uncorrected direction.  tools/scan_scc.py finds that shape in the generated
+                // assembly; tests/test_host_cpu.py runs it over every device source of the package.
                 const bool pick = a >= CORR_ACCEPT * a0 && (mode == 4 || Sc[S_RNC] <= tolk);
                 Sc[S_PICK] = pick ? 1.0 : 0.0;
                 Sc[S_NCORR] += 1.0;
@@ -2190,6 +2195,8 @@ struct Solver::Impl {
     double *kbx, *kbz, *kx, *kz, *kg, *kds, *kdz;        // centrality corrector: right-hand side (kbx stays zero), solution / candidate, its direction
     bool corrector = true;       // one centrality corrector per iteration (MBFIR_CORRECTOR=0: off; programs without orthant rows never run it)
     bool corr_plain = true;      // ... its solve is the Cholesky solve alone (MBFIR_CORR_PLAIN=0, a diagnostic: with the refinement sweeps of the other solves)
+    bool corr_guard = true;      // ... and a correction whose unrefined solve leaves more of the dual equation than the iterate's own residual is dropped (MBFIR_CORR_GUARD=0, a diagnostic: taken regardless)
+    int test_cap_kp = 0, ar_chunks = 4;      // MBFIR_TEST_CAP_KP (test hook), MBFIR_AR_CHUNKS (collectives per dense row-sharded build): read ONCE per solve (not in per-iteration paths)
     double *partR, *partR2, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
     // extended-precision KKT solve (ddkkt.inc): H = H_w + U'XU and its Cholesky factor in double-double.
@@ -2557,7 +2564,7 @@ struct Solver::Impl {
                 // y = H_w^-1 rhs_w ; zeta = S^-1 (U y - t) ; dx = y - Zt' zeta   (all double; zeta are the strong directions'
                 // multipliers X (U dx - t) themselves)
                 int kp = int(round_up(k, 64));
-                if (!dd_unit) if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) kp = std::max(kp, std::atoi(ev));     // test hook: pad S as a unit's largest lane would
+                if (!dd_unit) kp = std::max(kp, test_cap_kp);                                    // test hook (MBFIR_TEST_CAP_KP, read at solve start): pad S as a unit's largest lane would
                 cap_add_launch(rhsN, tmpN2, Bl, P.N, P.np, P.LDV, NV, st, nlanes, lane_bytes, P.mask);                       // rhs_w
                 double* yv = tmpN2;                                                              // (free from here on; yN is hsolve's own intermediate)
                 hsolve<NV>(Bl, yv);                                                              // y
@@ -2712,9 +2719,7 @@ struct Solver::Impl {
             // while the later ones are still queued behind it (MBFIR_AR_CHUNKS; 1 = one collective)
             const long nb = P.np / 64, ntile = nb * (nb + 1) / 2;
             hipLaunchKernelGGL(k_pack_tril, dim3((unsigned)ntile), dim3(256), 0, st, H, P.np, M, 0);
-            int chunks = 4;
-            if (const char* ev = std::getenv("MBFIR_AR_CHUNKS")) chunks = std::max(1, std::atoi(ev));
-            chunks = int(std::min<long>(chunks, ntile));
+            const int chunks = int(std::min<long>(ar_chunks, ntile));                    // (MBFIR_AR_CHUNKS, read once at solve start: every rank must issue the same number of collectives)
             for (int c = 0; c < chunks; ++c) {
                 const long lo = ntile * c / chunks, hi = ntile * (c + 1) / chunks;
                 allreduce(M + lo * 4096, (hi - lo) * 4096, 0);
@@ -2743,8 +2748,7 @@ struct Solver::Impl {
         } else if (ddk > 0 && cap_form) {
             // capacitance form: the ordinary double-precision factorisation of H_w, then Yt = U M', Zt = Yt M, S = Yt Yt' + X^-1
             // on the matrix cores and the same factorisation routine on S (kp x kp)
-            int kp = int(round_up(ddk, 64));
-            if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) kp = std::max(kp, std::atoi(ev));
+            const int kp = std::max(int(round_up(ddk, 64)), test_cap_kp);
             chol_launch_count += chol_inv_launch(H, M, fused_hsolve ? nullptr : Mt, W1, P.np, flag, st, nullptr, c0, nullptr, 1, 0, nullptr);
             hipLaunchKernelGGL(k_dd_rows, lane_grid(dim3(kp), nlanes), dim3(256), 0, st, P, D, P.np, ddk);      // (rows ddk .. kp-1: zero padding)
             hipEvent_t b0 = timing ? next_cap_event() : nullptr, b1 = timing ? next_cap_event() : nullptr;
@@ -3052,6 +3056,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_CORRECTOR")) S.corrector = std::atoi(ev) != 0;
     S.corr_plain = true;
     if (const char* ev = std::getenv("MBFIR_CORR_PLAIN")) S.corr_plain = std::atoi(ev) != 0;
+    S.corr_guard = true;
+    if (const char* ev = std::getenv("MBFIR_CORR_GUARD")) S.corr_guard = std::atoi(ev) != 0;
+    S.test_cap_kp = 0;
+    if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) S.test_cap_kp = std::atoi(ev);
+    S.ar_chunks = 4;
+    if (const char* ev = std::getenv("MBFIR_AR_CHUNKS")) S.ar_chunks = std::max(1, std::atoi(ev));
     if (S.shard_size > 1 && nlanes > 1) throw ShapeError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
@@ -3655,7 +3665,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         hipLaunchKernelGGL(k_corr_add, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.dxc, S.dzc, S.gdxc, S.kx, S.kz, S.kg);
         const int ndC = dots(S.kx, S.kz, 3);
         const int nsC = dir_post_c(S.kx, S.kz, S.kg, S.kds, S.kdz, 3, ndC);
-        scal_step(std::getenv("MBFIR_CORR_GUARD") && std::atoi(std::getenv("MBFIR_CORR_GUARD")) == 0 ? 4 : 3, nsC);
+        scal_step(S.corr_guard ? 3 : 4, nsC);
         hipLaunchKernelGGL(k_update_pick, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.kx, S.x, S.ds, S.dz,
                            S.kds, S.kdz, S.s, S.z);
         };

@@ -38,7 +38,11 @@ CORR_BMIN, CORR_BMAX = 0.1, 10.0      # box of the complementarity products, in 
 CORR_ACCEPT = 1.01            # the corrected direction is taken when its step is at least this factor longer
 CORR_ETA = 1.0                # ... and its (unrefined) solve leaves no more than CORR_ETA ||rx|| of the dual equation
 # end game (round 6): an iterate that meets the stopping rule is kept, and the iteration goes on until the gap measures are
-# POLISH times smaller (or POLISH_MAX more iterations): see solve()
+# POLISH times smaller (or POLISH_MAX more iterations): see solve().  Measured on the 58-tap S-C13 case (the oracle on 1 / 2 / 4 / 8
+# BLAS threads, i.e. four roundings of one path): taps 1e-6 apart without an end game, 4e-8 with POLISH = 0.1 (+0.5 iterations),
+# 1e-8 with 0.01 (+1.75).  0.1 was tried in the product: BASELINE config 4's design (j = 0, Peak = 1e-4; n = 200, ~55 iterations) then ends
+# 1.4e-6 from the oracle's taps -- outside north_star's 1e-6 -- and the headline batch gains nothing (49.0 against 49.2 iterations: its
+# end game runs into POLISH_MAX either way); stopping the end game when an iteration gains less than a factor five was tried with it.
 POLISH = 1e-2
 POLISH_MAX = 3
 STATUS_OPTIMAL = 0

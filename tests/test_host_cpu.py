@@ -179,3 +179,29 @@ def test_bench_untimed_legs_run_in_a_child_whose_failure_cannot_cost_the_metric_
     res = bench.other_configs_in_child(0, 2, timeout_s=120)
     assert isinstance(res, dict) and "error" in res and ("child exit code" in res["error"] or "GPU" in res["error"] or "Error" in res["error"])
 
+
+
+def test_generated_assembly_has_no_select_on_an_undefined_scalar_condition(tmp_path):
+    """Round 6 met a backend miscompile (ROCm 7.2, gfx950): a uniform select on a vector compare came out as `v_cmp_* vcc ... ;
+    s_cselect_b32 ...` with nothing defining SCC in between, so a flag the device solver branches its update on held a stale condition
+    (solver.hip k_scal_step; the symptom: a corrected step taken along the uncorrected direction).  tools/scan_scc.py recognises that
+    shape; every device source of the package is compiled to assembly here (hipcc cross-compiles without a GPU) and must be free of it."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "multiband-rf-pulse-design_amd", "csrc")
+    outs = []
+    procs = []
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith(".hip")):
+        out = str(tmp_path / (name[:-4] + ".s"))
+        outs.append(out)
+        procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(csrc, name), "-o", out],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err.decode()[-800:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_scc.py")] + outs, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0 suspicious sites"), r.stdout[-1500:]

@@ -12,6 +12,7 @@ environment switch (read at solve time), and the switched-off form is the refere
   MBFIR_FUSE=0         round 4's separate launches: k_freq_fold in front of the moment kernel, k_resid_norm behind k_gt_finish,
                        k_hsolve_fold + k_cg_start behind the one-pass M'(M b), k_scal_step in front of k_update (round 5 fused them
                        into their neighbours; the sums and their order are unchanged)
+  MBFIR_CORRECTOR=0    round 5's iteration, without the centrality corrector (round 6; the oracle: corrector=False)
 """
 import os
 
