@@ -4,7 +4,7 @@
 #   bash tools/collect_profiles.sh            -> gpurun_out/$ROUND/*  (then: python tools/rocprof_summary.py)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ROUND=${MBFIR_ROUND:-r05}
+ROUND=${MBFIR_ROUND:-r06}
 export MBFIR_ROUND=$ROUND
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("MBFIR_ROUND", "r05")
+ROUND = os.environ.get("MBFIR_ROUND", "r06")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.environ.get("MBFIR_PROFILE_DST", os.path.join(ROOT, "profiles"))
 
