@@ -1,6 +1,6 @@
 """Random specs through the row-sharded solve in loop-back (tests/test_shard_gpu.py's harness: 2 or 3 contexts on one GPU, the
 all-reduce hook sums the ranks' buffers in a fixed order) against the unsharded solve: same verdict, objective to 1e-8, taps to
-1e-6, the ranks' taps bit-identical, iteration counts within 2.    python tools/gpu_fuzz_shard.py lo hi"""
+1e-6, the ranks' taps bit-identical, iteration counts within 4 (20 %).    python tools/gpu_fuzz_shard.py lo hi"""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); warnings.filterwarnings("ignore")
@@ -36,7 +36,9 @@ for seed in range(lo, hi):
                 bad.append((seed, which, size, "taps differ by %.3g from the unsharded solve (iters %d / %d)" % (np.max(np.abs(h - h0)), info["iters"], i0["iters"]))); break
         # (an unsharded solve that ends `numerical` / reduced-accuracy is repeated with the extended-precision KKT solve and
         # reports the iterations of both attempts; a row-sharded one is not: compare the counts only without that retry)
-        if i0["dd_iters"] == 0 and abs(info["iters"] - i0["iters"]) > 2:
+        # (round 6: the corrector's take-or-leave decisions amplify the rounding of the sharded sums: the counts may differ by a few
+        #  iterations, the end points are compared above -- tests/test_switches_gpu.py ITER_SLACK)
+        if i0["dd_iters"] == 0 and abs(info["iters"] - i0["iters"]) > max(4, 0.2 * i0["iters"]):
             bad.append((seed, which, size, "iterations %d vs %d" % (info["iters"], i0["iters"]))); break
     if (seed - lo) % 20 == 19:
         print("seeds %d..%d done, %d failures so far, %.0f s" % (lo, seed, len(bad), time.time() - t0), flush=True)
