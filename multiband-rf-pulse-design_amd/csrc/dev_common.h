@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace mbfir {
 
@@ -85,11 +86,18 @@ struct GramPlan {
     int nw = 1;        // number of weight vectors
     size_t slab_doubles = 0;
 };
-GramPlan gram_plan(int Mf, int Nt, int nw);
+GramPlan gram_plan(int Mf, int Nt, int nw, int nlaunch = 1);   // nlaunch: the product goes in that many launches (gram_chunk_tables), each sized to fill the chip
 // T[w] (ld x ld, full symmetric) = A' diag(d[w]) A ; A is Mpad x ld row-major, d is nw x Mpad.
 // d_stride: doubles between the weight vectors of d (0: gp.Mpad; a lane of a heterogeneous unit keeps the unit's stride)
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
                  const int* tile_ij, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, size_t d_stride = 0);
+// The same product in chunks of tiles, each chunk's tiles folded into a PACKED buffer (tile p of the walk order at Tp + p * 128 * 128, whole
+// tiles): what the dense row-sharded build all-reduces chunk by chunk on a second stream while the next chunk is computed.
+struct GramChunk { int plo = 0, phi = 0, blocks = 0, pair_off = 0; };   // tiles order[plo .. phi), workgroups, offset of its pair table
+void gram_chunk_tables(const GramPlan& gp, int nchunks, std::vector<int>& table, std::vector<GramChunk>& chunks);
+void gram_chunk_launch(const GramPlan& gp, const GramChunk& ck, const double* A, const double* d, double* slab,
+                       const int* tile_ij, const int* chunk_table, double* Tp, hipStream_t st);
+void gram_unpack_launch(const GramPlan& gp, const double* Tp, const int* tile_ij, const int* chunk_table, double* T, hipStream_t st);
 int gram_grid_blocks(const GramPlan& gp);                 // workgroups of one k_gram launch
 int gram_table_ints(const GramPlan& gp);                  // length of the table gram_tiles_host fills
 void gram_tiles_host(const GramPlan& gp, int* tile_ij);   // tile list + the XCD-aware (tile, split) pair of every workgroup

@@ -23,7 +23,7 @@ constexpr int GLDP = 144;
 template <int NW>
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int ld,
                                               const double* __restrict__ d, int Mpad, int chunks,
-                                              const int* __restrict__ tile_ij, int ntiles,
+                                              const int* __restrict__ tile_ij, const int* __restrict__ pair_tab, int ntiles,
                                               double* __restrict__ slab) {
     __shared__ double As[2][GKB][GLDP];
     __shared__ double Bs[2][GKB][GLDP];
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ A, int 
     // (tile, split) of this workgroup from the XCD-aware table behind the tile list (gram_tiles_host): workgroups are
     // dealt round-robin over the 8 XCDs, and the table gives every XCD a compact 2 x 2 cluster of tiles with all their
     // K slices, so the column panels a cluster shares are fetched once per XCD (its L2) instead of once per workgroup
-    const int* pair = tile_ij + 2 * ntiles + 2 * blockIdx.x;
+    // (pair_tab: the table of this launch -- the whole product's, or one chunk's: gram_chunk_tables)
+    const int* pair = pair_tab + 2 * blockIdx.x;
     const int t = pair[0], split = pair[1];
     if (t < 0) return;
     const int ti = tile_ij[2 * t], tj = tile_ij[2 * t + 1];
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     }
 }
 
-GramPlan gram_plan(int Mf, int Nt, int nw) {
+GramPlan gram_plan(int Mf, int Nt, int nw, int nlaunch) {
     GramPlan gp;
     gp.nw = nw;
     gp.ld = int(round_up(Nt, GT));
@@ -164,7 +165,21 @@ GramPlan gram_plan(int Mf, int Nt, int nw) {
     int total_chunks = cdiv(Mf, GKB);
     // two workgroups fit on a CU (74 KB LDS, 196 VGPRs): 512 slots on 256 CUs.  Pick the split so
     // that ntiles * nsplit fills ONE round of slots -- one workgroup too many doubles the run time.
-    int want = 512 / gp.ntiles;
+    // nlaunch > 1: the tile list goes in that many launches (gram_chunk_tables), each of which should fill the slots by itself.
+    const int per_launch = cdiv(gp.ntiles, std::max(1, nlaunch));
+    int want = 512 / per_launch;
+    if (nlaunch > 1 || per_launch > 256) {
+        // More tiles than half the slots (n > 1400 taps), or a chunk of tiles: one round cannot be filled with whole tiles, so take
+        // the split whose workgroups fill their LAST round best (BASELINE config 5, 528 tiles: one slice each = 528 workgroups =
+        // two rounds, the second with 16 of 512 slots busy: 52.4 ms; 7 slices: 3696 = 7.2 rounds: 41 ms).  At least 8 chunks of
+        // 16 frequencies per slice, at most 16 slices (the partial tiles are 128 KB each).
+        double best = -1;
+        for (int ns = 1; ns <= 16 && ns * 8 <= std::max(8, total_chunks); ++ns) {
+            const long blocks = (long)per_launch * ns;
+            const double eff = double(blocks) / double(512L * cdiv(blocks, 512));
+            if (eff > best + 1e-9) { best = eff; want = ns; }
+        }
+    }
     gp.nsplit = std::max(1, std::min(want, total_chunks));
     gp.chunks = cdiv(total_chunks, gp.nsplit);
     gp.nsplit = cdiv(total_chunks, gp.chunks);
@@ -180,28 +195,91 @@ int gram_table_ints(const GramPlan& gp) { return 2 * gp.ntiles + 2 * gram_grid_b
 // Workgroup b runs on XCD b % 8 (observed dispatch; only speed depends on it): XCD c gets the c-th eighth of the pair
 // list, which walks the tiles in 2 x 2 clusters (a cluster's four tiles touch four column panels instead of eight)
 // with all K slices of a tile together.
-void gram_tiles_host(const GramPlan& gp, int* tile_ij) {
-    int t = 0;
-    std::vector<std::vector<int>> index(gp.ntile, std::vector<int>(gp.ntile, -1));
-    for (int i = 0; i < gp.ntile; ++i)
-        for (int j = 0; j <= i; ++j) { tile_ij[2 * t] = i; tile_ij[2 * t + 1] = j; index[i][j] = t; ++t; }
+// the tiles (index in the (i, j <= i) row-major list) in the order the workgroups walk them: 2 x 2 clusters
+static std::vector<int> gram_tile_order(const GramPlan& gp) {
     std::vector<int> order;
     for (int bi = 0; 2 * bi < gp.ntile; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             for (int di = 0; di < 2; ++di)
                 for (int dj = 0; dj < 2; ++dj) {
                     const int i = 2 * bi + di, j = 2 * bj + dj;
-                    if (i < gp.ntile && j <= i) order.push_back(index[i][j]);
+                    if (i < gp.ntile && j <= i) order.push_back(i * (i + 1) / 2 + j);
                 }
-    const int nblocks = gram_grid_blocks(gp), seg = nblocks / 8;
-    int* pair = tile_ij + 2 * gp.ntiles;
+    return order;
+}
+// pair table of the tiles order[lo .. hi): 8 * ceil((hi - lo) nsplit / 8) workgroups, dealt over the XCDs as described above
+static void gram_deal_pairs(const GramPlan& gp, const std::vector<int>& order, int lo, int hi, int* pair) {
+    const int nblocks = 8 * cdiv((long)(hi - lo) * gp.nsplit, 8), seg = nblocks / 8;
     for (int b = 0; b < nblocks; ++b) { pair[2 * b] = -1; pair[2 * b + 1] = 0; }
     long q = 0;
-    for (int tile : order)
+    for (int p = lo; p < hi; ++p)
         for (int s = 0; s < gp.nsplit; ++s, ++q) {
             const int c = int(q / seg), pos = int(q % seg);          // XCD c, its pos-th workgroup
-            pair[2 * (8 * pos + c)] = tile; pair[2 * (8 * pos + c) + 1] = s;
+            pair[2 * (8 * pos + c)] = order[p]; pair[2 * (8 * pos + c) + 1] = s;
         }
+}
+void gram_tiles_host(const GramPlan& gp, int* tile_ij) {
+    int t = 0;
+    for (int i = 0; i < gp.ntile; ++i)
+        for (int j = 0; j <= i; ++j) { tile_ij[2 * t] = i; tile_ij[2 * t + 1] = j; ++t; }
+    gram_deal_pairs(gp, gram_tile_order(gp), 0, gp.ntiles, tile_ij + 2 * gp.ntiles);
+}
+
+// ---- the product in CHUNKS of tiles (dense row-sharded builds: chunk c's all-reduce runs while chunk c + 1 is computed) ------------
+// table = [order: ntiles ints][pair table of chunk 0][pair table of chunk 1] ...; a tile's place in the packed output is its
+// position in `order`, so a chunk's tiles are one contiguous stretch of it
+void gram_chunk_tables(const GramPlan& gp, int nchunks, std::vector<int>& table, std::vector<GramChunk>& chunks) {
+    const std::vector<int> order = gram_tile_order(gp);
+    nchunks = std::max(1, std::min(nchunks, gp.ntiles));
+    table.assign(order.begin(), order.end());
+    chunks.clear();
+    for (int c = 0; c < nchunks; ++c) {
+        GramChunk ck;
+        ck.plo = int((long)gp.ntiles * c / nchunks); ck.phi = int((long)gp.ntiles * (c + 1) / nchunks);
+        ck.blocks = 8 * cdiv((long)(ck.phi - ck.plo) * gp.nsplit, 8);
+        ck.pair_off = int(table.size());
+        table.resize(table.size() + 2 * (size_t)ck.blocks);
+        gram_deal_pairs(gp, order, ck.plo, ck.phi, table.data() + ck.pair_off);
+        chunks.push_back(ck);
+    }
+}
+// fold of the split-K partials of the tiles order[0 .. gridDim.x) into the packed output (whole 128 x 128 tiles, diagonal ones too)
+__global__ __launch_bounds__(256) void k_gram_reduce_packed(const double* __restrict__ slab, int nsplit, int ntiles,
+                                                            const int* __restrict__ order, double* __restrict__ Tp) {
+    const int t = order[blockIdx.x];
+    const int e0 = blockIdx.y * (GT * GT / 16);
+    for (int e = e0 + threadIdx.x; e < e0 + GT * GT / 16; e += 256) {
+        double v = 0;
+        for (int s = 0; s < nsplit; ++s) v += slab[((long)s * ntiles + t) * (GT * GT) + e];
+        Tp[(long)blockIdx.x * (GT * GT) + e] = v;
+    }
+}
+// the full symmetric T from the packed tiles
+__global__ __launch_bounds__(256) void k_gram_unpack(const double* __restrict__ Tp, const int* __restrict__ order,
+                                                     const int* __restrict__ tile_ij, int ld, double* __restrict__ T) {
+    const int t = order[blockIdx.x];
+    const int ti = tile_ij[2 * t], tj = tile_ij[2 * t + 1];
+    const bool diag = ti == tj;
+    const int e0 = blockIdx.y * (GT * GT / 16);
+    for (int e = e0 + threadIdx.x; e < e0 + GT * GT / 16; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        if (diag && j > i) continue;
+        const double v = Tp[(long)blockIdx.x * (GT * GT) + e];
+        const long gi = (long)ti * GT + i, gj = (long)tj * GT + j;
+        T[gi * ld + gj] = v;
+        T[gj * ld + gi] = v;
+    }
+}
+void gram_chunk_launch(const GramPlan& gp, const GramChunk& ck, const double* A, const double* d, double* slab,
+                       const int* tile_ij, const int* chunk_table, double* Tp, hipStream_t st) {
+    if (gp.nw != 1) throw HipError("gram_chunk_launch: one weight vector");
+    hipLaunchKernelGGL(k_gram<1>, dim3(ck.blocks), dim3(256), 0, st, A, gp.ld, d, gp.Mpad, gp.chunks, tile_ij, chunk_table + ck.pair_off,
+                       gp.ntiles, slab);
+    hipLaunchKernelGGL(k_gram_reduce_packed, dim3(ck.phi - ck.plo, 16), dim3(256), 0, st, slab, gp.nsplit, gp.ntiles, chunk_table + ck.plo,
+                       Tp + (size_t)ck.plo * GT * GT);
+}
+void gram_unpack_launch(const GramPlan& gp, const double* Tp, const int* tile_ij, const int* chunk_table, double* T, hipStream_t st) {
+    hipLaunchKernelGGL(k_gram_unpack, dim3(gp.ntiles, 16), dim3(256), 0, st, Tp, chunk_table, tile_ij, gp.ld, T);
 }
 
 void gram_launch(const GramPlan& gp, const double* A, const double* d, double* slab, double* T,
@@ -215,7 +293,7 @@ void gram_launch(const GramPlan& gp, const double* A, const double* d, double* s
     if (ev0) hipEventRecord(ev0, st);
     for (int w = 0; w < gp.nw; ++w)
         hipLaunchKernelGGL(k_gram<1>, grid, dim3(256), 0, st, A, gp.ld, d + (size_t)w * d_stride, gp.Mpad,
-                           gp.chunks, tile_ij, gp.ntiles, slab + w * per_w);
+                           gp.chunks, tile_ij, tile_ij + 2 * gp.ntiles, gp.ntiles, slab + w * per_w);
     if (ev1) hipEventRecord(ev1, st);
     for (int w = 0; w < gp.nw; ++w)
         hipLaunchKernelGGL(k_gram_reduce, dim3(gp.ntiles, 16), dim3(256), 0, st, slab + w * per_w, gp.nsplit,

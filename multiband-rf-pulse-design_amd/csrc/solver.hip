@@ -2146,16 +2146,17 @@ struct Solver::Impl {
     long n_collectives = 0;      // issued by the current solve
     double collective_bytes = 0; // ... and the bytes they carried
     long n_gv = 0, n_gtv = 0;    // passes over the frequency rows of the current solve: G v (apply_G / apply_G_winv2, the residual's row response), G'v (apply_GT)
-    void allreduce(double* buf, long count, int op) {
+    void allreduce(double* buf, long count, int op, hipStream_t on = nullptr) {
         if (shard_size <= 1) return;
+        if (!on) on = st;
         ++n_collectives;
         collective_bytes += 8.0 * double(count);
         if (comm) {
-            ncclResult_t r = rccl().AllReduce(buf, buf, size_t(count), ncclDouble, op == 1 ? ncclMax : ncclSum, comm, st);
+            ncclResult_t r = rccl().AllReduce(buf, buf, size_t(count), ncclDouble, op == 1 ? ncclMax : ncclSum, comm, on);
             if (r != ncclSuccess) throw HipError(std::string("ncclAllReduce: ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "failed"));
             return;
         }
-        MBFIR_HIP(hipStreamSynchronize(st));
+        MBFIR_HIP(hipStreamSynchronize(on));
         if (!ar_fn || ar_fn(buf, count, op, ar_user) != 0) throw HipError("all-reduce hook failed");
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2196,7 +2197,19 @@ struct Solver::Impl {
     bool corrector = true;       // one centrality corrector per iteration (MBFIR_CORRECTOR=0: off; programs without orthant rows never run it)
     bool corr_plain = true;      // ... its solve is the Cholesky solve alone (MBFIR_CORR_PLAIN=0, a diagnostic: with the refinement sweeps of the other solves)
     bool corr_guard = true;      // ... and a correction whose unrefined solve leaves more of the dual equation than the iterate's own residual is dropped (MBFIR_CORR_GUARD=0, a diagnostic: taken regardless)
-    int test_cap_kp = 0, ar_chunks = 4;      // MBFIR_TEST_CAP_KP (test hook), MBFIR_AR_CHUNKS (collectives per dense row-sharded build): read ONCE per solve (not in per-iteration paths)
+    // dense row-sharded builds of a program with ONE weight matrix (fir_ap_cvx, fir_linprog): the Gram product goes in ar_chunks
+    // launches and the all-reduce of chunk c's packed tiles runs on st2 while chunk c + 1 is computed; the small
+    // ingredients (border products, y-y block) follow in one collective and every rank assembles and factorises the same H.
+    // MBFIR_AR_OVERLAP=0: the assembled H is summed instead (packed lower triangle, after the build; the only form for programs
+    // with three weight matrices, whose T is 3 x the size of H); =2 (diagnostic): the chunked form without shards, collectives skipped
+    int ar_overlap_mode = 1;
+    bool ar_overlap = false;
+    std::vector<GramChunk> gchunks;
+    const int* chunk_tab = nullptr;
+    double* Tp = nullptr;
+    hipStream_t st2 = nullptr;
+    std::vector<hipEvent_t> ovev;            // 2 per chunk: chunk folded (st), chunk summed (st2)
+    int test_cap_kp = 0, ar_chunks = 0;      // MBFIR_TEST_CAP_KP (test hook), MBFIR_AR_CHUNKS (collectives per dense row-sharded build): read ONCE per solve (not in per-iteration paths)
     double *partR, *partR2, *partN, *xout, *hout, *sfwork;
     int nbR = 0, nbN = 0, nbC = 0;
     // extended-precision KKT solve (ddkkt.inc): H = H_w + U'XU and its Cholesky factor in double-double.
@@ -2662,7 +2675,24 @@ struct Solver::Impl {
         // (one design: the events bracket the k_gram launches ALONE -- what a kernel trace reports for the kernel north_star
         //  grades; round 3 bracketed the split-K fold and the gaps between the launches too, 0.368 against 0.334 ms in the profile.
         //  Lock-step lanes: around the lanes' products together)
-        if (nlanes == 1) gram_launch(gps[0], A1, Dw, slab, T, tile_ij, st, g0, g1, P.Mpad);
+        if (ar_overlap) {
+            // chunk c: product + fold into the packed tiles on st; its all-reduce on st2 as soon as the fold is done, while st goes on
+            // with chunk c + 1.  (The events bracket all of it: the product is no longer one stretch of k_gram launches.)
+            if (g0) hipEventRecord(g0, st);
+            if (!st2) MBFIR_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            while (ovev.size() < 2 * gchunks.size()) { hipEvent_t e; MBFIR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ovev.push_back(e); }
+            for (size_t c = 0; c < gchunks.size(); ++c) {
+                const GramChunk& ck = gchunks[c];
+                gram_chunk_launch(gps[0], ck, A1, Dw, slab, tile_ij, chunk_tab, Tp, st);
+                if (shard_size > 1) {
+                    MBFIR_HIP(hipEventRecord(ovev[2 * c], st));
+                    MBFIR_HIP(hipStreamWaitEvent(st2, ovev[2 * c], 0));
+                    allreduce(Tp + (size_t)ck.plo * 16384, (long)(ck.phi - ck.plo) * 16384, 0, st2);
+                    MBFIR_HIP(hipEventRecord(ovev[2 * c + 1], st2));
+                }
+            }
+            if (g1) hipEventRecord(g1, st);
+        } else if (nlanes == 1) gram_launch(gps[0], A1, Dw, slab, T, tile_ij, st, g0, g1, P.Mpad);
         else {
         if (g0) hipEventRecord(g0, st);
         for (int b = 0; b < nlanes; ++b) {
@@ -2679,9 +2709,24 @@ struct Solver::Impl {
             atmulti_array(nvv, BB);
             hipLaunchKernelGGL(k_fold_partials, lane_grid(dim3(cdiv(P.ld, 64), nvv), nlanes), dim3(64, 16), 0, st, partial, nsplit_at, nvv, P.ld, P.LDV, TT, lane_bytes, P.mask, P.dims, -AT_ROWS);
         }
-        hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, shard_rank == 0 ? 1.0 : 0.0);
+        if (ar_overlap) {
+            // the small ingredients in one collective (border products, and behind them the 3 x 3 y-y block as in the lattice
+            // mode), issued while the last chunks are still on their way; then wait for the chunks and spread the tiles into T
+            if (P.Ne > 0) {
+                yy_sum = TT + (size_t)P.Ne * P.LDV;
+                hipMemsetAsync(yy_sum, 0, sizeof(double) * 9, st);
+                if (P.nyrows > 0) hipLaunchKernelGGL(k_H_yy, lane_grid(dim3(1), nlanes), dim3(256), 0, st, P, dlw, w3, yy_sum, 3L, 0L, m3c);
+            }
+            if (shard_size > 1) {
+                MBFIR_HIP(hipStreamWaitEvent(st, ovev[2 * gchunks.size() - 1], 0));      // (st2 runs the chunks in order: the last one's event covers them all)
+                if (P.Ne > 0) allreduce(TT, (long)P.Ne * P.LDV + 9, 0);
+            }
+            gram_unpack_launch(gps[0], Tp, tile_ij, chunk_tab, T, st);
         }
-        const bool summed = shard_size > 1 && !lead_factor();     // dense row-sharded path: H is summed over the ranks below
+        hipLaunchKernelGGL(k_assemble_H, lane_grid(dim3(cdiv(P.np, 256), P.np), nlanes), dim3(256), 0, st, P, T, TT, H, (ar_overlap || shard_rank == 0) ? 1.0 : 0.0);
+        }
+        const bool summed = shard_size > 1 && !lead_factor() && !ar_overlap;     // dense row-sharded path: H is summed over the ranks below
+        if (ar_overlap && P.Ne > 0) hipLaunchKernelGGL(k_H_yy_add, lane_grid(dim3(1), nlanes), dim3(16), 0, st, P, yy_sum, H);
         if (lead_factor() && P.Ne > 0) {
             // (summed over the ranks -- with the moments above, or here -- then added by every rank to its own H)
             const double* yy = yy_sum;
@@ -2696,7 +2741,7 @@ struct Solver::Impl {
         {
             // identity rows (all of them replicated rows): every rank adds them to its own H; where H is summed over the ranks
             // afterwards (dense path) the owner alone does, and the y-y block (last block of the grid) weights the replicated rows
-            const int yy_too = (!lead_factor() && P.Ne > 0 && P.nyrows > 0) ? 1 : 0;
+            const int yy_too = (!lead_factor() && !ar_overlap && P.Ne > 0 && P.nyrows > 0) ? 1 : 0;
             hipLaunchKernelGGL(k_H_identity, lane_grid(dim3(cdiv(P.Nt, 256) + yy_too), nlanes), dim3(256), 0, st, P, dlw, w3, H, m3c, yy_too, summed ? 1 : 0);
             if (P.big && (!summed || shard_rank == 0)) {
                 memset_lanes(qv, sizeof(double) * 3 * P.LDV);
@@ -2713,13 +2758,13 @@ struct Solver::Impl {
                 P.mask = live_mask;
             }
         }
-        if (!lead_factor() && shard_size > 1) {
+        if (!lead_factor() && !ar_overlap && shard_size > 1) {
             // dense path: sum the shards' normal matrices -- the packed lower triangle (M, rewritten by the factorisation that
             // follows, is the staging buffer), in AR_CHUNKS collectives so that a ring's pipeline starts on the first tile rows
             // while the later ones are still queued behind it (MBFIR_AR_CHUNKS; 1 = one collective)
             const long nb = P.np / 64, ntile = nb * (nb + 1) / 2;
             hipLaunchKernelGGL(k_pack_tril, dim3((unsigned)ntile), dim3(256), 0, st, H, P.np, M, 0);
-            const int chunks = int(std::min<long>(ar_chunks, ntile));                    // (MBFIR_AR_CHUNKS, read once at solve start: every rank must issue the same number of collectives)
+            const int chunks = int(std::min<long>(ar_chunks > 0 ? ar_chunks : 4, ntile));                    // (MBFIR_AR_CHUNKS, read once at solve start: every rank must issue the same number of collectives)
             for (int c = 0; c < chunks; ++c) {
                 const long lo = ntile * c / chunks, hi = ntile * (c + 1) / chunks;
                 allreduce(M + lo * 4096, (hi - lo) * 4096, 0);
@@ -2823,6 +2868,8 @@ Solver::~Solver() {
     for (hipEvent_t e : impl->capev) hipEventDestroy(e);
     if (impl->ev0) hipEventDestroy(impl->ev0);
     if (impl->ev1) hipEventDestroy(impl->ev1);
+    for (hipEvent_t e : impl->ovev) hipEventDestroy(e);
+    if (impl->st2) hipStreamDestroy(impl->st2);
     if (impl->st) hipStreamDestroy(impl->st);
     delete impl;
 }
@@ -3060,8 +3107,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_CORR_GUARD")) S.corr_guard = std::atoi(ev) != 0;
     S.test_cap_kp = 0;
     if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) S.test_cap_kp = std::atoi(ev);
-    S.ar_chunks = 4;
+    S.ar_chunks = 0;         // 0: the build's own choice
     if (const char* ev = std::getenv("MBFIR_AR_CHUNKS")) S.ar_chunks = std::max(1, std::atoi(ev));
+    S.ar_overlap_mode = 1;
+    if (const char* ev = std::getenv("MBFIR_AR_OVERLAP")) S.ar_overlap_mode = std::atoi(ev);
     if (S.shard_size > 1 && nlanes > 1) throw ShapeError("row-sharded solves run one design at a time");
     std::vector<LaneHost> LH(nlanes);
     for (int b = 0; b < nlanes; ++b) {
@@ -3137,10 +3186,15 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     // ---- sizes -----------------------------------------------------------------------------
     const int R = R_max, Nt = Nt_max, Ne = Q.Ne, N = Nt_max + Q.Ne, Mf = Mf_max;
     const int nw = Q.quad ? 3 : 1;
-    S.gp = gram_plan(Mf, Nt, nw);
+    // (dense row-sharded build with the chunked, overlapped all-reduce: see Impl::ar_overlap_mode)
+    S.ar_overlap = !Lt.ok && nw == 1 && nlanes == 1 && ((S.shard_size > 1 && S.ar_overlap_mode != 0) || S.ar_overlap_mode == 2);
+    // (chunks: MBFIR_AR_CHUNKS, else one per 32 tiles, at most 8 -- below that a chunk's product is too short to hide a collective behind)
+    const int gtiles = gram_plan(Mf, Nt, nw).ntiles;
+    const int gfill = S.ar_overlap ? std::max(1, std::min(S.ar_chunks > 0 ? S.ar_chunks : std::min(8, gtiles / 32), gtiles)) : 1;
+    S.gp = gram_plan(Mf, Nt, nw, gfill);
     S.gps.assign(nlanes, S.gp);
     for (int b = 0; b < nlanes; ++b) {
-        S.gps[b] = gram_plan(LH[b].Q->Mf, Nt, nw);
+        S.gps[b] = gram_plan(LH[b].Q->Mf, Nt, nw, gfill);
         S.gp.Mpad = std::max(S.gp.Mpad, S.gps[b].Mpad); S.gp.slab_doubles = std::max(S.gp.slab_doubles, S.gps[b].slab_doubles);
     }
     DProg& P = S.P;
@@ -3190,6 +3244,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     for (int b = 0; b < nlanes; ++b) S.lane_n[b] = LH[b].Q->n;
     std::vector<std::vector<int>> tiles(nlanes);
     for (int b = 0; b < nlanes; ++b) { tiles[b].resize(gram_table_ints(S.gps[b])); gram_tiles_host(S.gps[b], tiles[b].data()); }
+    S.gchunks.clear();
+    if (S.ar_overlap) {              // the chunk tables ride behind the tile table
+        std::vector<int> ctab;
+        gram_chunk_tables(S.gps[0], gfill, ctab, S.gchunks);
+        tiles[0].insert(tiles[0].end(), ctab.begin(), ctab.end());
+    }
     S.cap_form = o.dd_form == 0;                              // its capacitance form in plain double (capkkt.hip) or the double-double one
     if (const char* ev = std::getenv("MBFIR_DDFORM")) S.cap_form = std::strcmp(ev, "dd") != 0;
     // extended-precision KKT solve (ddkkt.inc); lock-step units: in its capacitance form (round 5; the double-double kernels take one design)
@@ -3235,6 +3295,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     zero_from = ar.base + ar.off;
     S.A1 = ar.get<double>(P.trig ? 0 : Mpad * ld);
     S.T = ar.get<double>(P.trig ? 0 : nw * ld * ld);
+    S.Tp = ar.get<double>(S.ar_overlap ? (size_t)S.gps[0].ntiles * 16384 : 0);
+    S.chunk_tab = S.ar_overlap ? S.tile_ij + gram_table_ints(S.gps[0]) : nullptr;
     {
         const size_t nch = std::max(P.nchunk, 1), d1 = std::max(P.D1, 1);
         P.seed_tau = ar.get<double4>(P.trig ? nch * d1 : 1);

@@ -87,7 +87,20 @@ def test_row_sharded_solve_matches_unsharded(name, size):
         assert all(abs(i["iters"] - i0["iters"]) <= max(4, 0.2 * i0["iters"]) for _, _, i in res), ([i["iters"] for _, _, i in res], i0["iters"])
 
 
-@pytest.mark.parametrize("name", ["ap_c13_64", "qp_modelB25"])
+def _dense_bytes_per_build(fn, info, overlapped):
+    """What one dense row-sharded build puts into collectives (lower bound; the rest of an iteration is vectors and scalars).
+    Programs with one weight matrix (fir_ap_cvx, fir_linprog), round 6: the Gram product's lower-triangular 128 x 128 tiles, chunk
+    by chunk while the next chunk is computed.  Otherwise (and with MBFIR_AR_OVERLAP=0), round 5: the assembled normal matrix as
+    its PACKED lower triangle -- nblk (nblk + 1) / 2 tiles of 64 x 64, not np^2 doubles."""
+    if overlapped:
+        nt = info["n_unknowns"] - {"fir_ap_cvx": 1, "fir_linprog": 0}[fn]
+        nb = -(-nt // 128)
+        return 8.0 * (nb * (nb + 1) // 2) * 128 * 128
+    nb = -(-info["n_unknowns"] // 64)
+    return 8.0 * (nb * (nb + 1) // 2) * 4096
+
+
+@pytest.mark.parametrize("name", ["ap_c13_64", "qp_modelB25", "lin_cplx32"])
 def test_row_sharded_dense_path_all_reduces_the_normal_matrix(name):
     """opts.dense_trig = 1: no moments to share, the shards' Gram matrices are summed and every rank factorises."""
     fn, args = CASES[name]
@@ -98,17 +111,49 @@ def test_row_sharded_dense_path_all_reduces_the_normal_matrix(name):
     for h, s, info in res:
         assert s == s0 == "Solved" and info["lattice"] == 0 and relinf(h, h0) <= 1e-6
         assert np.array_equal(h, res[0][0])
-        # round 5: the normal matrix travels as its PACKED lower triangle -- nblk (nblk + 1) / 2 tiles of 64 x 64 per
-        # build, not np^2 doubles.  Every other collective of a dense iteration is a vector of <= 2 LDV doubles or a few scalars.
         npad = -(-info["n_unknowns"] // 64) * 64
-        nb = npad // 64
-        tri, full = 8.0 * (nb * (nb + 1) // 2) * 4096, 8.0 * npad * npad
+        want = _dense_bytes_per_build(fn, info, overlapped=fn in ("fir_ap_cvx", "fir_linprog"))
         per_build = info["collective_bytes"] / info["builds"]
-        assert tri <= per_build <= tri + 8.0 * 40 * 2 * (npad + 128) and (nb == 1 or tri < full), (per_build, tri, full)
+        assert want <= per_build <= want + 8.0 * 40 * 2 * (npad + 128), (per_build, want)
+        assert info["collective_bytes"] == res[0][2]["collective_bytes"] and info["collectives"] == res[0][2]["collectives"]
     # the frequency rows partition; the rows without a frequency (identity rows, spike cones) are replicated on every rank
     assert sum(i["n_freq"] for _, _, i in res) == i0["n_freq"]
     nrep = res[0][2]["n_rows"] + res[1][2]["n_rows"] - i0["n_rows"]
-    assert 0 < nrep < i0["n_rows"] - 2 * i0["n_freq"] + 8
+    assert (nrep == 0 if fn == "fir_linprog" else 0 < nrep < i0["n_rows"] - 2 * i0["n_freq"] + 8)      # (fir_linprog: every row has a frequency)
+
+
+# 199 trigonometric unknowns = 2 x 2 Gram tiles of 128 (3 in the lower triangle): the smallest size whose product goes in several chunks.
+# (The two-band spec of conftest's ap_twoband33: its taps follow the conic solution at ~1e3; S-C13 at 100 taps amplifies a 1e-10
+#  difference of the two forms' solutions to 5e-5 in the taps -- tools/gpu_overlap_debug.py prints both.)
+AP_2B_100 = ("fir_ap_cvx", (100,) + CASES["ap_twoband33"][1][1:])
+
+
+@pytest.mark.parametrize("name,size", [("ap_2b_100", 2), ("ap_2b_100", 3), ("ap_c13_64", 2), ("lin_cplx32", 3)])
+def test_row_sharded_dense_build_overlapped_and_summed_forms_agree(name, size, monkeypatch):
+    """The two forms of the dense row-sharded build: the Gram tiles all-reduced chunk by chunk on a second stream
+    while the next chunk is computed, every rank assembling the same H from the summed ingredients (default) -- against the
+    assembled H summed after the build (MBFIR_AR_OVERLAP=0).  Sums in another order: same optimum; in both, every rank returns
+    the same bits and has issued the same collectives; the chunk count (MBFIR_AR_CHUNKS) changes the number of collectives, not
+    the bytes."""
+    fn, args = AP_2B_100 if name == "ap_2b_100" else CASES[name]
+    runs = {}
+    for key, envs in (("overlap", {}), ("overlap7", {"MBFIR_AR_CHUNKS": "7"}), ("summed", {"MBFIR_AR_OVERLAP": "0"})):
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        runs[key] = _run_sharded(fn, args, size, dense=1)
+        for k in envs:
+            monkeypatch.delenv(k)
+        for r in runs[key]:
+            assert not isinstance(r, Exception), r
+        for h, s, info in runs[key]:
+            assert s == "Solved" and np.array_equal(h, runs[key][0][0])
+            assert (info["collectives"], info["collective_bytes"]) == (runs[key][0][2]["collectives"], runs[key][0][2]["collective_bytes"])
+    (h0, _, i0), (h7, _, i7), (h1, _, i1) = runs["overlap"][0], runs["overlap7"][0], runs["summed"][0]
+    assert relinf(h1, h0) <= 1e-6 and relinf(h7, h0) <= 1e-6
+    assert abs(i0["pcost"] - i1["pcost"]) <= 1e-9 * max(1.0, abs(i0["pcost"])) and abs(i0["iters"] - i1["iters"]) <= 4
+    if i7["iters"] == i0["iters"] and name == "ap_2b_100":     # (3 tiles: one chunk by default -- a chunk per 32 tiles --, three under MBFIR_AR_CHUNKS=7)
+        assert i7["collective_bytes"] == i0["collective_bytes"] and i7["collectives"] == i0["collectives"] + 2 * i0["builds"]
+    assert np.allclose(i0["_z"], i1["_z"], rtol=0, atol=1e-6 * np.abs(i0["_z"]).max())
 
 
 def test_native_rccl_communicator_single_rank():

@@ -366,3 +366,20 @@ def test_centrality_corrector_in_a_lock_step_batch_every_lane_picks_for_itself()
         assert np.array_equal(h, h1)
         taken.add(i["correctors_taken"])
     assert len(taken) >= 2                                               # (the lanes did decide differently)
+
+
+@pytest.mark.parametrize("which,args,okw", [CASES[0], CASES[2], ("fir_ap_cvx", (100, F6, A6, D3, 0.1, 1e-2), {})])      # (the last: 3 tiles)
+def test_chunked_gram_product_of_the_row_sharded_build_equals_the_one_launch_product(which, args, okw):
+    """MBFIR_AR_OVERLAP=2 runs the dense row-sharded build's form of the Gram product WITHOUT shards: the tiles in MBFIR_AR_CHUNKS
+    launches, folded into the packed buffer the ranks would all-reduce chunk by chunk on the second stream, spread into T
+    afterwards, border products and y-y block added as on the lattice path.  Same sums per tile up to the split of the frequency
+    rows (more slices per tile: each chunk fills the chip by itself) -- the same optimum as the one-launch product."""
+    fn = getattr(mbfir, which)
+    h0, s0, i0 = fn(*args, info=True, opts=mbfir.make_opts(dense_trig=1))
+    z0 = solution_of(i0)
+    for chunks in (1, 3, 4):
+        with env(MBFIR_AR_OVERLAP=2, MBFIR_AR_CHUNKS=chunks):
+            h1, s1, i1 = fn(*args, info=True, opts=mbfir.make_opts(dense_trig=1))
+            z1 = solution_of(i1)
+        assert s0 == s1 == "Solved" and i1["lattice"] == 0
+        same_optimum(h0, i0, h1, i1, z0, z1)
