@@ -116,7 +116,7 @@ constexpr double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEP
 // end game: an iterate that meets the stopping rule is kept and the iteration goes on until the gap measures are POLISH times below
 // the tolerances, at most POLISH_MAX more iterations (oracle/conic_ipm.py POLISH*)
 constexpr double POLISH = 1e-2;
-constexpr int POLISH_MAX = 3;
+constexpr int POLISH_MAX = 3, POLISH_SWEEPS = 2;     // (POLISH_SWEEPS: refinement sweeps on top of the controller's count during the end game)
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding kernels (a 1024-thread block has to wait for a
                               // whole CU when other units share the chip)
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void k_amulti(const double* __restrict__ A1, i
     double acc[NVV];
 #pragma unroll
     for (int v = 0; v < NVV; ++v) acc[v] = 0;
+#pragma unroll 8
     for (int j = 2 * lane; j < ld; j += 128) {
         double2 t = *reinterpret_cast<const double2*>(a + j);
 #pragma unroll
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restri
     double2 acc[NVV];
 #pragma unroll
     for (int v = 0; v < NVV; ++v) acc[v] = make_double2(0, 0);
-#pragma unroll 4
+#pragma unroll 16
     for (int i = r0 + wq; i < r1; i += 4) {
         double2 t = *reinterpret_cast<const double2*>(A1 + (long)i * ld + col0);
 #pragma unroll
@@ -1611,15 +1612,19 @@ __global__ __launch_bounds__(256) void k_update_pick(DProg P, const double* __re
 // S_ALPHA0 its step.  On the orthant rows the products at the trial step  at = min(1, alpha0 + CORR_DELTA),
 //   v = (lam + at W^-1 ds)(lam + at W dz),
 // are projected onto [CORR_BMIN, CORR_BMAX] sigma mu; t = projection - v, bounded below by -CORR_BMAX sigma mu;
-//   bz = -W (lam \ t),  wbz = W^-2 bz;   the cone rows get zeros (their products are left alone).
+//   bz = -W (lam \ t),  wbz = W^-2 bz;   the 3-row cones get zeros (their products are left alone).
+// The big cone (k_big_corr_rhs): the same for the two eigenvalues v0 +- ||v1|| of the Jordan product
+// v = (lam + at W^-1 ds) o (lam + at W dz) (corr_target), except on the extended-precision path.
+__device__ __forceinline__ void corr_target(double e1, double e2, double mut, double& d1, double& d2) {
+    d1 = fmax(fmin(fmax(e1, CORR_BMIN * mut), CORR_BMAX * mut) - e1, -CORR_BMAX * mut);
+    d2 = fmax(fmin(fmax(e2, CORR_BMIN * mut), CORR_BMAX * mut) - e2, -CORR_BMAX * mut);
+}
 __global__ __launch_bounds__(256) void k_corr_rhs(DProg P, const double* __restrict__ wl, const double* __restrict__ dl,
                                                   const double* __restrict__ lam, const double* __restrict__ ds,
                                                   const double* __restrict__ dz, const double* __restrict__ Sc,
                                                   double* __restrict__ bz, double* __restrict__ wbz) {
     LANES(P, wl, dl, lam, ds, dz, Sc, bz, wbz);
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.R) return;
-    double b = 0.0, wb = 0.0;
     if (t < P.l) {
         const double at = fmin(1.0, Sc[S_ALPHA0] + CORR_DELTA), mut = Sc[S_SIGMA] * Sc[S_MU];
         const double l = lam[t], w = wl[t];
@@ -1627,10 +1632,53 @@ __global__ __launch_bounds__(256) void k_corr_rhs(DProg P, const double* __restr
         const double v = (l + at * dss) * (l + at * wdz);
         double tt = fmin(fmax(v, CORR_BMIN * mut), CORR_BMAX * mut) - v;
         tt = fmax(tt, -CORR_BMAX * mut);
-        b = -w * (tt / l);
-        wb = dl[t] * b;
+        const double b = -w * (tt / l);
+        bz[t] = b; wbz[t] = dl[t] * b;
+    } else if (t < P.l + P.nq3) {
+        const int r = P.l + 3 * (t - P.l);
+        for (int a = 0; a < 3; ++a) { bz[r + a] = 0.0; wbz[r + a] = 0.0; }
     }
-    bz[t] = b; wbz[t] = wb;
+}
+// ... the big cone's rows (one workgroup; W^-2 bz of these rows is formed by k_big_winv2 in the solve that follows)
+__global__ __launch_bounds__(1024) void k_big_corr_rhs(DProg P, const double* __restrict__ wbb, const double* __restrict__ lam,
+                                                       const double* __restrict__ ds, const double* __restrict__ dz,
+                                                       const double* __restrict__ Sc, double* __restrict__ bz,
+                                                       double* __restrict__ scratch, int on, const int* __restrict__ dd_mask) {
+    LANES(P, wbb, lam, ds, dz, Sc, bz, scratch);
+    __shared__ double sh[17];
+    const long ob = P.l + 3L * P.nq3;
+    const int big = P.big, n1 = big - 1;
+    if (!on || (dd_mask && dd_mask[blockIdx.z])) {       // extended-precision path: the cone is left alone
+        for (int i = threadIdx.x; i < big; i += blockDim.x) bz[ob + i] = 0.0;
+        return;
+    }
+    const double at = fmin(1.0, Sc[S_ALPHA0] + CORR_DELTA), mut = Sc[S_SIGMA] * Sc[S_MU];
+    const double* L = lam + ob;
+    double* u = scratch;                   // lam + at W^-1 ds
+    double* w = scratch + big;             // lam + at W dz
+    double* v = scratch + 2 * big;         // their Jordan product, then the target t, then W (lam \ t)
+    double* q = scratch + 3 * big;         // lam \ t
+    big_apply(big, wbb, Sc[S_ETAB], ds + ob, u, true, sh);
+    big_apply(big, wbb, Sc[S_ETAB], dz + ob, w, false, sh);
+    for (int i = threadIdx.x; i < big; i += blockDim.x) { u[i] = L[i] + at * u[i]; w[i] = L[i] + at * w[i]; }
+    __syncthreads();
+    const double v0 = big_dot(u, w, big, sh), u0 = u[0], w0 = w[0];
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) v[1 + i] = u0 * w[1 + i] + w0 * u[1 + i];
+    __syncthreads();
+    const double nv = sqrt(big_dot(v + 1, v + 1, n1, sh));
+    double d1, d2;
+    corr_target(v0 + nv, v0 - nv, mut, d1, d2);
+    const double f = 0.5 * (d1 - d2) / (nv > 0 ? nv : 1.0), t0 = 0.5 * (d1 + d2);
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) v[1 + i] *= f;
+    __syncthreads();
+    // q = lam \ t
+    const double l0 = L[0], nl = sqrt(big_dot(L + 1, L + 1, n1, sh)), a = jres(l0, nl), ld = big_dot(L + 1, v + 1, n1, sh);
+    const double q0 = (l0 * t0 - ld) / a;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) q[1 + i] = (v[1 + i] - q0 * L[1 + i]) / l0;
+    if (threadIdx.x == 0) q[0] = q0;
+    __syncthreads();
+    big_apply(big, wbb, Sc[S_ETAB], q, v, false, sh);
+    for (int i = threadIdx.x; i < big; i += blockDim.x) bz[ob + i] = -v[i];
 }
 // candidate = predictor-corrector solution + corrector solution, in place in the corrector's arrays
 __global__ __launch_bounds__(256) void k_corr_add(DProg P, const double* __restrict__ x2, const double* __restrict__ z2,
@@ -3436,7 +3484,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
 
     int it = 0;
     bool dd_now = false;
-    const bool use_corr = S.corrector && P.l > 0;             // (every lane of a unit is the same designer: orthant rows in all of them or in none)
+    // (every lane of a unit is the same designer: orthant rows in all of them or in none.  What is corrected: the orthant rows and,
+    //  on the plain path, the big cone -- oracle/conic_ipm.py)
+    const bool use_corr = S.corrector && P.l > 0;
     // MBFIR_TRACE_HOST=1: where the host thread of this unit spends the solve -- issuing launches, or waiting in the one
     // synchronisation per iteration (a stream whose host thread issues most of the time is launch-bound, not GPU-bound)
     const bool trace_host = std::getenv("MBFIR_TRACE_HOST") != nullptr;
@@ -3553,6 +3603,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                     else need = std::max(need, k);
                 }
                 L.nsweep = unconverged ? std::min(MAX_SWEEPS, L.nsweep + 1) : need;
+                if (L.first_opt >= 0) L.nsweep = std::min(MAX_SWEEPS, L.nsweep + POLISH_SWEEPS);      // end game (oracle/conic_ipm.py POLISH_SWEEPS)
             }
             L.rx_prev = hs[S_DRES] * hs[S_TAU] * hs[S_NRMC];
             info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
@@ -3577,9 +3628,10 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                     S.hostMask[ROW_BEST * MAX_LANES + b] = 1;
                     any_best = true;
                 }
-                if (L.first_opt < 0) L.first_opt = it;
-                if (hs[S_GAP] <= POLISH * o.abstol || hs[S_RELGAP] <= POLISH * o.reltol || it >= L.first_opt + POLISH_MAX) { finish(ST_OPTIMAL); continue; }
+                if (L.first_opt < 0) { L.first_opt = it; L.nsweep = std::min(MAX_SWEEPS, L.nsweep + POLISH_SWEEPS); }
+                if (hs[S_GAP] <= POLISH * o.abstol || hs[S_RELGAP] <= POLISH * o.reltol) { finish(ST_OPTIMAL); continue; }
             }
+            if (L.first_opt >= 0 && it >= L.first_opt + POLISH_MAX) { finish(ST_OPTIMAL); continue; }      // (whether or not this iterate still meets the rule)
             if (!finite) { finish(ST_NUMERICAL); continue; }
             const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
             if (L.first_opt < 0 && (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5))) { finish(ST_PRIMAL_INFEASIBLE); continue; }
@@ -3688,6 +3740,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                                S.scratch);
         solve2(std::integral_constant<int, 1>(), S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
         const int nd1 = dots(S.dxc, S.dzc, 1);
+        // (extended-precision iterations: the corrector works on the orthant rows alone, with the usual passes: oracle/conic_ipm.py)
+        const int corr_cones = (!S.dd_unit && dd_any) ? 0 : 1;                              // one design: this iteration's mode ...
+        const int* corr_ddm = (S.dd_unit && dd_any) ? S.mask_row(ROW_DD) : nullptr;         // ... a unit: lane by lane
         if (!use_corr) {
             const int ns1 = dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
             hipLaunchKernelGGL(k_update, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.Sc, x1, S.dxc, S.x, S.ds, S.dz, S.s, S.z,
@@ -3722,7 +3777,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         };
         const int nsA = dir_post_c(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);
         scal_step(2, nsA);
-        hipLaunchKernelGGL(k_corr_rhs, lane_grid(dim3(cdiv(R, 256)), nlanes), dim3(256), 0, st, P, S.wl, S.dl, S.lam, S.ds, S.dz, S.Sc, S.kbz, S.wbz);
+        hipLaunchKernelGGL(k_corr_rhs, lane_grid(dim3(std::max(S.nbC, 1)), nlanes), dim3(256), 0, st, P, S.wl, S.dl, S.lam, S.ds, S.dz, S.Sc, S.kbz, S.wbz);
+        if (P.big) hipLaunchKernelGGL(k_big_corr_rhs, lane_grid(dim3(1), nlanes), dim3(1024), 0, st, P, S.wbb, S.lam, S.ds, S.dz, S.Sc, S.kbz, S.scratch, corr_cones, corr_ddm);
         solve2(std::integral_constant<int, 1>(), S.kbx, S.kbz, S.kx, S.kz, S.kg, S_RNC, S.corr_plain);     // the Cholesky solve and its residual norm (S_RNC), no sweeps (lanes on the extended-precision path: their usual passes)
         hipLaunchKernelGGL(k_corr_add, lane_grid(dim3(cdiv(std::max(N, R), 256)), nlanes), dim3(256), 0, st, P, S.dxc, S.dzc, S.gdxc, S.kx, S.kz, S.kg);
         const int ndC = dots(S.kx, S.kz, 3);

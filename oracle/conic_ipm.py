@@ -45,6 +45,7 @@ CORR_ETA = 1.0                # ... and its (unrefined) solve leaves no more tha
 # end game runs into POLISH_MAX either way); stopping the end game when an iteration gains less than a factor five was tried with it.
 POLISH = 1e-2
 POLISH_MAX = 3
+POLISH_SWEEPS = 2             # end game: refinement sweeps on top of the controller's count (see solve())
 STATUS_OPTIMAL = 0
 STATUS_PRIMAL_INFEASIBLE = 1
 STATUS_DUAL_INFEASIBLE = 2
@@ -250,6 +251,19 @@ def _soc_div(lam, d):
     out = np.empty_like(d)
     out[:, 0] = (l0 * d[:, 0] - ld) / a
     out[:, 1:] = (d[:, 1:] - out[:, :1] * l1) / l0[:, None]
+    return out
+
+
+def _soc_target(v, mut):
+    """Centrality corrector on second-order cones: t such that the eigenvalues v0 +- ||v1|| of v + t lie in
+    [CORR_BMIN, CORR_BMAX] * mut (each eigenvalue's move bounded below by -CORR_BMAX mut), in the Jordan frame of v."""
+    n1 = np.sqrt(np.sum(v[:, 1:] ** 2, axis=1))
+    e1, e2 = v[:, 0] + n1, v[:, 0] - n1
+    d1 = np.maximum(np.minimum(np.maximum(e1, CORR_BMIN * mut), CORR_BMAX * mut) - e1, -CORR_BMAX * mut)
+    d2 = np.maximum(np.minimum(np.maximum(e2, CORR_BMIN * mut), CORR_BMAX * mut) - e2, -CORR_BMAX * mut)
+    out = np.empty_like(v)
+    out[:, 0] = 0.5 * (d1 + d2)
+    out[:, 1:] = (0.5 * (d1 - d2) / np.where(n1 > 0, n1, 1.0))[:, None] * v[:, 1:]
     return out
 
 
@@ -682,10 +696,18 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             if opt_best[0] is None or merit_o < opt_best[0]:
                 opt_best = (merit_o, x / tau, dict(info), s / tau, z / tau)
             if first_opt is None:
+                # (the end game's solves are the worst conditioned of the whole iteration and the sweep controller answers one
+                #  iteration late: POLISH_SWEEPS more sweeps than it asks for, so that the iterate after the first one that met
+                #  the rule does not fail it by its dual residual -- fuzz seed 55, fir_qprog_phs: dres 5.7e-10 -> 1.7e-8)
                 first_opt = it
-            if gap <= POLISH * abstol or relgap <= POLISH * reltol or it >= first_opt + POLISH_MAX:
+                nsweep[0] = min(MAX_SWEEPS, nsweep[0] + POLISH_SWEEPS)
+            if gap <= POLISH * abstol or relgap <= POLISH * reltol:
                 status = STATUS_OPTIMAL
                 break
+        if first_opt is not None and it >= first_opt + POLISH_MAX:
+            # (also when this iterate no longer meets the rule: the end game has had its iterations)
+            status = STATUS_OPTIMAL
+            break
         if not finite:
             status = STATUS_NUMERICAL
             break
@@ -768,6 +790,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         dx, ds, dz, dtau, dkap, dss, wdz = direction(sigma, dk_c, x2, z2, Gx2)
         alpha = step_of(dss, wdz, dtau, dkap, STEP)
         ncorr_ok = 0
+        # (the big cone's products are corrected along with the orthant rows', on the plain path: see below)
+        corr_big = cone.big > 0 and cone.l > 0 and not isinstance(cf, dict)
         if corrector and cone.l > 0:
             # Centrality corrector (round 6).  The fir_ap_cvx programs keep thousands of rows S(w_i) >= 1e-20 whose products
             # s_i z_i are spread over five decades around mu; the predictor-corrector direction is then cut at alpha = 0.01-0.3
@@ -775,10 +799,19 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             # v = (lam + at dss)(lam + at wdz) are projected onto the box [CORR_BMIN, CORR_BMAX] * sigma mu; the difference
             # (bounded below by -CORR_BMAX sigma mu) is one more complementarity right-hand side for the factorisation at hand:
             # [0 G'; G -W^2][dxk; dzk] = [0; -W (lam \ t)].  The corrected direction is taken when its step is longer by
-            # CORR_ACCEPT.  Second-order-cone rows and the (tau, kappa) pair are left alone.  Measured over eight S-C13
+            # CORR_ACCEPT.  The 3-row cones and the (tau, kappa) pair are left alone.  Measured over eight S-C13
             # instances (n = 80 ... 200): 380 -> 301 iterations (-21 %) for one more Cholesky solve per iteration -- without
             # refinement sweeps: with them the count is 303; with the residual guard below 317 of 392 (both with the end game;
             # DESIGN.md section 5).
+            # The big cone (the quadratic objective's epigraph in fir_qprog_phs) gets the same projection for the two eigenvalues
+            # v0 +- ||v1|| of the Jordan product (lam + at dss) o (lam + at wdz) (_soc_target): fir_qprog_phs 25 -> 19, 28 -> 21
+            # iterations.  Not on the extended-precision path, and not in a program WITHOUT orthant rows (fir_qp_cvx: its
+            # frequency rows are 3-row cones): correcting all its cones saves a quarter of its iterations (H-1 dual band,
+            # n = 256 / 384 / 512: 55 -> 41, 82 -> 59, 79 -> 68) -- measured, built on the device and taken back: the optimum of
+            # E + obj Peak is flat, two paths that part end 1e-5 ... 3e-4 apart in the taps at 1e-10 in the objective, and the
+            # comparisons that hold device, oracle, shards and the two extended-precision forms together at 1e-6 ... 1e-4 rely
+            # on all of them walking ONE path.  fir_ap_cvx's 3-row cones are its n spike constraints
+            # beside 6 n ... 60 n orthant rows: correcting them changes nothing (14 instances: 536 against 533 iterations).
             at = min(1.0, alpha + CORR_DELTA)
             mut = sigma * mu
             ll_ = cone.l
@@ -787,6 +820,11 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             tt = np.maximum(tt, -CORR_BMAX * mut)
             bzk = np.zeros(R)
             bzk[:ll_] = -Wm.wl * (tt / lam[:ll_])
+            if corr_big:
+                ub, wb = (lam + at * dss)[cone.ob:], (lam + at * wdz)[cone.ob:]
+                tc = np.zeros(R)
+                tc[cone.ob:] = _soc_target(_soc_prod(ub[None, :], wb[None, :]), mut)[0]
+                bzk[cone.ob:] = -Wm.apply(_cone_div(cone, lam, tc))[cone.ob:]
             try:
                 rk = kkt_solve(Wm, H, cf, np.zeros(N), bzk, plain=True)
             except FloatingPointError:
@@ -812,6 +850,8 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             # or the absolute floor, whichever is larger.  Same iterates at the end (the floor rules once ||rx|| is
             # small), 30-40 % fewer refinement sweeps over a solve.
             nsweep[0] = next_sweeps(sweep_log, nsweep[0], max(REFTOL * nrm_c, REFETA * float(np.linalg.norm(rx))))
+            if first_opt is not None:
+                nsweep[0] = min(MAX_SWEEPS, nsweep[0] + POLISH_SWEEPS)
         if history is not None:
             sl_, zl_ = s[:cone.l], z[:cone.l]
             _ts, _tz = _max_step(cone, lam, dss), _max_step(cone, lam, wdz)

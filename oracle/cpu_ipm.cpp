@@ -22,7 +22,7 @@ namespace {
 
 typedef std::vector<double> vec;
 const double POLISH = 1e-2;      // conic_ipm.py: the end game
-const int POLISH_MAX = 3;
+const int POLISH_MAX = 3, POLISH_SWEEPS = 2;
 const double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEPT = 1.01, CORR_ETA = 1.0;      // conic_ipm.py: the centrality corrector
 const double STEP = 0.99, SIGMA_MAX = 0.25, REFTOL = 1e-11, REFETA = 1e-1, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
 const int MAX_SWEEPS = 8, WALL_ITERS = 3, NB = 64;
@@ -496,9 +496,10 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
                 const double oi[6] = {pcost, dcost, gap, relgap, pres, dres};
                 std::memcpy(opt_info, oi, sizeof(oi));
             }
-            if (first_opt < 0) first_opt = it;
-            if (gap <= POLISH * abstol || relgap <= POLISH * reltol || it >= first_opt + POLISH_MAX) { status = ST_OPTIMAL; break; }
+            if (first_opt < 0) { first_opt = it; nsweep = std::min(MAX_SWEEPS, nsweep + POLISH_SWEEPS); }      // (conic_ipm.py: POLISH_SWEEPS)
+            if (gap <= POLISH * abstol || relgap <= POLISH * reltol) { status = ST_OPTIMAL; break; }
         }
+        if (first_opt >= 0 && it >= first_opt + POLISH_MAX) { status = ST_OPTIMAL; break; }      // (whether or not this iterate still meets the rule)
         if (!finite) { status = ST_NUMERICAL; break; }
         const bool collapsed = kappa / tau >= 1e6;
         if (first_opt < 0 && (pinf <= feastol || (collapsed && pinf <= 1e-5))) { status = ST_PINF; break; }
@@ -564,9 +565,10 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         direction(sigma, dk_c, x2.data(), z2.data(), g2.data(), ds.data(), dz.data(), dss.data(), wdz.data());
         double alpha = step_of(dss.data(), wdz.data(), STEP);
         if (K.l > 0) {
-            // one centrality corrector on the orthant rows (conic_ipm.py: CORR_*): trial step alpha + CORR_DELTA, the rows'
-            // products projected onto [CORR_BMIN, CORR_BMAX] sigma mu, one more solve with the factorisation at hand, the
-            // corrected direction taken when its step is CORR_ACCEPT times longer
+            // one centrality corrector (conic_ipm.py: CORR_*): trial step alpha + CORR_DELTA, the complementarity products
+            // projected onto [CORR_BMIN, CORR_BMAX] sigma mu -- the orthant rows' products and the two eigenvalues of the big
+            // cone's Jordan product --, one more solve with the factorisation at hand, the corrected direction taken when its
+            // step is CORR_ACCEPT times longer
             const double at = std::min(1.0, alpha + CORR_DELTA), mut = sigma * mu, dtau0 = dtau, dkap0 = dkap;
             for (int i = 0; i < R; ++i) bzk[i] = 0.0;
             for (int i = 0; i < K.l; ++i) {
@@ -574,6 +576,28 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
                 double tt = std::min(std::max(v, CORR_BMIN * mut), CORR_BMAX * mut) - v;
                 tt = std::max(tt, -CORR_BMAX * mut);
                 bzk[i] = -W.wl[i] * (tt / lam[i]);
+            }
+            if (K.big > 0) {
+                // t in the Jordan frame of v = (lam + at dss) o (lam + at wdz), then bz = -W (lam \ t)      (ll, pr, dsc: scratch)
+                const int off = K.ob, d = K.big;
+                for (int i = 0; i < R; ++i) dsc[i] = 0.0;
+                double* u = &ll[off];
+                double* w = &pr[off];
+                for (int i = 0; i < d; ++i) { u[i] = lam[off + i] + at * dss[off + i]; w[i] = lam[off + i] + at * wdz[off + i]; }
+                double* v = &dsc[off];
+                soc_prod(u, w, v, d);
+                double n1 = 0;
+                for (int i = 1; i < d; ++i) n1 += v[i] * v[i];
+                n1 = std::sqrt(n1);
+                const double e1 = v[0] + n1, e2 = v[0] - n1;
+                const double d1 = std::max(std::min(std::max(e1, CORR_BMIN * mut), CORR_BMAX * mut) - e1, -CORR_BMAX * mut);
+                const double d2 = std::max(std::min(std::max(e2, CORR_BMIN * mut), CORR_BMAX * mut) - e2, -CORR_BMAX * mut);
+                const double f = 0.5 * (d1 - d2) / (n1 > 0 ? n1 : 1.0);
+                v[0] = 0.5 * (d1 + d2);
+                for (int i = 1; i < d; ++i) v[i] = f * v[i];
+                cone_div(K, lam.data(), dsc.data(), pr.data());
+                W.apply(pr.data(), ll.data(), false);
+                for (int i = K.ob; i < R; ++i) bzk[i] = -ll[i];
             }
             kkt_solve(zero_n.data(), bzk.data(), xk.data(), zk.data(), gk.data(), true);
             for (int j = 0; j < N; ++j) xk[j] += x2[j];
@@ -586,6 +610,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
             } else { dtau = dtau0; dkap = dkap0; }
         }
         nsweep = next_sweeps(std::max(REFTOL * nrm_c, REFETA * nrm2(rx.data(), N)));   // forcing term, see conic_ipm.py
+        if (first_opt >= 0) nsweep = std::min(MAX_SWEEPS, nsweep + POLISH_SWEEPS);
         for (int j = 0; j < N; ++j) x[j] += alpha * (x2[j] + dtau * x1[j]);
         for (int i = 0; i < R; ++i) { s[i] += alpha * ds[i]; z[i] += alpha * dz[i]; }
         tau += alpha * dtau; kappa += alpha * dkap;
