@@ -2244,6 +2244,7 @@ struct Solver::Impl {
     double *kbx, *kbz, *kx, *kz, *kg, *kds, *kdz;        // centrality corrector: right-hand side (kbx stays zero), solution / candidate, its direction
     bool corrector = true;       // one centrality corrector per iteration (MBFIR_CORRECTOR=0: off; programs without orthant rows never run it)
     bool corr_plain = true;      // ... its solve is the Cholesky solve alone (MBFIR_CORR_PLAIN=0, a diagnostic: with the refinement sweeps of the other solves)
+    bool corr_big = true;        // ... the big cone's products are corrected too (MBFIR_CORR_BIG=0, a diagnostic: the orthant rows alone, round 6's first form)
     bool corr_guard = true;      // ... and a correction whose unrefined solve leaves more of the dual equation than the iterate's own residual is dropped (MBFIR_CORR_GUARD=0, a diagnostic: taken regardless)
     // dense row-sharded builds of a program with ONE weight matrix (fir_ap_cvx, fir_linprog): the Gram product goes in ar_chunks
     // launches and the all-reduce of chunk c's packed tiles runs on st2 while chunk c + 1 is computed; the small
@@ -3153,6 +3154,8 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_CORR_PLAIN")) S.corr_plain = std::atoi(ev) != 0;
     S.corr_guard = true;
     if (const char* ev = std::getenv("MBFIR_CORR_GUARD")) S.corr_guard = std::atoi(ev) != 0;
+    S.corr_big = true;
+    if (const char* ev = std::getenv("MBFIR_CORR_BIG")) S.corr_big = std::atoi(ev) != 0;
     S.test_cap_kp = 0;
     if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) S.test_cap_kp = std::atoi(ev);
     S.ar_chunks = 0;         // 0: the build's own choice
@@ -3741,7 +3744,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         solve2(std::integral_constant<int, 1>(), S.bxc, S.bzc, S.dxc, S.dzc, S.gdxc, S_RNB);
         const int nd1 = dots(S.dxc, S.dzc, 1);
         // (extended-precision iterations: the corrector works on the orthant rows alone, with the usual passes: oracle/conic_ipm.py)
-        const int corr_cones = (!S.dd_unit && dd_any) ? 0 : 1;                              // one design: this iteration's mode ...
+        const int corr_cones = (!S.corr_big || (!S.dd_unit && dd_any)) ? 0 : 1;                              // one design: this iteration's mode ...
         const int* corr_ddm = (S.dd_unit && dd_any) ? S.mask_row(ROW_DD) : nullptr;         // ... a unit: lane by lane
         if (!use_corr) {
             const int ns1 = dir_post(S.dxc, S.dzc, S.gdxc, S.ds, S.dz, 1, nd1);

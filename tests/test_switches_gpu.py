@@ -329,7 +329,7 @@ def test_extended_precision_units_against_one_design_per_stream():
         assert s1 == s0 and i1["iters"] == i0["iters"] and i1["dd_iters"] == i0["dd_iters"] and i1["pcost"] == i0["pcost"] and np.array_equal(h1, h0)
 
 
-@pytest.mark.parametrize("which,args,okw", CASES[:3])
+@pytest.mark.parametrize("which,args,okw", CASES)        # (the last one, fir_qprog_phs: orthant rows AND the big cone are corrected)
 def test_centrality_corrector_is_the_oracles_twin_on_and_off(which, args, okw):
     """MBFIR_CORRECTOR=0 is round 5's iteration (no corrector solve); either way the device follows the oracle run with the same
     setting -- iteration count, number of corrected directions taken, taps -- and both settings end at the same optimum (the end
@@ -342,9 +342,11 @@ def test_centrality_corrector_is_the_oracles_twin_on_and_off(which, args, okw):
         ho, so, io = getattr(designers, which)(*args, info=True, corrector=bool(corr), **okw)
         assert st == so == "Solved"
         # (short runs: the device's path IS the oracle's -- same iterations, same take-or-leave decisions)
-        assert i["iters"] == io["iters"] and i["correctors"] == io["correctors"] and i["correctors_taken"] == io["correctors_taken"], (corr, i["iters"], io["iters"])
+        # (fir_qprog_phs: one of the 21 decisions is a tie the two arithmetics break differently -- a step longer by 1.01 or not)
+        assert i["iters"] == io["iters"] and i["correctors"] == io["correctors"], (corr, i["iters"], io["iters"])
+        assert abs(i["correctors_taken"] - io["correctors_taken"]) <= (1 if which == "fir_qprog_phs" else 0), (corr, i["correctors_taken"], io["correctors_taken"])
         z = solution_of(i)
-        assert relinf(z, io["x"]) <= 1e-9
+        assert relinf(z, io["x"]) <= (1e-7 if which == "fir_qprog_phs" else 1e-9)      # (a quadratic objective: the solution moves with the square root of the gap)
         if okw.get("grid_m") != 1201:
             assert relinf(h, ho) <= 1e-6
         out[corr] = (h, i, z)
@@ -366,6 +368,29 @@ def test_centrality_corrector_in_a_lock_step_batch_every_lane_picks_for_itself()
         assert np.array_equal(h, h1)
         taken.add(i["correctors_taken"])
     assert len(taken) >= 2                                               # (the lanes did decide differently)
+
+
+def test_centrality_corrector_on_the_big_cone_of_fir_qprog_phs():
+    """fir_qprog_phs keeps its quadratic objective as one big second-order cone beside the orthant rows; the corrector projects the
+    two eigenvalues of that cone's scaled product like the rows' products (k_big_corr_rhs; oracle _soc_target).  MBFIR_CORR_BIG=0
+    is round 6's first form (orthant rows alone): more iterations, the same optimum.  And a lock-step unit of such designs equals
+    the single solves bit for bit."""
+    which, args, okw = CASES[3]
+    h1, s1, i1 = mbfir.fir_qprog_phs(*args, info=True)
+    z1 = solution_of(i1)
+    with env(MBFIR_CORR_BIG=0):
+        h0, s0, i0 = mbfir.fir_qprog_phs(*args, info=True)
+        z0 = solution_of(i0)
+    assert s0 == s1 == "Solved" and i1["iters"] < i0["iters"] and i1["correctors_taken"] > i0["correctors_taken"]
+    same_optimum(h0, dict(i0, iters=0), h1, dict(i1, iters=0), z0, z1)
+    n, f, a, d = args
+    jobs = [("fir_qprog_phs", (n, f, a, [d[0] * (1 + 0.15 * q), d[1] * (1 + 0.1 * q)])) for q in range(5)]
+    res = mbfir.solve_batch(jobs, streams=1, info=True, opts=mbfir.make_opts(lanes=5))
+    assert res[0][2]["lanes"] == 5
+    for job, (h, st, i) in zip(jobs, res):
+        hs, ss, is_ = mbfir.fir_qprog_phs(*job[1], info=True)
+        assert ss == st == "Solved" and is_["iters"] == i["iters"] and is_["correctors_taken"] == i["correctors_taken"] and is_["pcost"] == i["pcost"]
+        assert np.array_equal(h, hs)
 
 
 @pytest.mark.parametrize("which,args,okw", [CASES[0], CASES[2], ("fir_ap_cvx", (100, F6, A6, D3, 0.1, 1e-2), {})])      # (the last: 3 tiles)
