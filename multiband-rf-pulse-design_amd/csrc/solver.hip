@@ -333,13 +333,14 @@ __global__ void k_rows_G(DProg P, const double* __restrict__ UU, const double* _
 
 // K3: G'v.  Two launches:
 //  k_atmulti<NVV, AGG>: partial[split][v][j] = sum_{i in split} A1[i][j] PP[v][i].  Block = 64 x 4
-//     threads: 4 waves share 128 columns and interleave the 256 rows of the split; with AGG the
+//     threads: 4 waves share 128 columns and interleave the AT_ROWS rows of the split (128: 1040 workgroups at the headline
+//     size, 22.7 us per pass; 256 rows -- two workgroups per CU in ONE round -- took 32.7 us, 64 rows 24.2); with AGG the
 //     per-frequency operands p1[i] = sum_{rows at i} alpha_r val_r, p2[i] = sum beta_r val_r are
 //     formed in LDS first from the CSR map (each of the ld/128 column blocks redoes that cheap walk),
 //     otherwise they are read from the array PP (border products of the H assembly).
 //  k_gt_finish<NV>: folds the split partials (fixed order), applies the quadrature permutation,
 //     adds the identity rows and the y block.
-constexpr int AT_ROWS = 256;
+constexpr int AT_ROWS = 128;
 template <int NVV, bool AGG>
 __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restrict__ A1, const double* __restrict__ src,
                                                  double* __restrict__ partial) {
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_atmulti(DProg P, const double* __restri
     const int col0 = blockIdx.x * 128 + 2 * lane, split = blockIdx.y;
     const int ld = P.ld, Mpad = P.Mpad;
     const int r0 = split * AT_ROWS, r1 = min(r0 + AT_ROWS, Mpad);
-    {
+    if (tid < AT_ROWS) {
         const int i = r0 + tid;                        // one frequency row per thread
         if (AGG) {
             constexpr int NV = NVV;                    // upper bound; the real NV is NVV or NVV/2
