@@ -133,7 +133,8 @@ constexpr double REFTOL = 1e-11, REFETA = 1e-1 /* forcing term of the refinement
 // device-side problem description
 // (round 5: a unit may also hold designs of different ORDERS -- the probes of a min-order search: the dimensions that move with the
 //  order follow the six that move with the band edges)
-struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, Nt, N, nq3, big, D1, seg, useg, Mown /* dense path: the lane's own padded row count */, pad1, pad2; };
+struct LaneDims { int Mf, R, l, nyrows, nfold, nchunk, Nt, N, nq3, big, D1, seg, useg, Mown /* dense path: the lane's own padded row count */; double tmin /* the lane's lattice origin */; };
+static_assert(sizeof(LaneDims) == 64, "LaneDims: 14 ints + one double");
 struct DProg {
     int Nt, Ne, N, Mf, R, l, nq3, big, quad;
     int ld, Mpad, LDV, Rp, np;
@@ -194,6 +195,9 @@ struct DProg {
         // columns, which the factorisation passes through untouched (the same blocks see the same arithmetic as in the lane's
         // single solve at its own np; the padding blocks factorise to the identity)
         Nt = d.Nt; N = d.N; nq3 = d.nq3; big = d.big; D1 = d.D1; seg = d.seg; useg = d.useg; Mown = d.Mown;
+        // ... and its lattice origin (round 6: the centred delays of fir_qprog_phs / fir_qp_cvx start at -(n - 1) / 2; the origin enters the
+        // seed tables alone -- k_build_seeds_m / _e --, which every lane of such a unit builds for itself)
+        tmin = d.tmin;
     }
     template <class T>
     __device__ __forceinline__ static void sh(const T*& p, size_t off) { p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + off); }
@@ -640,9 +644,11 @@ __global__ __launch_bounds__(256) void k_trig_eval(DProg P, const double* __rest
 }
 
 // seed tables for the recurrences below (once per design)
-__global__ void k_build_seeds_m(DProg P, double t0a, int na, double t0b, int nb, double4* __restrict__ seeds) {
+// (the progressions start at ka * tmin and kb * tmin: the LANE's origin)
+__global__ void k_build_seeds_m(DProg P, double ka, int na, double kb, int nb, double4* __restrict__ seeds) {
     LANES(P, seeds);
     if (P.dims) { na = P.D1; nb = nb ? 2 * P.D1 - 1 : 0; }      // (the launch carries the unit's largest extent: the lane's own)
+    const double t0a = ka * P.tmin, t0b = kb * P.tmin;
     const int m = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
     if (m >= na + nb || ch >= P.nchunk) return;
     const double t = m < na ? t0a + m : t0b + (m - na);
@@ -3038,8 +3044,9 @@ static std::shared_ptr<LanePrep> lane_prep(const TrigProgram& Q, const SolveOpts
 std::vector<long> Solver::shape_key(const TrigProgram& Q, const SolveOpts& o) {
     const std::shared_ptr<LanePrep> pr = lane_prep(Q, o);
     const LatticeInfo& Lt = pr->Lt;
-    long tbits = 0;
-    std::memcpy(&tbits, &Lt.tmin, sizeof(double));
+    // (the lattice origin itself is a per-lane dimension since round 6 -- the centred delays of fir_qprog_phs / fir_qp_cvx move it with
+    //  the order --; what a unit shares is whether it is ZERO: then the border moments ride the difference progression, build_H's one_pass)
+    const long tbits = Lt.tmin == 0.0 ? 0 : 1;
     // the CLASS of the program: what all lanes of a unit must share (solve_lanes)
     // (round 5: designs of different ORDERS share a unit too -- the probes of a min-order search -- when their padded sizes fall into
     //  the same power-of-two bucket: a unit runs every lane at the size of its largest)
@@ -3213,9 +3220,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         const TrigProgram& Qb = *LH[b].Q;
         const LatticeInfo& Lb = LH[b].Lt;
         if (Qb.which != Q.which || Qb.Ne != Q.Ne || (Qb.nq3 > 0) != (Q.nq3 > 0) || (Qb.big > 0) != (Q.big > 0) || Qb.quad != Q.quad ||
-            Lb.ok != Lt.ok || Lb.tmin != Lt.tmin)
-            throw ShapeError("lock-step batch: lanes differ in class (designer, slack columns, cone kinds or lattice origin)");
-        if (Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.nq3 != Q.nq3 || Qb.big != Q.big || Lb.D1 != Lt.D1 || LH[b].c_rows.size() != LH[0].c_rows.size())
+            Lb.ok != Lt.ok || (Lb.tmin == 0.0) != (Lt.tmin == 0.0))
+            throw ShapeError("lock-step batch: lanes differ in class (designer, slack columns, cone kinds, lattice origin at zero or not)");
+        if (Qb.n != Q.n || Qb.Nt != Q.Nt || Qb.nq3 != Q.nq3 || Qb.big != Q.big || Lb.D1 != Lt.D1 || Lb.tmin != Lt.tmin || LH[b].c_rows.size() != LH[0].c_rows.size())
             hetero = orders = true;
         if (Qb.Mf != Q.Mf || Qb.R != Q.R || Qb.l != Q.l || LH[b].yrows.size() != LH[0].yrows.size() || Lb.ch_start.size() != Lt.ch_start.size() ||
             Lb.wf.size() != Lt.wf.size())
@@ -3261,7 +3268,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
         bool same = true;
         for (int b = 1; b < nlanes && same; ++b) {
             const LatticeInfo& Lb = LH[b].Lt;
-            same = Lb.D1 == Lt.D1 && Lb.wf == Lt.wf && Lb.ch_w0 == Lt.ch_w0 && Lb.ch_dw == Lt.ch_dw && Lb.ch_start == Lt.ch_start && Lb.ch_count == Lt.ch_count;
+            same = Lb.D1 == Lt.D1 && Lb.tmin == Lt.tmin && Lb.wf == Lt.wf && Lb.ch_w0 == Lt.ch_w0 && Lb.ch_dw == Lt.ch_dw && Lb.ch_start == Lt.ch_start && Lb.ch_count == Lt.ch_count;
         }
         P.seeds_shared = same ? 1 : 0;
     }
@@ -3282,7 +3289,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             const TrigProgram& Qb = *LH[b].Q;
             const int d1 = LH[b].Lt.D1, sg = seg_of(d1);
             S.hostDims[b] = LaneDims{Qb.Mf, Qb.R, Qb.l, int(LH[b].yrows.size()), int(LH[b].Lt.wf.size()), int(LH[b].Lt.ch_start.size()),
-                                     Qb.Nt, Qb.Nt + Qb.Ne, Qb.nq3, Qb.big, d1, sg, LH[b].Lt.ok ? cdiv(d1, sg) : 1, S.gps[b].Mpad, 0, 0};
+                                     Qb.Nt, Qb.Nt + Qb.Ne, Qb.nq3, Qb.big, d1, sg, LH[b].Lt.ok ? cdiv(d1, sg) : 1, S.gps[b].Mpad, LH[b].Lt.tmin};
         }
         MBFIR_HIP(hipMemcpyAsync(S.dimsT, S.hostDims, sizeof(LaneDims) * nlanes, hipMemcpyHostToDevice, st));
         P.dims = S.dimsT;
@@ -3445,9 +3452,9 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (!P.trig) hipLaunchKernelGGL(k_build_A1, lane_grid(dim3(cdiv(Nt, 256), Mf), nlanes), dim3(256), 0, st, P, S.A1);
     else {
         const int seed_lanes = P.seeds_shared ? 1 : nlanes;
-        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, P.tmin, P.D1, 0.0, 0,
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(P.D1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, 1.0, P.D1, 0.0, 0,
                            const_cast<double4*>(P.seed_tau));
-        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0 * P.tmin,
+        hipLaunchKernelGGL(k_build_seeds_m, lane_grid(dim3(cdiv(3 * P.D1 - 1, 256), P.nchunk), seed_lanes), dim3(256), 0, st, P, 0.0, P.D1, 2.0,
                            2 * P.D1 - 1, const_cast<double4*>(P.seed_h));
         hipLaunchKernelGGL(k_build_seeds_e, lane_grid(dim3(cdiv(P.nfold, 256), P.useg), seed_lanes), dim3(256), 0, st, P, const_cast<double4*>(P.seed_eval));
     }
