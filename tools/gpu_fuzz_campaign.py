@@ -10,7 +10,7 @@ from oracle import conic_ipm, designers
 import test_fuzz_gpu as F
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-bad, t0 = [], time.time()
+bad, illcond, t0 = [], [], time.time()
 counts = {}
 for seed in range(lo, hi):
     which, args = F.make_case(seed)
@@ -27,12 +27,21 @@ for seed in range(lo, hi):
             bad.append((seed, which, "objective %.12g vs %.12g" % (ig["pcost"], io["pcost"]))); continue
         clean = io["status"] == conic_ipm.STATUS_OPTIMAL and ig["relgap"] <= 1e-6
         if clean and np.max(np.abs(hg - ho)) > 1e-6 * max(np.max(np.abs(ho)), 1e-3):
-            bad.append((seed, which, "taps differ by %.3g (iters %d / %d)" % (np.max(np.abs(hg - ho)), ig["iters"], io["iters"])))
+            # how far apart are the CONIC solutions?  (fir_ap_cvx's taps are that solution seen through the spectral factorisation --
+            # the log of a spectrum that may touch 1e-20, fir_ap_cvx.m:281,296 --, which amplifies by up to 1e9 on some instances)
+            z = mbfir.get_context().last_solution(ig["n_unknowns"])
+            xo = np.asarray(io["x"]); nn = min(len(z), len(xo))
+            xd = float(np.abs(z[:nn] - xo[:nn]).max() / np.abs(xo[:nn]).max())
+            (illcond if xd <= 1e-9 else bad).append((seed, which, "taps differ by %.3g relative to the largest (iters %d / %d), conic solutions %.1e apart" % (
+                np.max(np.abs(hg - ho)) / max(np.max(np.abs(ho)), 1e-3), ig["iters"], io["iters"], xd)))
     if (seed - lo) % 50 == 49:
         print("seeds %d..%d done, %d failures so far, %.0f s" % (lo, seed, len(bad), time.time() - t0), flush=True)
-print("random specs %d..%d: %d failures; verdict counts %s" % (lo, hi - 1, len(bad), sorted(counts.items())))
+print("random specs %d..%d: %d failures, %d more with taps apart at conic solutions equal to 1e-9 (conditioning of the spectral factorisation); verdict counts %s" % (
+    lo, hi - 1, len(bad), len(illcond), sorted(counts.items())))
 for b in bad:
     print("  FAIL", b)
+for b in illcond:
+    print("  ill-conditioned taps", b)
 
 # ---- fir_qp_cvx the way dzrf_mb calls it (large k, obj): seeds qlo..qhi-1 of test_random_quadratic_phase_specs_with_large_peak_weights
 if len(sys.argv) > 4:
