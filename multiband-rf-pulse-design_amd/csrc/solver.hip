@@ -107,16 +107,18 @@ enum {
     S_ALPHA0, S_DTAU_C, S_DKAP_C, S_PICK, S_NCORR, S_NPICK,
     S_RNA = 40 /* 9 residual norms, batch solve */, S_RNB = 49 /* 9 residual norms, combined solve */,
     S_CG_RZ = 58 /* 2 */, S_CG_ALPHA = 60 /* 2 */, S_CG_BETA = 62 /* 2 */,
-    S_RNC = 64 /* 9 residual norms, corrector solve */, S_COUNT = 80
+    S_RNC = 64 /* 9 residual norms, corrector solve */, S_SIGMAX = 76 /* the cap on Mehrotra's sigma of this solve: SIGMA_MAX, or SIGMA_MAX_CORR where the centrality corrector runs */, S_COUNT = 80
 };
 constexpr double STEP = 0.99;
 constexpr double SIGMA_MAX = 0.25;   // cap of Mehrotra's centring parameter (oracle/conic_ipm.py SIGMA_MAX)
+constexpr double SIGMA_MAX_CORR = 0.05;      // ... where a centrality corrector follows the direction (oracle/conic_ipm.py SIGMA_MAX_CORR; MBFIR_SIGMA_MAX overrides it, a diagnostic)
 // one centrality corrector per iteration on the orthant rows (oracle/conic_ipm.py CORR_*)
 constexpr double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEPT = 1.01, CORR_ETA = 1.0;
 // end game: an iterate that meets the stopping rule is kept and the iteration goes on until the gap measures are POLISH times below
 // the tolerances, at most POLISH_MAX more iterations (oracle/conic_ipm.py POLISH*)
 constexpr double POLISH = 1e-2;
-constexpr int POLISH_MAX = 3, POLISH_SWEEPS = 2;     // (POLISH_SWEEPS: refinement sweeps on top of the controller's count during the end game)
+constexpr int POLISH_MAX = 3, POLISH_SWEEPS = 1;     // (POLISH_SWEEPS: refinement sweeps on top of the controller's count during the final approach and the end game)
+constexpr double POLISH_APPROACH = 30.0;              // ... the final approach: a gap measure within this factor of its tolerance (oracle/conic_ipm.py)
 constexpr int NPART = 1024;   // max blocks contributing to a reduction
 constexpr int SCAL_T = 256;   // threads of the one-workgroup-per-design folding kernels (a 1024-thread block has to wait for a
                               // whole CU when other units share the chip)
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(1024) void k_scal_step(DProg P, double* __restrict_
         if (mode == 0) {
             double a = t == 0.0 ? 1.0 : fmin(1.0, 1.0 / t);
             Sc[S_ALPHA_A] = a;
-            Sc[S_SIGMA] = fmin((1 - a) * (1 - a) * (1 - a), SIGMA_MAX);
+            Sc[S_SIGMA] = fmin((1 - a) * (1 - a) * (1 - a), Sc[S_SIGMAX]);
             sh[16] = Sc[S_SIGMA];
         } else if (mode == 2) {                           // the uncorrected direction's step, kept for the corrector: nothing moves yet
             Sc[S_ALPHA0] = t == 0.0 ? 1.0 : fmin(1.0, STEP / t);
@@ -1510,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_comb_rhs(DProg P, const double* __restr
         const double tau = Sc[S_TAU], kap = Sc[S_KAPPA];
         const double tt = fmax(0.0, fmax(fmax(ts, tz), fmax(-Sc[S_DTAU_A] / tau, -Sc[S_DKAP_A] / kap)));
         const double a = tt == 0.0 ? 1.0 : fmin(1.0, 1.0 / tt);
-        sigma = fmin((1 - a) * (1 - a) * (1 - a), SIGMA_MAX);
+        sigma = fmin((1 - a) * (1 - a) * (1 - a), Sc[S_SIGMAX]);
         if (blockIdx.x == 0) {
             if (threadIdx.x == 0) { Sc[S_TMAX] = tt; Sc[S_ALPHA_A] = a; Sc[S_SIGMA] = sigma; }
             for (int j = threadIdx.x; j < P.N; j += blockDim.x) bxc[j] = -(1.0 - sigma) * rx[j];
@@ -2251,6 +2253,9 @@ struct Solver::Impl {
     double *kbx, *kbz, *kx, *kz, *kg, *kds, *kdz;        // centrality corrector: right-hand side (kbx stays zero), solution / candidate, its direction
     bool corrector = true;       // one centrality corrector per iteration (MBFIR_CORRECTOR=0: off; programs without orthant rows never run it)
     bool corr_plain = true;      // ... its solve is the Cholesky solve alone (MBFIR_CORR_PLAIN=0, a diagnostic: with the refinement sweeps of the other solves)
+    double sigma_max_corr = SIGMA_MAX_CORR;      // (MBFIR_SIGMA_MAX, read once per solve)
+    double polish_approach = POLISH_APPROACH;    // (MBFIR_POLISH_APPROACH, a diagnostic)
+    int polish_sweeps = POLISH_SWEEPS;           // (MBFIR_POLISH_SWEEPS, a diagnostic: 0 = the controller's count alone)
     bool corr_big = true;        // ... the big cone's products are corrected too (MBFIR_CORR_BIG=0, a diagnostic: the orthant rows alone, round 6's first form)
     bool corr_guard = true;      // ... and a correction whose unrefined solve leaves more of the dual equation than the iterate's own residual is dropped (MBFIR_CORR_GUARD=0, a diagnostic: taken regardless)
     // dense row-sharded builds of a program with ONE weight matrix (fir_ap_cvx, fir_linprog): the Gram product goes in ar_chunks
@@ -2981,7 +2986,7 @@ struct LaneHost {
     LatticeInfo Lt;
     double nrm_h = 1, nrm_c = 1, degree = 0;
     // IPM state
-    int status = ST_MAXIT, nsweep = 0, wall = 0, iters = 0;
+    int status = ST_MAXIT, nsweep = 0 /* sweeps the iteration's solves run */, nsweep_ctl = 0 /* ... of which the controller asks for (the rest: POLISH_SWEEPS) */, wall = 0, iters = 0;
     bool live = true, have_best = false;
     double best_merit = 1e300, rx_prev = 0;
     SolveInfo info, best_info;
@@ -3164,6 +3169,12 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     if (const char* ev = std::getenv("MBFIR_CORR_GUARD")) S.corr_guard = std::atoi(ev) != 0;
     S.corr_big = true;
     if (const char* ev = std::getenv("MBFIR_CORR_BIG")) S.corr_big = std::atoi(ev) != 0;
+    S.polish_approach = POLISH_APPROACH;
+    if (const char* ev = std::getenv("MBFIR_POLISH_APPROACH")) S.polish_approach = std::max(1.0, std::atof(ev));
+    S.polish_sweeps = POLISH_SWEEPS;
+    if (const char* ev = std::getenv("MBFIR_POLISH_SWEEPS")) S.polish_sweeps = std::max(0, std::min(MAX_SWEEPS, std::atoi(ev)));
+    S.sigma_max_corr = SIGMA_MAX_CORR;
+    if (const char* ev = std::getenv("MBFIR_SIGMA_MAX")) S.sigma_max_corr = std::max(0.0, std::min(1.0, std::atof(ev)));
     S.test_cap_kp = 0;
     if (const char* ev = std::getenv("MBFIR_TEST_CAP_KP")) S.test_cap_kp = std::atoi(ev);
     S.ar_chunks = 0;         // 0: the build's own choice
@@ -3190,7 +3201,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
             L.f_ptr = pr->f_ptr; L.f_rows = pr->f_rows; L.c_ptr = pr->c_ptr; L.c_rows = pr->c_rows; L.yrows = pr->yrows; L.rep = pr->rep;
             L.Lt = pr->Lt;
         }
-        L.nsweep = o.refine;
+        L.nsweep = o.refine; L.nsweep_ctl = o.refine;
     }
     const TrigProgram& Q = *LH[0].Q;
     const LatticeInfo& Lt = LH[0].Lt;
@@ -3462,6 +3473,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     for (int b = 0; b < nlanes; ++b) {
         double* q = sc0.data() + (size_t)b * S_COUNT;
         q[S_NRMH] = LH[b].nrm_h; q[S_NRMC] = LH[b].nrm_c; q[S_DEG] = LH[b].degree; q[S_TAU] = 1.0; q[S_KAPPA] = 1.0;
+        q[S_SIGMAX] = (S.corrector && LH[b].Q->l > 0) ? S.sigma_max_corr : SIGMA_MAX;
         MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(S.Sc) + (size_t)b * S.lane_bytes, q, sizeof(double) * S_COUNT, hipMemcpyHostToDevice, st));
     }
     MBFIR_HIP(hipStreamSynchronize(st));
@@ -3613,8 +3625,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                     if (k < 0) unconverged = true;
                     else need = std::max(need, k);
                 }
-                L.nsweep = unconverged ? std::min(MAX_SWEEPS, L.nsweep + 1) : need;
-                if (L.first_opt >= 0) L.nsweep = std::min(MAX_SWEEPS, L.nsweep + POLISH_SWEEPS);      // end game (oracle/conic_ipm.py POLISH_SWEEPS)
+                L.nsweep_ctl = unconverged ? std::min(MAX_SWEEPS, L.nsweep + 1) : need;
             }
             L.rx_prev = hs[S_DRES] * hs[S_TAU] * hs[S_NRMC];
             info.iters = it; info.pcost = hs[S_PCOST]; info.dcost = hs[S_DCOST]; info.gap = hs[S_GAP];
@@ -3639,10 +3650,14 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
                     S.hostMask[ROW_BEST * MAX_LANES + b] = 1;
                     any_best = true;
                 }
-                if (L.first_opt < 0) { L.first_opt = it; L.nsweep = std::min(MAX_SWEEPS, L.nsweep + POLISH_SWEEPS); }
+                if (L.first_opt < 0) L.first_opt = it;
                 if (hs[S_GAP] <= POLISH * o.abstol || hs[S_RELGAP] <= POLISH * o.reltol) { finish(ST_OPTIMAL); continue; }
             }
             if (L.first_opt >= 0 && it >= L.first_opt + POLISH_MAX) { finish(ST_OPTIMAL); continue; }      // (whether or not this iterate still meets the rule)
+            {   // what this iteration's solves run: the controller's count, POLISH_SWEEPS more in the final approach and the end game
+                const bool approach = finite && (hs[S_GAP] <= S.polish_approach * o.abstol || hs[S_RELGAP] <= S.polish_approach * o.reltol);
+                L.nsweep = std::min(MAX_SWEEPS, L.nsweep_ctl + ((approach || L.first_opt >= 0) ? S.polish_sweeps : 0));
+            }
             if (!finite) { finish(ST_NUMERICAL); continue; }
             const bool collapsed = hs[S_KAPPA] / hs[S_TAU] >= 1e6;
             if (L.first_opt < 0 && (hs[S_PINF] <= o.feastol || (collapsed && hs[S_PINF] <= 1e-5))) { finish(ST_PRIMAL_INFEASIBLE); continue; }

@@ -31,6 +31,7 @@ import numpy as np
 
 STEP = 0.99
 SIGMA_MAX = 0.25              # cap of Mehrotra's centring parameter (see solve())
+SIGMA_MAX_CORR = 0.05         # ... where a centrality corrector follows the direction (programs with orthant rows; see solve())
 # one centrality corrector per iteration (J. Gondzio, "Multiple centrality corrections in a primal-dual method for linear
 # programming", Comput. Optim. Appl. 6, 1996), on the rows of the non-negative orthant: see solve()
 CORR_DELTA = 0.5              # the corrector aims at the step alpha + CORR_DELTA (capped at 1)
@@ -45,7 +46,8 @@ CORR_ETA = 1.0                # ... and its (unrefined) solve leaves no more tha
 # end game runs into POLISH_MAX either way); stopping the end game when an iteration gains less than a factor five was tried with it.
 POLISH = 1e-2
 POLISH_MAX = 3
-POLISH_SWEEPS = 2             # end game: refinement sweeps on top of the controller's count (see solve())
+POLISH_SWEEPS = 1             # final approach and end game: refinement sweeps on top of the controller's count (see solve())
+POLISH_APPROACH = 30.0         # ... the final approach: a gap measure within this factor of its tolerance
 STATUS_OPTIMAL = 0
 STATUS_PRIMAL_INFEASIBLE = 1
 STATUS_DUAL_INFEASIBLE = 2
@@ -621,6 +623,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
 
     # ---- initial point (W = I) ------------------------------------------
     nsweep = [int(refine)]
+    nsweep_ctl = int(refine)   # the sweep controller's count; nsweep[0] = what the solves of the iteration run (see POLISH_SWEEPS)
     H, cf = factor(None)
     X0, Z0, _ = kkt_solve(None, H, cf, np.stack([np.zeros(N), -c], 1), np.stack([h, np.zeros(R)], 1))
     x = X0[:, 0]                                            # min ||Gx-h||
@@ -696,11 +699,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             if opt_best[0] is None or merit_o < opt_best[0]:
                 opt_best = (merit_o, x / tau, dict(info), s / tau, z / tau)
             if first_opt is None:
-                # (the end game's solves are the worst conditioned of the whole iteration and the sweep controller answers one
-                #  iteration late: POLISH_SWEEPS more sweeps than it asks for, so that the iterate after the first one that met
-                #  the rule does not fail it by its dual residual -- fuzz seed 55, fir_qprog_phs: dres 5.7e-10 -> 1.7e-8)
                 first_opt = it
-                nsweep[0] = min(MAX_SWEEPS, nsweep[0] + POLISH_SWEEPS)
             if gap <= POLISH * abstol or relgap <= POLISH * reltol:
                 status = STATUS_OPTIMAL
                 break
@@ -708,6 +707,15 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             # (also when this iterate no longer meets the rule: the end game has had its iterations)
             status = STATUS_OPTIMAL
             break
+        # The solves of the final approach (a gap measure within POLISH_APPROACH of its tolerance) and of the end game are the worst
+        # conditioned of the whole iteration, mu falls by up to 100 x per iteration there (sigma ~ 1e-4), and the sweep controller
+        # answers one iteration late: POLISH_SWEEPS more sweeps than it asks for, so that an iterate does not miss the stopping
+        # rule by its dual residual when its gap is already there (fuzz seed 55, fir_qprog_phs: dres 5.7e-10 -> 1.7e-8 behind the
+        # first iterate that met the rule; a 29-tap fir_qprog_phs: 1.1e-9 -> 9.5e-8 one iteration BEFORE, then the numerical wall).
+        # Measured on the device, one box (tools/gpu_polish_ab2.py): no extra sweeps 305.6 designs/s on the headline batch and 17 of
+        # 600 fuzz designs retried in extended precision; + 2 from a factor 1000 on: 271.1 and none; + 1 from a factor 30 on: 298.6, none.
+        approach = finite and (gap <= POLISH_APPROACH * abstol or relgap <= POLISH_APPROACH * reltol)
+        nsweep[0] = min(MAX_SWEEPS, nsweep_ctl + (POLISH_SWEEPS if (approach or first_opt is not None) else 0))
         if not finite:
             status = STATUS_NUMERICAL
             break
@@ -778,7 +786,11 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
         # affine direction: lam \ (-lam o lam) = -lam, W lam = s  ->  bz = s - rz (in the batch above)
         dxa, dsa, dza, dta, dka, dssa, wdza = direction(0.0, -kappa * tau, XB[:, 1], ZB[:, 1], GB[:, 1])
         alpha_a = step_of(dssa, wdza, dta, dka, 1.0)
-        sigma = min((1.0 - alpha_a) ** 3, SIGMA_MAX)
+        # (the cap: 0.25 keeps Mehrotra's rule from over-centring -- measured in round 2 --; where the centrality corrector below looks
+        #  after the outliers itself, the direction can aim lower still: 0.05.  Nine S-C13 instances of 58 ... 200 taps in this oracle:
+        #  417 iterations at 0.25, 384 at 0.1, 365 at 0.05, 362 at 0.02, 346 at 0 -- and 433 ... 465 at 0.4 ... 1.0; the device's
+        #  headline batch 49.2 -> 41.6 iterations per design, no verdict of 800 fuzz specs changed: DESIGN.md section 5a)
+        sigma = min((1.0 - alpha_a) ** 3, SIGMA_MAX_CORR if (corrector and cone.l > 0) else SIGMA_MAX)
         ds_c = sigma * mu * e - ll - _cone_prod(cone, dssa, wdza)
         dk_c = sigma * mu - kappa * tau - dka * dta
         lds = _cone_div(cone, lam, ds_c)
@@ -849,9 +861,7 @@ def solve(c, G, h, l, nq3=0, big=0, max_iter=200, feastol=1e-8, abstol=1e-10,
             # driving the linear system's residual twelve digits below it -- the controller asks for REFETA * ||rx||
             # or the absolute floor, whichever is larger.  Same iterates at the end (the floor rules once ||rx|| is
             # small), 30-40 % fewer refinement sweeps over a solve.
-            nsweep[0] = next_sweeps(sweep_log, nsweep[0], max(REFTOL * nrm_c, REFETA * float(np.linalg.norm(rx))))
-            if first_opt is not None:
-                nsweep[0] = min(MAX_SWEEPS, nsweep[0] + POLISH_SWEEPS)
+            nsweep_ctl = next_sweeps(sweep_log, nsweep[0], max(REFTOL * nrm_c, REFETA * float(np.linalg.norm(rx))))
         if history is not None:
             sl_, zl_ = s[:cone.l], z[:cone.l]
             _ts, _tz = _max_step(cone, lam, dss), _max_step(cone, lam, wdz)

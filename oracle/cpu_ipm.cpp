@@ -22,9 +22,10 @@ namespace {
 
 typedef std::vector<double> vec;
 const double POLISH = 1e-2;      // conic_ipm.py: the end game
-const int POLISH_MAX = 3, POLISH_SWEEPS = 2;
+const int POLISH_MAX = 3, POLISH_SWEEPS = 1;
+const double POLISH_APPROACH = 30.0;      // conic_ipm.py: the final approach
 const double CORR_DELTA = 0.5, CORR_BMIN = 0.1, CORR_BMAX = 10.0, CORR_ACCEPT = 1.01, CORR_ETA = 1.0;      // conic_ipm.py: the centrality corrector
-const double STEP = 0.99, SIGMA_MAX = 0.25, REFTOL = 1e-11, REFETA = 1e-1, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
+const double STEP = 0.99, SIGMA_MAX = 0.25, SIGMA_MAX_CORR = 0.05 /* where the centrality corrector follows: programs with orthant rows (conic_ipm.py) */, REFTOL = 1e-11, REFETA = 1e-1, INACC_FEAS = 1e-6, INACC_GAP = 1.22e-4, PIVTOL = 1e-13;
 const int MAX_SWEEPS = 8, WALL_ITERS = 3, NB = 64;
 enum { ST_OPTIMAL = 0, ST_PINF = 1, ST_DINF = 2, ST_MAXIT = 3, ST_NUMERICAL = 4, ST_INACC = 5 };
 
@@ -356,7 +357,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
     vec H((size_t)N * N), B((size_t)R * Npad, 0.0), tmpR(R), tmpR2(R), tmpN(N), tmpN2(N);
     Scaling W;
     bool unit = true;
-    int chol_fixes = 0, nsweep = refine;
+    int chol_fixes = 0, nsweep = refine, nsweep_ctl = refine;      // (nsweep_ctl: the controller's count; nsweep: what the iteration's solves run)
     std::vector<vec> sweep_log;
     auto winv2 = [&](const double* v, double* out) { if (unit) std::memcpy(out, v, sizeof(double) * R); else W.inv2(v, out); };
     auto factor = [&]() {
@@ -496,10 +497,14 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
                 const double oi[6] = {pcost, dcost, gap, relgap, pres, dres};
                 std::memcpy(opt_info, oi, sizeof(oi));
             }
-            if (first_opt < 0) { first_opt = it; nsweep = std::min(MAX_SWEEPS, nsweep + POLISH_SWEEPS); }      // (conic_ipm.py: POLISH_SWEEPS)
+            if (first_opt < 0) first_opt = it;
             if (gap <= POLISH * abstol || relgap <= POLISH * reltol) { status = ST_OPTIMAL; break; }
         }
         if (first_opt >= 0 && it >= first_opt + POLISH_MAX) { status = ST_OPTIMAL; break; }      // (whether or not this iterate still meets the rule)
+        {   // final approach and end game: POLISH_SWEEPS sweeps on top of the controller's count (conic_ipm.py)
+            const bool approach = finite && (gap <= POLISH_APPROACH * abstol || relgap <= POLISH_APPROACH * reltol);
+            nsweep = std::min(MAX_SWEEPS, nsweep_ctl + ((approach || first_opt >= 0) ? POLISH_SWEEPS : 0));
+        }
         if (!finite) { status = ST_NUMERICAL; break; }
         const bool collapsed = kappa / tau >= 1e6;
         if (first_opt < 0 && (pinf <= feastol || (collapsed && pinf <= 1e-5))) { status = ST_PINF; break; }
@@ -551,7 +556,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         direction(0.0, -kappa * tau, x2.data(), z2.data(), g2.data(), dsa.data(), dza.data(), dssa.data(), wdza.data());
         const double dta = dtau, dka = dkap;
         const double alpha_a = step_of(dssa.data(), wdza.data(), 1.0);
-        const double sigma = std::min((1 - alpha_a) * (1 - alpha_a) * (1 - alpha_a), SIGMA_MAX);
+        const double sigma = std::min((1 - alpha_a) * (1 - alpha_a) * (1 - alpha_a), K.l > 0 ? SIGMA_MAX_CORR : SIGMA_MAX);
         cone_prod(K, lam.data(), lam.data(), ll.data());
         cone_prod(K, dssa.data(), wdza.data(), pr.data());
         for (int i = 0; i < R; ++i) dsc[i] = -ll[i] - pr[i];
@@ -609,8 +614,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
                 x2.swap(xk); ds.swap(dsk); dz.swap(dzk);
             } else { dtau = dtau0; dkap = dkap0; }
         }
-        nsweep = next_sweeps(std::max(REFTOL * nrm_c, REFETA * nrm2(rx.data(), N)));   // forcing term, see conic_ipm.py
-        if (first_opt >= 0) nsweep = std::min(MAX_SWEEPS, nsweep + POLISH_SWEEPS);
+        nsweep_ctl = next_sweeps(std::max(REFTOL * nrm_c, REFETA * nrm2(rx.data(), N)));   // forcing term, see conic_ipm.py
         for (int j = 0; j < N; ++j) x[j] += alpha * (x2[j] + dtau * x1[j]);
         for (int i = 0; i < R; ++i) { s[i] += alpha * ds[i]; z[i] += alpha * dz[i]; }
         tau += alpha * dtau; kappa += alpha * dkap;

@@ -55,6 +55,8 @@ def run(tag, **kw):
         assert r["status"] == 0, (nm, r["status"])
     print("%-44s iterations %s total %d, corrector solves %d -> cost ~ %.0f" % (tag, its, sum(its), solves, sum(its) * 1.0 + solves * 0.12), flush=True)
     for k in kw: setattr(mod, k, {"PROTO_K": 1, "PROTO_MULT": 0.0, "PROTO_GATE": 2.0, "CORR_DELTA": 0.5, "CORR_ACCEPT": 1.01, "CORR_BMIN": 0.1, "CORR_BMAX": 10.0}[k])
+if len(sys.argv) > 1 and sys.argv[1] == "sigma":
+    run = lambda *a, **k: None
 run("baseline (K=1, delta 0.5)")
 run("delta 0.3", CORR_DELTA=0.3)
 run("delta 0.2", CORR_DELTA=0.2)
@@ -69,3 +71,16 @@ run("K=2, delta 0.3", PROTO_K=2, CORR_DELTA=0.3)
 run("K=3, delta 0.3, while alpha<0.5", PROTO_K=3, CORR_DELTA=0.3, PROTO_GATE=0.5)
 run("box [0.3, 3]", CORR_BMIN=0.3, CORR_BMAX=3.0)
 run("box [0.03, 30]", CORR_BMIN=0.03, CORR_BMAX=30.0)
+# ---- the cap on Mehrotra's sigma (SIGMA_MAX = 0.25 in the product) ---------------------------------------------------------------
+_defaults = {"SIGMA_MAX": 0.25}
+def run2(tag, **kw):
+    for k, v in kw.items(): setattr(mod, k, v)
+    its = []
+    for nm, P in Ps:
+        r = mod.solve(P["c"], P["G"], P["h"], P["l"], P["nq3"], P["big"])
+        its.append(r["iters"] if r["status"] == 0 else -r["iters"])
+    print("%-44s iterations %s total %d" % (tag, its, sum(abs(v) for v in its)), flush=True)
+    for k in kw: setattr(mod, k, _defaults[k])
+if len(sys.argv) > 1 and sys.argv[1] == "sigma":
+    for sm in [float(v) for v in sys.argv[2:]] or (0.25, 0.4, 0.6, 0.8, 1.0):
+        run2("SIGMA_MAX %.2f" % sm, SIGMA_MAX=sm)
