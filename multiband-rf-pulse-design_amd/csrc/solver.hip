@@ -3473,7 +3473,7 @@ void Solver::solve_lanes(const std::vector<const TrigProgram*>& Qs, const SolveO
     for (int b = 0; b < nlanes; ++b) {
         double* q = sc0.data() + (size_t)b * S_COUNT;
         q[S_NRMH] = LH[b].nrm_h; q[S_NRMC] = LH[b].nrm_c; q[S_DEG] = LH[b].degree; q[S_TAU] = 1.0; q[S_KAPPA] = 1.0;
-        q[S_SIGMAX] = (S.corrector && LH[b].Q->l > 0) ? S.sigma_max_corr : SIGMA_MAX;
+        q[S_SIGMAX] = (S.corrector && LH[b].Q->l > 0 && LH[b].Q->big == 0) ? S.sigma_max_corr : SIGMA_MAX;      // (not with a big cone: oracle/conic_ipm.py)
         MBFIR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(S.Sc) + (size_t)b * S.lane_bytes, q, sizeof(double) * S_COUNT, hipMemcpyHostToDevice, st));
     }
     MBFIR_HIP(hipStreamSynchronize(st));

@@ -556,7 +556,7 @@ int cpu_ipm_solve(int R, int N, const double* G, const double* h, const double* 
         direction(0.0, -kappa * tau, x2.data(), z2.data(), g2.data(), dsa.data(), dza.data(), dssa.data(), wdza.data());
         const double dta = dtau, dka = dkap;
         const double alpha_a = step_of(dssa.data(), wdza.data(), 1.0);
-        const double sigma = std::min((1 - alpha_a) * (1 - alpha_a) * (1 - alpha_a), K.l > 0 ? SIGMA_MAX_CORR : SIGMA_MAX);
+        const double sigma = std::min((1 - alpha_a) * (1 - alpha_a) * (1 - alpha_a), (K.l > 0 && K.big == 0) ? SIGMA_MAX_CORR : SIGMA_MAX);
         cone_prod(K, lam.data(), lam.data(), ll.data());
         cone_prod(K, dssa.data(), wdza.data(), pr.data());
         for (int i = 0; i < R; ++i) dsc[i] = -ll[i] - pr[i];
