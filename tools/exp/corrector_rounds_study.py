@@ -55,7 +55,7 @@ def run(tag, **kw):
         assert r["status"] == 0, (nm, r["status"])
     print("%-44s iterations %s total %d, corrector solves %d -> cost ~ %.0f" % (tag, its, sum(its), solves, sum(its) * 1.0 + solves * 0.12), flush=True)
     for k in kw: setattr(mod, k, {"PROTO_K": 1, "PROTO_MULT": 0.0, "PROTO_GATE": 2.0, "CORR_DELTA": 0.5, "CORR_ACCEPT": 1.01, "CORR_BMIN": 0.1, "CORR_BMAX": 10.0}[k])
-if len(sys.argv) > 1 and sys.argv[1] == "sigma":
+if len(sys.argv) > 1 and sys.argv[1] in ("sigma", "after"):
     run = lambda *a, **k: None
 run("baseline (K=1, delta 0.5)")
 run("delta 0.3", CORR_DELTA=0.3)
@@ -84,3 +84,19 @@ def run2(tag, **kw):
 if len(sys.argv) > 1 and sys.argv[1] == "sigma":
     for sm in [float(v) for v in sys.argv[2:]] or (0.25, 0.4, 0.6, 0.8, 1.0):
         run2("SIGMA_MAX %.2f" % sm, SIGMA_MAX=sm)
+# ---- after the cap on sigma was lowered (final build): the other constants once more ---------------------------------------------
+if len(sys.argv) > 1 and sys.argv[1] == "after":
+    _defaults.update({"STEP": 0.99, "CORR_DELTA": 0.5, "CORR_BMIN": 0.1, "CORR_BMAX": 10.0, "CORR_ACCEPT": 1.01, "PROTO_K": 1, "PROTO_GATE": 2.0, "SIGMA_MAX_CORR": 0.05})
+    run2("final build")
+    run2("STEP 0.995", STEP=0.995)
+    run2("STEP 0.999", STEP=0.999)
+    run2("STEP 0.98", STEP=0.98)
+    run2("delta 0.3", CORR_DELTA=0.3)
+    run2("delta 0.7", CORR_DELTA=0.7)
+    run2("box [0.3, 3]", CORR_BMIN=0.3, CORR_BMAX=3.0)
+    run2("box [0.03, 30]", CORR_BMIN=0.03, CORR_BMAX=30.0)
+    run2("accept 1.0", CORR_ACCEPT=1.0)
+    run2("accept 1.1", CORR_ACCEPT=1.1)
+    run2("K=2", PROTO_K=2)
+    run2("cap 0.02", SIGMA_MAX_CORR=0.02)
+    run2("cap 0.1", SIGMA_MAX_CORR=0.1)
